@@ -1,0 +1,607 @@
+"""CPU oracle for the open-genie hot path.
+
+TEST INFRASTRUCTURE -- NOT PRODUCT CODE.  Only ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` may import this file; the product path (``open-genie_amd/``)
+never does and fails loudly when its HIP library is missing.
+
+What it is: a *functional* restatement (no ``nn.Module``; explicit ``state_dict`` + blueprint in,
+tensors out) of the reference's algorithm, in fp32 (or fp64 on request) on the CPU.  The reference
+delegates all arithmetic to PyTorch ATen (pinned ``torch==2.3.0``, requirements.txt:1-4; this image
+has torch 2.10) -- conv3d, group_norm, layer_norm, softmax, scaled-dot-product attention.  ATen *is*
+the reference's arithmetic provider, so the restatement calls the same ATen CPU primitives
+(``torch.nn.functional``) where the reference does and spells out everything the reference builds
+on top of them (padding arithmetic, rotary angles, the attention-scale quirk, LFQ bit packing, the
+loss expressions, MaskGIT scheduling) from its documented behaviour.  Every function cites the
+reference ``file:line`` it follows (paths relative to ``/root/reference``).
+
+Parity pinning: the reference holds NO golden vectors for this path -- its tests
+assert shapes only.  The oracle is therefore pinned against outputs of the reference itself:
+``tests/golden/make_golden.py`` imports the real reference in the build container and commits
+seeded input/output fixtures under ``tests/golden/``; ``tests/test_oracle_golden.py`` checks this
+file against them on every run, and ``tests/test_oracle_vs_reference.py`` checks it against the
+live reference whenever ``/root/reference`` is present.
+
+Known reference quirks reproduced on purpose are marked QUIRK.
+"""
+from __future__ import annotations
+
+import copy
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import Tensor
+
+SD = Dict[str, Tensor]
+
+
+def _triple(v) -> Tuple[int, int, int]:
+    return (v, v, v) if isinstance(v, int) else tuple(v)
+
+
+def _get(sd: SD, key: str) -> Optional[Tensor]:
+    return sd.get(key, None)
+
+
+# ----------------------------------------------------------------------------------------------
+# a1  CausalConv3d                                   genie/module/video.py:106-200
+# ----------------------------------------------------------------------------------------------
+def causal_pad_amounts(kernel_size, stride=(1, 1, 1), dilation=(1, 1, 1), padding=None):
+    """(time_front, height, width) zero padding.  video.py:154-164.
+
+    time pad = (kt-1)*dil_t + (1 - stride_t), all of it in FRONT (causal); h/w pad = (k-1)//2 on
+    both sides unless given.
+    """
+    kt, kh, kw = _triple(kernel_size)
+    st, _, _ = _triple(stride)
+    dt, _, _ = _triple(dilation)
+    if padding is None or isinstance(padding, int):
+        padding = (padding, padding)
+    tp = (kt - 1) * dt + (1 - st)
+    hp = padding[0] if padding[0] is not None else (kh - 1) // 2
+    wp = padding[1] if padding[1] is not None else (kw - 1) // 2
+    return tp, hp, wp
+
+
+def causal_conv3d(x: Tensor, w: Tensor, b: Optional[Tensor], stride=(1, 1, 1), dilation=(1, 1, 1),
+                  padding=None) -> Tensor:
+    """video.py:178-192: F.pad(x, (wp, wp, hp, hp, tp, 0)) then conv3d without padding."""
+    stride, dilation = _triple(stride), _triple(dilation)
+    tp, hp, wp = causal_pad_amounts(w.shape[2:], stride, dilation, padding)
+    x = F.pad(x, (wp, wp, hp, hp, tp, 0))
+    return F.conv3d(x, w, b, stride=stride, dilation=dilation)
+
+
+def conv3d_same(x: Tensor, w: Tensor, b: Optional[Tensor]) -> Tensor:
+    """nn.Conv3d(k, padding=(k-1)//2) as used by VideoResidualBlock (video.py:580-586, 614-620)
+    and the ST-block FFN (attention.py:429-438).  Symmetric zero padding: NOT causal (QUIRK 5)."""
+    pad = tuple((k - 1) // 2 for k in w.shape[2:])
+    return F.conv3d(x, w, b, padding=pad)
+
+
+# ----------------------------------------------------------------------------------------------
+# a3  GroupNorm / SiLU                               torch.nn.GroupNorm, torch.nn.SiLU
+# ----------------------------------------------------------------------------------------------
+def group_norm(x: Tensor, groups: int, w: Optional[Tensor], b: Optional[Tensor], eps: float = 1e-5) -> Tensor:
+    """Spelled-out group norm: per (sample, group) biased variance over (C/G, *spatial)."""
+    n, c = x.shape[:2]
+    xg = x.reshape(n, groups, -1)
+    mean = xg.mean(dim=-1, keepdim=True)
+    var = xg.var(dim=-1, unbiased=False, keepdim=True)
+    y = ((xg - mean) * torch.rsqrt(var + eps)).reshape(x.shape)
+    shape = (1, c) + (1,) * (x.dim() - 2)
+    if w is not None:
+        y = y * w.reshape(shape)
+    if b is not None:
+        y = y + b.reshape(shape)
+    return y
+
+
+def silu(x: Tensor) -> Tensor:
+    return x * torch.sigmoid(x)
+
+
+# ----------------------------------------------------------------------------------------------
+# a6  AdaptiveGroupNorm                              genie/module/norm.py:55-69
+# ----------------------------------------------------------------------------------------------
+def adaptive_group_norm(x: Tensor, cond: Tensor, sd: SD, prefix: str, num_groups: int, eps: float = 1e-5) -> Tensor:
+    """norm.py:55-69: group_norm(x) * Linear_std(mean_{t,h,w} cond) + Linear_avg(mean cond)."""
+    y = group_norm(x, num_groups, _get(sd, prefix + 'weight'), _get(sd, prefix + 'bias'), eps)
+    c = cond.reshape(cond.shape[0], cond.shape[1], -1).mean(-1)          # norm.py:62
+    std = F.linear(c, sd[prefix + 'std.weight'], sd[prefix + 'std.bias'])
+    shape = std.shape + (1,) * (x.dim() - 2)
+    y = y * std.reshape(shape)
+    if prefix + 'avg.weight' in sd:
+        avg = F.linear(c, sd[prefix + 'avg.weight'], sd[prefix + 'avg.bias'])
+        y = y + avg.reshape(shape)
+    return y
+
+
+# ----------------------------------------------------------------------------------------------
+# a7  BlurPooling3d                                  genie/module/video.py:22-56, 487-537
+# ----------------------------------------------------------------------------------------------
+def blur_kernel(kernel_size) -> Tensor:
+    """video.py:22-56.  Pascal-triangle taps, outer product over (t, h, w), normalised to sum 1.
+    QUIRK: the w taps use comb(kw-1, i) for i in range(kt) (video.py:47) -- identical for cubes."""
+    kt, kh, kw = _triple(kernel_size)
+    t = torch.tensor([math.comb(kt - 1, i) for i in range(kt)], dtype=torch.float32)
+    h = torch.tensor([math.comb(kt - 1, i) for i in range(kt)], dtype=torch.float32)
+    w = torch.tensor([math.comb(kw - 1, i) for i in range(kt)], dtype=torch.float32)
+    k = t[:, None, None] * h[None, :, None] * w[None, None, :]
+    return k / k.sum()
+
+
+def blur_pool3d(x: Tensor, kernel_size, time_factor: int, space_factor, num_groups: int = 1,
+                out_channels: Optional[int] = None) -> Tensor:
+    """video.py:516-534.  QUIRK 6: with num_groups=1 this is a DENSE conv whose every (out, in) tap
+    is the same blur kernel -> each output channel is the blur of the SUM over input channels."""
+    kt, kh, kw = _triple(kernel_size)
+    sf = (space_factor, space_factor) if isinstance(space_factor, int) else tuple(space_factor)
+    c = x.shape[1]
+    o = out_channels if out_channels is not None else c
+    ker = blur_kernel((kt, kh, kw)).to(x.dtype)
+    ker = ker[None, None].expand(o, c // num_groups, kt, kh, kw)
+    pad = ((kt - 1) // 2, (kh - 1) // 2, (kw - 1) // 2)
+    return F.conv3d(x, ker, stride=(time_factor, *sf), padding=pad, groups=num_groups)
+
+
+# ----------------------------------------------------------------------------------------------
+# a2  VideoResidualBlock                             genie/module/video.py:539-656
+# ----------------------------------------------------------------------------------------------
+def _act(name: str, x: Tensor) -> Tensor:
+    if name in ('swish', 'silu'):
+        return silu(x)
+    if name == 'relu':
+        return F.relu(x)
+    if name == 'gelu':
+        return F.gelu(x)
+    if name == 'leaky':
+        return F.leaky_relu(x)
+    raise ValueError(name)
+
+
+def video_residual_block(x: Tensor, sd: SD, prefix: str, in_channels: int, out_channels: Optional[int] = None,
+                         kernel_size=3, num_groups: int = 1, downsample=None, use_causal: bool = False,
+                         use_norm: bool = True, use_blur: bool = True, act_fn: str = 'swish', **_) -> Tensor:
+    """video.py:588-648: main = [GN, act, conv k, (down), GN, act, conv k]; res = [(down), conv 1].
+    QUIRK 5: plain (non-causal) convs and num_groups=1 by default; res always has the 1x1x1 conv."""
+    if isinstance(downsample, int):
+        downsample = (downsample, downsample)
+    ks = _triple(kernel_size)
+
+    def conv(t: Tensor, key: str) -> Tensor:
+        if use_causal:   # CausalConv3d wraps the conv as .conv3d and ignores the passed `padding`
+            w, b = sd[prefix + key + '.conv3d.weight'], _get(sd, prefix + key + '.conv3d.bias')
+            pad = tuple((k - 1) // 2 for k in w.shape[2:])
+            # video.py:580-586 passes padding=(pt, ph, pw); CausalConv3d reads padding[0], padding[1]
+            # as (height, width) pads (video.py:157-158): for the 1x1x1 res conv padding is None.
+            if w.shape[2:] == (1, 1, 1):
+                return causal_conv3d(t, w, b)
+            return causal_conv3d(t, w, b, padding=(pad[0], pad[1]))
+        return conv3d_same(t, sd[prefix + key + '.weight'], _get(sd, prefix + key + '.bias'))
+
+    def down(t: Tensor, key: str, ch: int) -> Tensor:
+        if downsample is None:
+            return t
+        tf, sf = downsample
+        if use_blur:
+            return blur_pool3d(t, ks, tf, sf, num_groups=num_groups)
+        w, b = sd[prefix + key + '.go_down.conv3d.weight'], _get(sd, prefix + key + '.go_down.conv3d.bias')
+        return causal_conv3d(t, w, b, stride=(tf, sf, sf))
+
+    def norm(t: Tensor, key: str) -> Tensor:
+        if not use_norm:
+            return t
+        return group_norm(t, num_groups, sd[prefix + key + '.weight'], sd[prefix + key + '.bias'])
+
+    out_channels = out_channels if out_channels is not None else in_channels
+    res = conv(down(x, 'res.0', in_channels), 'res.1')
+    h = conv(_act(act_fn, norm(x, 'main.0')), 'main.2')
+    h = down(h, 'main.3', out_channels)
+    h = conv(_act(act_fn, norm(h, 'main.4')), 'main.6')
+    return h + res
+
+
+# ----------------------------------------------------------------------------------------------
+# a4 / a5  SpaceTimeDownsample, DepthToSpaceTimeUpsample   video.py:457-483, 379-430
+# ----------------------------------------------------------------------------------------------
+def spacetime_downsample(x: Tensor, sd: SD, prefix: str, time_factor: int = 2, space_factor: int = 2, **_) -> Tensor:
+    w, b = sd[prefix + 'go_down.conv3d.weight'], _get(sd, prefix + 'go_down.conv3d.bias')
+    return causal_conv3d(x, w, b, stride=(time_factor, space_factor, space_factor))
+
+
+def depth_to_spacetime(y: Tensor, time_factor: int, space_factor: int) -> Tensor:
+    """'b (c p q r) t h w -> b c (t p) (h q) (w r)'  (video.py:403-408)."""
+    b, cpqr, t, h, w = y.shape
+    p, q, r = time_factor, space_factor, space_factor
+    c = cpqr // (p * q * r)
+    y = y.reshape(b, c, p, q, r, t, h, w).permute(0, 1, 5, 2, 6, 3, 7, 4)
+    return y.reshape(b, c, t * p, h * q, w * r)
+
+
+def depth2spacetime_upsample(x: Tensor, sd: SD, prefix: str, time_factor: int = 2, space_factor: int = 2, **_) -> Tensor:
+    w, b = sd[prefix + 'go_up.0.conv3d.weight'], _get(sd, prefix + 'go_up.0.conv3d.bias')
+    return depth_to_spacetime(causal_conv3d(x, w, b), time_factor, space_factor)
+
+
+# ----------------------------------------------------------------------------------------------
+# a8  LookupFreeQuantization                          genie/module/quantization.py:77-133
+# ----------------------------------------------------------------------------------------------
+def lfq_bit_mask(d: int) -> Tensor:
+    """quantization.py:72: MSB first (QUIRK 7)."""
+    return 2 ** torch.arange(d - 1, -1, -1)
+
+
+def lfq_codebook(d: int, num_codebook: int = 1) -> Tensor:
+    """quantization.py:74-75: code k -> {-1,+1}^d, bit i of k (MSB first) set -> +1."""
+    codes = torch.arange((2 ** d) * num_codebook)[:, None] & lfq_bit_mask(d)
+    return 2 * (codes != 0).float() - 1
+
+
+def lfq_indices_numpy(x: np.ndarray) -> np.ndarray:
+    """Integer part of LFQ in plain numpy: idx = sum_i (x[..., i] > 0) << (d-1-i)   (quantization.py:97-98).
+    x: (..., d) float.  Returns int64 (...)."""
+    d = x.shape[-1]
+    weights = (1 << np.arange(d - 1, -1, -1)).astype(np.int64)
+    return ((x > 0).astype(np.int64) * weights).sum(-1)
+
+
+def entropy(p: Tensor, eps: float = 1e-6) -> Tensor:
+    """quantization.py:17-28: the clamp is INSIDE the log only (QUIRK 7)."""
+    return -(p * torch.log(p.clamp(min=eps))).sum(dim=-1)
+
+
+def lfq_forward(x: Tensor, sd: SD, prefix: str, codebook_dim: int, num_codebook: int = 1, training: bool = False,
+                beta: float = 100., transpose: bool = False, commit_weight: float = 0.25,
+                entropy_weight: float = 0.1, diversity_weight: float = 1.):
+    """quantization.py:77-133.  Returns ((out, idxs), loss-or-None)."""
+    if transpose:
+        x = x.movedim(1, -1)                                   # 'b d ... -> b ... d'
+    lead = x.shape[:-1]
+    z = x.reshape(x.shape[0], -1, x.shape[-1])                 # pack 'b * d'
+    if prefix + 'proj_inp.weight' in sd:
+        z = F.linear(z, sd[prefix + 'proj_inp.weight'], _get(sd, prefix + 'proj_inp.bias'))
+    b, n, _ = z.shape
+    z = z.reshape(b, n, num_codebook, codebook_dim)
+    quant = torch.sign(z)                                      # sign(0) = 0 ...
+    mask = lfq_bit_mask(codebook_dim)
+    idxs = ((z > 0).to(torch.int32) * mask.to(torch.int32)).sum(-1)   # ... but the bit uses > 0
+    idxs = idxs.to(torch.int64)                                # einops-reduce sum of int32 -> int64
+    code = (z + (quant - z).detach()) if training else quant   # straight-through estimator
+    code = code.reshape(b, n, num_codebook * codebook_dim)
+    out = code
+    if prefix + 'proj_out.weight' in sd:
+        out = F.linear(code, sd[prefix + 'proj_out.weight'], _get(sd, prefix + 'proj_out.bias'))
+    out = out.reshape(*lead, out.shape[-1])
+    if transpose:
+        out = out.movedim(-1, 1)
+    idxs = idxs.reshape(*lead, num_codebook).squeeze()         # QUIRK 7: drops EVERY size-1 dim
+    if not training:
+        return (out, idxs), None
+    cb = lfq_codebook(codebook_dim, num_codebook).to(z.dtype)  # (K, d)
+    logits = 2 * torch.einsum('bncd,jd->bncj', z, cb)
+    prob = (logits * beta).softmax(dim=-1).reshape(b * n, num_codebook, -1)
+    avg_prob = prob.mean(dim=0)
+    inp_ent = entropy(prob).mean()
+    avg_ent = entropy(avg_prob).mean()
+    ent_loss = inp_ent + diversity_weight * avg_ent            # QUIRK 7: plus, not minus
+    commit = F.mse_loss(z, quant.detach(), reduction='mean')
+    loss = ent_loss * entropy_weight + commit * commit_weight
+    return (out, idxs), loss
+
+
+def lfq_entropy_terms_factored(z: Tensor, beta: float = 100., eps: float = 1e-6, split: Optional[int] = None):
+    """Exact factorisation of the LFQ entropy terms used by the HIP kernel (LFQ section).
+
+    softmax(2*beta * z.c) over c in {-1,+1}^d is a product of d independent two-point distributions,
+    so with the bits split into a high group (first `split` dims, MSB side) and a low group,
+    p[token, code] = A[token, hi(code)] * B[token, lo(code)].  The clamp inside the log prevents a
+    closed form, so the per-code terms are still enumerated -- but from A (x) B, never from an
+    N x 2^d logits matrix.  z: (N, d) fp.  Returns (inp_ent, avg_ent) as the reference defines them
+    for num_codebook == 1 (quantization.py:116-123)."""
+    n, d = z.shape
+    split = d // 2 if split is None else split
+    zz = z.double()
+
+    def part(zs: Tensor) -> Tensor:
+        cb = lfq_codebook(zs.shape[1]).double()
+        return ((2 * beta) * (zs @ cb.T)).softmax(-1)           # logits 2*z.c, times beta -> softmax
+
+    a, bb = part(zz[:, :split]), part(zz[:, split:])
+    inp = torch.zeros((), dtype=torch.float64)
+    for i in range(n):
+        p = torch.outer(a[i], bb[i]).reshape(-1)
+        inp = inp - (p * torch.log(p.clamp(min=eps))).sum()
+    inp_ent = inp / n
+    avg = (a.T @ bb / n).reshape(-1)
+    avg_ent = -(avg * torch.log(avg.clamp(min=eps))).sum()
+    return inp_ent, avg_ent
+
+
+# ----------------------------------------------------------------------------------------------
+# a9  RotaryEmbedding                                 genie/module/attention.py:17-103
+# ----------------------------------------------------------------------------------------------
+def rotary_freq(dim: int, kind: str, theta: float = 10000., max_freq: float = 10.) -> Tensor:
+    """attention.py:33-39."""
+    if kind == '1d':
+        return 1. / (theta ** (torch.arange(0, dim, 2)[: dim // 2].float() / dim))
+    if kind == '2d':
+        return torch.linspace(1., max_freq / 2, dim // 2) * math.pi
+    raise ValueError(kind)
+
+
+def rotary_apply(x: Tensor, freq: Tensor) -> Tensor:
+    """attention.py:48-100 for seq_dim=-2: x (..., S, C), freq (C/2,).
+
+    angle[s, 2i] = angle[s, 2i+1] = s * freq[i]; out[2i] = x[2i] cos - x[2i+1] sin,
+    out[2i+1] = x[2i+1] cos + x[2i] sin.  Rotation covers ALL C features (QUIRK 2); the position is
+    the flattened index along S -- for the '2d' kind too (the flattened h*w index)."""
+    s, c = x.shape[-2], x.shape[-1]
+    pos = torch.arange(s, dtype=freq.dtype)
+    ang = torch.repeat_interleave(pos[:, None] * freq[None, :], 2, dim=-1)       # (S, C)
+    assert ang.shape[-1] <= c, f'feature dimension {c} is not of sufficient size to rotate in all the positions {ang.shape[-1]}'
+    x1, x2 = x[..., 0::2], x[..., 1::2]
+    rot = torch.stack((-x2, x1), dim=-1).reshape(x.shape)
+    return (x * ang.cos() + rot * ang.sin()).to(x.dtype)
+
+
+# ----------------------------------------------------------------------------------------------
+# a10  Attention core                                  genie/module/attention.py:154-239
+# ----------------------------------------------------------------------------------------------
+def attention_core(x: Tensor, sd: SD, prefix: str, n_head: int, d_head: int, causal: bool, rotary_kind: Optional[str],
+                   cond: Optional[Tensor] = None, scale: Optional[float] = None) -> Tensor:
+    """x: (B', S, C) with C == n_head*d_head (QUIRK 3: to_q/to_k/to_v/to_out are Identity then).
+
+    attention.py:219-236: rotary (before the norm, QUIRK 2) -> LayerNorm -> q = k = v = that tensor
+    unless `cond` is given, in which case k = to_k(cond) and v = to_v(k) ... see below.
+    QUIRK 1: scale = n_head * d_head**-0.5 (attention.py:195)."""
+    c = n_head * d_head
+    if rotary_kind is not None:
+        x = rotary_apply(x, sd[prefix + 'embed.freq'])
+    q = F.layer_norm(x, (c,), sd[prefix + 'norm.weight'], sd[prefix + 'norm.bias'])
+    key = q if cond is None else cond
+    val = key                                                       # attention.py:222-223
+    # Adapter.forward attention.py:133-149: key = default(key, qry); val = default(val, key)
+    k = F.linear(key, sd[prefix + 'to_qkv.to_k.weight'], _get(sd, prefix + 'to_qkv.to_k.bias')) \
+        if prefix + 'to_qkv.to_k.weight' in sd else key
+    v = F.linear(val, sd[prefix + 'to_qkv.to_v.weight'], _get(sd, prefix + 'to_qkv.to_v.bias')) \
+        if prefix + 'to_qkv.to_v.weight' in sd else val
+
+    def heads(t: Tensor) -> Tensor:
+        return t.reshape(t.shape[0], t.shape[1], n_head, d_head).transpose(1, 2)
+
+    qh, kh, vh = heads(q), heads(k), heads(v)
+    scale = scale if scale is not None else n_head * d_head ** -0.5
+    att = torch.matmul(qh, kh.transpose(-1, -2)) * scale
+    if causal:
+        sq, sk = att.shape[-2:]
+        m = torch.ones(sq, sk, dtype=torch.bool).tril()              # SDPA is_causal: top-left aligned
+        att = att.masked_fill(~m, float('-inf'))
+    att = att.softmax(dim=-1)
+    out = torch.matmul(att, vh).transpose(1, 2).reshape(x.shape[0], x.shape[1], c)
+    return out
+
+
+def spatial_attention(video: Tensor, sd: SD, prefix: str, n_head: int, d_head: int, transpose: bool, embed: bool = True,
+                      cond: Optional[Tensor] = None, scale=None) -> Tensor:
+    """attention.py:279-307.  video (B, C, T, H, W) if transpose else (B, T, H, W, C)."""
+    x = video.permute(0, 2, 3, 4, 1) if transpose else video
+    b, t, h, w, c = x.shape
+    seq = x.reshape(b * t, h * w, c)
+    if cond is not None:
+        cond = cond.repeat_interleave(t, dim=0)                     # 'b hw c -> (b t) hw c'
+    out = attention_core(seq, sd, prefix, n_head, d_head, False, '2d' if embed else None, cond, scale)
+    out = out.reshape(b, t, h, w, c)
+    return out.permute(0, 4, 1, 2, 3) if transpose else out
+
+
+def temporal_attention(video: Tensor, sd: SD, prefix: str, n_head: int, d_head: int, transpose: bool, embed: bool = True,
+                       cond: Optional[Tensor] = None, scale=None) -> Tensor:
+    """attention.py:347-371.  Causal over T, one sequence per (b, h, w)."""
+    x = video.permute(0, 2, 3, 4, 1) if transpose else video           # b t h w c
+    b, t, h, w, c = x.shape
+    seq = x.permute(0, 2, 3, 1, 4).reshape(b * h * w, t, c)
+    if cond is not None:
+        cond = cond.repeat_interleave(h * w, dim=0)                 # 'b t c -> (b h w) t c'
+    out = attention_core(seq, sd, prefix, n_head, d_head, True, '1d' if embed else None, cond, scale)
+    out = out.reshape(b, h, w, t, c).permute(0, 3, 1, 2, 4)
+    return out.permute(0, 4, 1, 2, 3) if transpose else out
+
+
+# ----------------------------------------------------------------------------------------------
+# a12  SpaceTimeAttention block                        genie/module/attention.py:373-474
+# ----------------------------------------------------------------------------------------------
+def space_time_block(video: Tensor, sd: SD, prefix: str, n_head: int, d_head: int, transpose: bool = False,
+                     embed=True, kernel_size: int = 3, cond=None, scale=None, **_) -> Tensor:
+    """attention.py:456-474: x = space(x)+x; x = temp(x)+x; x = ffn(x)+x with
+    ffn = GroupNorm(n_head, C) -> Conv3d(C, C, k, padding=(k-1)//2, bias=False)  (QUIRK 4)."""
+    if not isinstance(cond, tuple):
+        cond = (cond, cond)
+    if isinstance(embed, bool):
+        embed = (embed, embed)
+    video = spatial_attention(video, sd, prefix + 'space_attn.', n_head, d_head, transpose, embed[0], cond[0], scale) + video
+    video = temporal_attention(video, sd, prefix + 'temp_attn.', n_head, d_head, transpose, embed[1], cond[1], scale) + video
+    x = video if transpose else video.permute(0, 4, 1, 2, 3)
+    y = group_norm(x, n_head, sd[prefix + 'ffn.1.net.0.weight'], sd[prefix + 'ffn.1.net.0.bias'])
+    y = conv3d_same(y, sd[prefix + 'ffn.1.net.1.0.weight'], _get(sd, prefix + 'ffn.1.net.1.0.bias'))
+    y = y if transpose else y.permute(0, 2, 3, 4, 1)
+    return y + video
+
+
+# ----------------------------------------------------------------------------------------------
+# blueprint walking                                    genie/module/__init__.py:71-93
+# ----------------------------------------------------------------------------------------------
+def expand_blueprint(blueprint) -> List[Tuple[str, dict, bool]]:
+    """One (name, kwargs, has_ext) per instantiated layer; pops has_ext / n_rep like the reference
+    (on a deep copy: the reference mutates the caller's dicts)."""
+    out = []
+    for desc in copy.deepcopy(list(blueprint)):
+        if isinstance(desc, str):
+            desc = (desc, {})
+        name, kw = desc
+        kw = dict(kw)
+        has_ext = kw.pop('has_ext', False)
+        n_rep = kw.pop('n_rep', 1)
+        out.extend([(name, kw, has_ext)] * n_rep)
+    return out
+
+
+def run_layer(name: str, kw: dict, x: Tensor, sd: SD, prefix: str, cond=None, use_cond: bool = False) -> Tensor:
+    if name == 'causal-conv3d':
+        return causal_conv3d(x, sd[prefix + 'conv3d.weight'], _get(sd, prefix + 'conv3d.bias'),
+                             stride=kw.get('stride', (1, 1, 1)), dilation=kw.get('dilation', (1, 1, 1)),
+                             padding=kw.get('padding', None))
+    if name == 'video-residual':
+        return video_residual_block(x, sd, prefix, **kw)
+    if name == 'spacetime_downsample':
+        return spacetime_downsample(x, sd, prefix, **kw)
+    if name == 'depth2spacetime_upsample':
+        return depth2spacetime_upsample(x, sd, prefix, **kw)
+    if name == 'group_norm':
+        return group_norm(x, kw['num_groups'], _get(sd, prefix + 'weight'), _get(sd, prefix + 'bias'), kw.get('eps', 1e-5))
+    if name == 'adaptive_group_norm':
+        return adaptive_group_norm(x, cond, sd, prefix, kw['num_groups'], kw.get('eps', 1e-5))
+    if name == 'silu':
+        return silu(x)
+    if name == 'space-time_attn':
+        return space_time_block(x, sd, prefix, cond=cond if use_cond else None, **kw)
+    raise ValueError(f'Unknown module name: {name}')
+
+
+# ----------------------------------------------------------------------------------------------
+# a13  VideoTokenizer                                  genie/tokenizer.py:307-387
+# ----------------------------------------------------------------------------------------------
+def tokenizer_encode(video: Tensor, sd: SD, enc_desc) -> Tensor:
+    x = video
+    for i, (name, kw, has_ext) in enumerate(expand_blueprint(enc_desc)):
+        x = run_layer(name, kw, x, sd, f'enc_layers.{i}.', cond=None, use_cond=has_ext)
+    return x
+
+
+def tokenizer_decode(quant: Tensor, sd: SD, dec_desc, cond: Optional[Tensor] = None) -> Tensor:
+    cond = quant if cond is None else cond                           # tokenizer.py:324
+    x = quant
+    for i, (name, kw, has_ext) in enumerate(expand_blueprint(dec_desc)):
+        x = run_layer(name, kw, x, sd, f'dec_layers.{i}.', cond=cond if has_ext else None, use_cond=has_ext)
+    return x
+
+
+def tokenizer_tokenize(video: Tensor, sd: SD, enc_desc, d_codebook: int, n_codebook: int = 1, beta: float = 100.):
+    """tokenizer.py:332-350 (eval-mode LFQ, transpose=True)."""
+    enc = tokenizer_encode(video, sd, enc_desc)
+    (q, idx), _ = lfq_forward(enc, sd, 'quant.', d_codebook, n_codebook, training=False, beta=beta, transpose=True)
+    return q, idx
+
+
+def tokenizer_forward_hotpath(video: Tensor, sd: SD, enc_desc, dec_desc, d_codebook: int, n_codebook: int = 1,
+                              beta: float = 100., quant_loss_weight: float = 1., **lfq_kw):
+    """R-fwd: tokenizer.py:352-387 with the GAN and perceptual terms omitted (they
+    cannot execute offline): loss = mse(rec, video) + quant_loss * w.  Training-mode LFQ."""
+    enc = tokenizer_encode(video, sd, enc_desc)
+    (q, idx), q_loss = lfq_forward(enc, sd, 'quant.', d_codebook, n_codebook, training=True, beta=beta,
+                                   transpose=True, **lfq_kw)
+    rec = tokenizer_decode(q, sd, dec_desc)
+    rec_loss = F.mse_loss(rec, video)
+    loss = rec_loss + q_loss * quant_loss_weight
+    return loss, (rec_loss, q_loss), rec, idx
+
+
+# ----------------------------------------------------------------------------------------------
+# a14-a16  DynamicsModel                               genie/dynamics.py:44-195
+# ----------------------------------------------------------------------------------------------
+def dynamics_forward(tokens: Tensor, act_id: Tensor, sd: SD, desc) -> Tuple[Tensor, Tensor]:
+    """dynamics.py:44-64.  tokens (B,T,H,W) int64, act_id (B,T) int64 -> logits (B,T,H,W,V)."""
+    x = F.embedding(tokens, sd['tok_emb.weight']) + F.embedding(act_id, sd['act_emb.0.weight'])[:, :, None, None, :]
+    for i, (name, kw, has_ext) in enumerate(expand_blueprint(desc)):
+        x = run_layer(name, kw, x, sd, f'dec_layers.{i}.')             # dynamics.py:59: no cond passed
+    logits = F.linear(x, sd['head.weight'], sd['head.bias'])
+    return logits, logits[:, -1]
+
+
+def dynamics_loss(tokens: Tensor, act_id: Tensor, mask: Tensor, sd: SD, desc, fill: int = 0) -> Tensor:
+    """dynamics.py:66-99 with an explicit mask.  QUIRK 9: targets are read AFTER masked_fill, so every
+    target equals `fill`; `mask.squeeze()` requires batch >= 2."""
+    tokens = torch.masked_fill(tokens, mask, fill)
+    logits, _ = dynamics_forward(tokens, act_id, sd, desc)
+    m = mask.squeeze()
+    return F.cross_entropy(logits[m].reshape(-1, logits.shape[-1]), tokens[m].reshape(-1))
+
+
+def maskgit_schedule(steps: int, shape: Sequence[int], which: str = 'linear') -> Tensor:
+    """dynamics.py:167-195."""
+    n = int(np.prod(shape))
+    t = torch.linspace(1, 0, steps)
+    if which == 'linear':
+        s = 1 - t
+    elif which == 'cosine':
+        s = torch.cos(t * math.pi * .5)
+    elif which == 'arccos':
+        s = torch.acos(t) / (math.pi * .5)
+    else:
+        raise ValueError(f'Unknown schedule type: {which}')
+    sch = ((s / s.sum()) * n).round().int().clamp(min=1)
+    sch[-1] += n - sch.sum()
+    return sch
+
+
+def sample_from_uniform(prob: Tensor, u: Tensor) -> Tensor:
+    """Inverse-CDF categorical sampling with an injected uniform ('hard parts'):
+    pred = #(cumsum(prob) <= u * total), clamped.  Stands in for torch.multinomial (dynamics.py:141),
+    whose RNG stream differs between devices; both the oracle and the HIP path use THIS rule so token
+    ids can be compared bit for bit.  prob (N, V) fp32, u (N,) in [0, 1)."""
+    cdf = prob.double().cumsum(-1)
+    thr = (u.double() * cdf[:, -1])[:, None]
+    return (cdf <= thr).sum(-1).clamp(max=prob.shape[-1] - 1)
+
+
+def dynamics_generate(tokens: Tensor, act_id: Tensor, sd: SD, desc, uniforms: Tensor, steps: int = 10,
+                      which: str = 'linear', temp: float = 1., masked_tok: int = 0) -> Tensor:
+    """dynamics.py:101-165 with injected noise.  uniforms: (steps, B*H*W).  QUIRK 9: painted codes are
+    never fed back into tok_id (dynamics.py:128,136)."""
+    b, t, h, w = tokens.shape
+    schedule = maskgit_schedule(steps, (h, w), which)
+    mask = torch.ones(b, h * w, dtype=torch.bool)
+    code = torch.full((b, h * w), masked_tok, dtype=tokens.dtype)
+    tok_id = torch.cat([tokens, code.reshape(b, 1, h, w)], dim=1)
+    act = torch.cat([act_id, torch.zeros(b, 1, dtype=act_id.dtype)], dim=1)
+    pred_tok = tok_id
+    for step, k in enumerate(schedule.tolist()):
+        if mask.sum() == 0:
+            break
+        _, logits = dynamics_forward(tok_id, act, sd, desc)
+        prob = torch.softmax(logits / temp, dim=-1).reshape(b * h * w, -1)
+        pred = sample_from_uniform(prob, uniforms[step])
+        conf = prob.gather(-1, pred[:, None]).reshape(b, h * w).clone()
+        conf[~mask] = -math.inf
+        idxs = torch.topk(conf, k=k, dim=-1).indices
+        vals = pred.reshape(b, -1).gather(-1, idxs).to(code.dtype)
+        code.scatter_(1, idxs, vals)
+        mask.scatter_(1, idxs, False)
+        pred_tok = torch.cat([tokens, code.reshape(b, 1, h, w)], dim=1)
+    assert mask.sum() == 0
+    return pred_tok
+
+
+# ----------------------------------------------------------------------------------------------
+# a17  LatentAction, repaired (R-lam)    genie/action.py:111-176
+# ----------------------------------------------------------------------------------------------
+def latent_action_forward(video: Tensor, sd: SD, enc_desc, dec_desc, d_codebook: int, training: bool = True,
+                          quant_loss_weight: float = 1., beta: float = 100.):
+    """action.py:111-176 with the three R-lam repairs applied by the CALLER's blueprint (transpose=True ST
+    blocks with n_head*d_head == n_embd, 'depth2spacetime_upsample', LFQ input_dim = d_codebook)."""
+    x = causal_conv3d(video, sd['proj_in.conv3d.weight'], _get(sd, 'proj_in.conv3d.bias'))
+    for i, (name, kw, _) in enumerate(expand_blueprint(enc_desc)):
+        x = run_layer(name, kw, x, sd, f'enc_layers.{i}.')
+    enc_video = x
+    b, c, t = x.shape[:3]
+    act = F.linear(x.permute(0, 2, 1, 3, 4).reshape(b, t, -1), sd['to_act.1.weight'])   # 'b c t ... -> b t (c ...)'
+    (q_act, idxs), q_loss = lfq_forward(act, sd, 'quant.', d_codebook, training=training, beta=beta, transpose=False)
+    y = enc_video
+    for i, (name, kw, has_ext) in enumerate(expand_blueprint(dec_desc)):
+        y = run_layer(name, kw, y, sd, f'dec_layers.{i}.', cond=(None, q_act if has_ext else None), use_cond=True)
+    recon = causal_conv3d(y, sd['proj_out.conv3d.weight'], _get(sd, 'proj_out.conv3d.bias'))
+    rec_loss = F.mse_loss(recon, video)
+    loss = rec_loss + (q_loss * quant_loss_weight if q_loss is not None else 0)
+    return idxs, loss, (rec_loss, q_loss), recon
