@@ -1,0 +1,172 @@
+/* genie_hip.h -- C ABI of libgenie_hip.so, the MI355X (gfx950) implementation of open-genie's hot path.
+ *
+ * The reference (myscience/open-genie) has no FFI/plugin layer: its hot path is a set of Python
+ * nn.Modules that call PyTorch ATen.  The drop-in seam is therefore the Python module registry
+ * (reference genie/module/__init__.py:23-93); this header is the boundary UNDER that seam -- what a
+ * maintainer's ctypes/cffi stub binds (INTEGRATION.md shows the stub).  Every entry point names the
+ * reference call site(s) it replaces.
+ *
+ * Conventions
+ *   - plain C: pointers are DEVICE pointers unless stated, sizes are explicit, no torch types.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  All functions only ENQUEUE
+ *     work; none synchronises, allocates or frees device memory -> safe inside hipGraph capture.
+ *   - return value: 0 = ok, <0 = error (GENIE_ERR_*); genie_last_error() returns the message for the
+ *     calling thread.
+ *   - activations are "CL": bf16, channels-last (N, T, H, W, Cp); the channel pitch Cp is a multiple
+ *     of 8 and pad channels [C, Cp) hold zeros.  A CL tensor is what torch calls a
+ *     (N, C, T, H, W) tensor in channels_last_3d strides.
+ *   - fp32 for parameters, statistics, accumulation and losses.
+ */
+#ifndef GENIE_HIP_H
+#define GENIE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GENIE_ABI_VERSION 1
+
+#define GENIE_F32 0
+#define GENIE_BF16 1
+
+#define GENIE_ERR_ARG (-1)
+#define GENIE_ERR_HIP (-2)
+
+int genie_abi_version(void);
+const char* genie_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Layout conversion at the model boundary.
+ * replaces: the implicit NCTHW fp32 tensors the reference feeds to nn.Conv3d (video.py:185-192) and
+ *           returns from VideoTokenizer.decode (tokenizer.py:319-330).
+ * dims = {N, C, T, H, W}; strides in ELEMENTS of the strided tensor, same order.
+ * ------------------------------------------------------------------------------------------- */
+int genie_to_channels_last(const void* src, int src_dtype, const int64_t* dims, const int64_t* strides,
+                           void* dst_cl, int cpitch, void* stream);
+int genie_from_channels_last(const void* src_cl, int cpitch, const int64_t* dims, void* dst, int dst_dtype,
+                             const int64_t* strides, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Conv3d family as one gather-GEMM (conv_igemm.hip).
+ * replaces: F.pad + nn.Conv3d in CausalConv3d.forward (video.py:178-192), nn.Conv3d in
+ *           VideoResidualBlock (video.py:580-620) and the ST-block FFN (attention.py:429-438),
+ *           SpaceTimeDownsample (video.py:457-483), DepthToSpaceTimeUpsample conv + Rearrange
+ *           (video.py:396-408), and their autograd backward-data passes.
+ *
+ *   D[m][n] = sum_taps sum_{c<nch} SRC[pix(m)*step + (dt,dh,dw)][c0 + c] * WGT[row(n)][wofs + c]
+ *   dest element = DST[(pix(m) * dm + do + subpixel(n / shuf_c))][n % shuf_c]  (+ bias, + resid)
+ * ------------------------------------------------------------------------------------------- */
+typedef struct GenieTap {
+    int32_t dt, dh, dw; /* source coordinate offset of this tap                              */
+    int32_t wofs;       /* element offset of this tap's K segment inside a weight row        */
+    int32_t c0;         /* first source channel                                              */
+    int32_t nch;        /* channels (multiple of 8)                                          */
+    int32_t pad0, pad1;
+} GenieTap;
+
+typedef struct GenieConvDesc {
+    const void* src;      /* CL bf16 (N, Ts, Hs, Ws, Cs)                                       */
+    const void* wgt;      /* bf16 rows, K-contiguous segments (see genie_pack_weight)          */
+    void* dst;            /* CL bf16 (N, Td, Hd, Wd, Cd)                                       */
+    const void* resid;    /* optional CL bf16, same geometry as dst: added in the epilogue     */
+    const float* bias;    /* optional fp32 [Ncols], indexed by the NATURAL weight row          */
+    const GenieTap* taps; /* DEVICE pointer, ntaps entries                                     */
+    int32_t ntaps;
+    int32_t nk;           /* sum over taps of ceil(nch / 64) (ignored when small_c)            */
+    int32_t small_c;      /* 1: Cs in {8,16,32}, taps packed back to back inside 64-wide K chunks;
+                             needs nch == Cs, c0 == 0 and wofs == tap * Cs for every tap        */
+    int32_t N, Ts, Hs, Ws, Cs;
+    int32_t To, Ho, Wo;   /* row grid                                                          */
+    int32_t st, sh, sw;   /* source step per row-grid step                                     */
+    int32_t Ncols;        /* GEMM N = number of weight rows used                               */
+    int32_t w_row_stride; /* elements between weight rows                                      */
+    int32_t perm_c, perm_f; /* weight row of column n = (n % perm_c) * perm_f + n / perm_c; perm_f<=1: identity */
+    int32_t Td, Hd, Wd, Cd;
+    int32_t dmt, dmh, dmw; /* dest coordinate = row-grid coordinate * dm + do (+ sub-pixel)    */
+    int32_t dot, doh, dow;
+    int32_t shuf_c, shuf_q, shuf_r; /* column n -> sub-pixel (p,q,r) = unravel(n / shuf_c, (P, shuf_q, shuf_r)), channel n % shuf_c;
+                                       no shuffle: shuf_c >= Ncols, shuf_q = shuf_r = 1          */
+    int32_t act;          /* epilogue activation: 0 none, 1 SiLU                               */
+} GenieConvDesc;
+
+int genie_conv_igemm(const GenieConvDesc* desc, void* stream);
+
+/* Weight gradient: dW[row(n)][tap][c] += sum_m DY[dpix(m)][n'] * SRC[pix(m)*step + off_tap][c]
+ * replaces: the weight/bias gradient of nn.Conv3d computed by autograd for every conv above.
+ * Accumulates with fp32 atomics into a strided fp32 gradient (any layout: pass element strides). */
+typedef struct GenieWgradDesc {
+    const void* src;      /* CL bf16 (N, Ts, Hs, Ws, Cs): the conv INPUT                        */
+    const void* dy;       /* CL bf16 (N, Td, Hd, Wd, Cd): gradient of the conv OUTPUT           */
+    float* dw;            /* fp32, element (cout, tap, cin) at cout*s_cout + tap*s_tap + cin*s_cin */
+    float* dbias;         /* optional fp32 [Cout]                                               */
+    const GenieTap* taps; /* DEVICE pointer: dt/dh/dw per tap (wofs/c0/nch unused)              */
+    int32_t ntaps;
+    int32_t N, Ts, Hs, Ws, Cs, Cin;
+    int32_t To, Ho, Wo, st, sh, sw;
+    int32_t Td, Hd, Wd, Cd, Cout;
+    int32_t dmt, dmh, dmw, dot, doh, dow;
+    int32_t shuf_c, shuf_q, shuf_r;
+    int64_t s_cout, s_tap, s_cin;
+    int32_t split_k;      /* 0 = choose */
+} GenieWgradDesc;
+
+int genie_conv_wgrad(const GenieWgradDesc* desc, void* stream);
+
+/* Strided fp32 (R, J, K) -> dense bf16 [R][J][roundup8(K)], zero padded; optional K permutation
+ * natural k = (k' % perm_c) * perm_f + k' / perm_c.  Builds the forward pack (R=cout, J=tap, K=cin) and the
+ * transposed pack for dgrad (R=cin, J=tap, K=cout) from an nn.Conv3d weight in any strides. */
+int genie_pack_weight(const float* src, void* dst, int R, int J, int K, int64_t sR, int64_t sJ, int64_t sK,
+                      int perm_c, int perm_f, void* stream);
+int genie_cast_f32_to_bf16(const float* src, void* dst, int64_t numel, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * GroupNorm (+ optional adaptive scale/shift, + optional SiLU), forward and backward (norm.hip).
+ * replaces: nn.GroupNorm + nn.SiLU (video.py:578-579, 612-613; tokenizer.py descs 'group_norm','silu'),
+ *           AdaptiveGroupNorm.forward (norm.py:55-69), ForwardBlock's GroupNorm (misc.py:92).
+ *   y = act( ((x - mean[n,g]) * rstd[n,g] * gamma[c] + beta[c]) * ada_scale[n,c] + ada_shift[n,c] )
+ * Workspaces are caller-owned device fp32 buffers; sizes from genie_groupnorm_ws_floats().
+ * ------------------------------------------------------------------------------------------- */
+int64_t genie_groupnorm_ws_floats(int N, int C, int G);
+int genie_groupnorm_fwd(const void* x, void* y, int N, int64_t npix, int C, int cpitch, int G, const float* gamma,
+                        const float* beta, const float* ada_scale, const float* ada_shift, float eps, int act,
+                        float* mean, float* rstd, float* ws, void* stream);
+/* dgamma/dbeta (fp32 [C]) are ACCUMULATED; dada_scale/dada_shift (fp32 [N][C]) are written. */
+int genie_groupnorm_bwd(const void* x, const void* dy, void* dx, int N, int64_t npix, int C, int cpitch, int G,
+                        const float* gamma, const float* beta, const float* ada_scale, const float* ada_shift, int act,
+                        const float* mean, const float* rstd, float* dgamma, float* dbeta, float* dada_scale,
+                        float* dada_shift, float* ws, void* stream);
+
+int genie_silu_fwd(const void* x, void* y, int64_t numel, void* stream);
+int genie_silu_bwd(const void* x, const void* dy, void* dx, int64_t numel, void* stream);
+int genie_add(const void* a, const void* b, void* y, int64_t numel, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Lookup-free quantisation (lfq.hip).   replaces: LookupFreeQuantization.forward, quantization.py:77-133
+ * z: (ntok, pitch) rows holding num_codebook*codebook_dim values; idx: int64 (ntok, num_codebook),
+ * MSB-first bit order; quant = sign(z) (may be NULL).
+ * ------------------------------------------------------------------------------------------- */
+int genie_lfq_quantize(const void* z, int dtype, int64_t ntok, int num_codebook, int codebook_dim, int64_t pitch,
+                       void* quant, int64_t* idx, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Losses and optimiser (elementwise.hip).
+ * replaces: F.mse_loss (tokenizer.py:364, action.py:166) and torch.optim.AdamW (tokenizer.py:437-442).
+ * ------------------------------------------------------------------------------------------- */
+int genie_mse_fwd(const void* rec_cl, int cpitch, const void* target, int target_dtype, const int64_t* dims,
+                  const int64_t* strides, float* partial_ws /* >= 1024 floats */, float* loss, void* stream);
+int genie_mse_bwd(const void* rec_cl, int cpitch, const void* target, int target_dtype, const int64_t* dims,
+                  const int64_t* strides, const float* grad_loss /* device scalar or NULL (=1) */, void* drec_cl,
+                  void* stream);
+int genie_adamw_step(float* p, float* g, float* m, float* v, int64_t numel, float lr, float beta1, float beta2, float eps,
+                     float weight_decay, int step, float grad_scale, int zero_grad, void* stream);
+
+/* Debug / bring-up probes (used by tests only). */
+int genie_probe_ds_read_tr16(const void* lds_image_u16_2048, const int32_t* lane_byte_addr_64, void* out_u16_64x4,
+                             void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GENIE_HIP_H */

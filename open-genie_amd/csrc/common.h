@@ -1,0 +1,83 @@
+// Shared device/host helpers for the genie HIP library (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+typedef uint16_t bf16_t;   // raw bfloat16 bits
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;   // MFMA A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) short bf16x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;  // 32x32 MFMA accumulator
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;    // 16x16 MFMA accumulator
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+
+#define GENIE_OK 0
+#define GENIE_ERR_ARG (-1)
+#define GENIE_ERR_HIP (-2)
+
+void genie_set_error(const char* fmt, ...);
+
+#define GENIE_CHECK_ARG(cond, ...)                      \
+    do {                                                \
+        if (!(cond)) {                                  \
+            genie_set_error(__VA_ARGS__);               \
+            return GENIE_ERR_ARG;                       \
+        }                                               \
+    } while (0)
+
+#define GENIE_CHECK_LAUNCH()                                                        \
+    do {                                                                            \
+        hipError_t e__ = hipGetLastError();                                         \
+        if (e__ != hipSuccess) {                                                    \
+            genie_set_error("%s:%d: HIP launch failed: %s", __FILE__, __LINE__,     \
+                            hipGetErrorString(e__));                                \
+            return GENIE_ERR_HIP;                                                   \
+        }                                                                           \
+    } while (0)
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+
+// round-to-nearest-even, NaN preserved (same rule as torch's float -> bfloat16)
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+__device__ __forceinline__ void unpack8(const u32x4_t v, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f[2 * i] = __uint_as_float(v[i] << 16);
+        f[2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u);
+    }
+}
+
+__device__ __forceinline__ u32x4_t pack8(const float* f) {
+    u32x4_t v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = pack_bf16x2(f[2 * i], f[2 * i + 1]);
+    return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ float silu_f(float z) { return z / (1.f + __expf(-z)); }
+// d silu(z) / dz = s (1 + z (1 - s)),  s = sigmoid(z)
+__device__ __forceinline__ float silu_grad_f(float z) {
+    float s = 1.f / (1.f + __expf(-z));
+    return s * (1.f + z * (1.f - s));
+}
+
+static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,409 @@
+// HBM-bound elementwise / reduction kernels: layout conversion at the model boundary, SiLU,
+// residual add, MSE loss, fused AdamW, fp32 -> bf16 weight packing.
+//
+// Internal activation layout ("CL"): bf16, channels-last (N, T, H, W, Cp) with the channel pitch
+// Cp a multiple of 8 (16 B), pad channels kept at zero.  Every kernel here moves 16 B per lane.
+#include "common.h"
+#include "genie_hip.h"
+
+// ------------------------------------------------------------------------------------------------
+// strided (fp32 | bf16) NCTHW  ->  CL bf16        one lane = one pixel x 8 channels
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ float load_as_f32(const T* p);
+template <>
+__device__ __forceinline__ float load_as_f32<float>(const float* p) { return *p; }
+template <>
+__device__ __forceinline__ float load_as_f32<bf16_t>(const bf16_t* p) { return bf16_to_f32(*p); }
+
+template <typename T>
+__global__ void __launch_bounds__(256) to_cl_kernel(const T* __restrict__ src, bf16_t* __restrict__ dst,
+                                                    int N, int C, int T_, int H, int W, long long sN, long long sC,
+                                                    long long sT, long long sH, long long sW, int Cp) {
+    const long long npix = (long long)N * T_ * H * W;
+    const int nchunk = Cp >> 3;
+    const long long total = npix * nchunk;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        // pixel fastest within a chunk plane: lanes read consecutive w for one channel (coalesced for NCTHW)
+        const long long pix = i % npix;
+        const int chunk = (int)(i / npix);
+        long long r = pix;
+        const int w = (int)(r % W); r /= W;
+        const int h = (int)(r % H); r /= H;
+        const int t = (int)(r % T_); r /= T_;
+        const int n = (int)r;
+        const T* base = src + n * sN + t * sT + h * sH + w * sW;
+        float f[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = chunk * 8 + j;
+            f[j] = c < C ? load_as_f32<T>(base + c * sC) : 0.f;
+        }
+        *reinterpret_cast<u32x4_t*>(dst + pix * Cp + chunk * 8) = pack8(f);
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void store_from_f32(T* p, float v);
+template <>
+__device__ __forceinline__ void store_from_f32<float>(float* p, float v) { *p = v; }
+template <>
+__device__ __forceinline__ void store_from_f32<bf16_t>(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+
+template <typename T>
+__global__ void __launch_bounds__(256) from_cl_kernel(const bf16_t* __restrict__ src, T* __restrict__ dst, int N, int C,
+                                                      int T_, int H, int W, long long sN, long long sC, long long sT,
+                                                      long long sH, long long sW, int Cp) {
+    const long long npix = (long long)N * T_ * H * W;
+    const int nchunk = (C + 7) >> 3;
+    const long long total = npix * nchunk;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long pix = i % npix;
+        const int chunk = (int)(i / npix);
+        long long r = pix;
+        const int w = (int)(r % W); r /= W;
+        const int h = (int)(r % H); r /= H;
+        const int t = (int)(r % T_); r /= T_;
+        const int n = (int)r;
+        float f[8];
+        unpack8(*reinterpret_cast<const u32x4_t*>(src + pix * Cp + chunk * 8), f);
+        T* base = dst + n * sN + t * sT + h * sH + w * sW;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = chunk * 8 + j;
+            if (c < C) store_from_f32<T>(base + c * sC, f[j]);
+        }
+    }
+}
+
+static int ew_grid(long long total) {
+    long long b = (total + 255) / 256;
+    if (b > 2048) b = 2048;   // 256 CUs x 8 blocks: grid-stride the rest
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+extern "C" int genie_to_channels_last(const void* src, int src_dtype, const int64_t* dims, const int64_t* strides, void* dst,
+                                      int cpitch, void* stream) {
+    GENIE_CHECK_ARG(src && dst && dims && strides, "genie_to_channels_last: null pointer");
+    GENIE_CHECK_ARG(cpitch % 8 == 0 && cpitch >= dims[1], "genie_to_channels_last: channel pitch %d must be a multiple of 8 and >= C=%lld", cpitch, (long long)dims[1]);
+    const int N = (int)dims[0], C = (int)dims[1], T = (int)dims[2], H = (int)dims[3], W = (int)dims[4];
+    const long long total = (long long)N * T * H * W * (cpitch / 8);
+    if (total == 0) return GENIE_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (src_dtype == GENIE_F32)
+        to_cl_kernel<float><<<ew_grid(total), 256, 0, s>>>((const float*)src, (bf16_t*)dst, N, C, T, H, W, strides[0], strides[1], strides[2], strides[3], strides[4], cpitch);
+    else if (src_dtype == GENIE_BF16)
+        to_cl_kernel<bf16_t><<<ew_grid(total), 256, 0, s>>>((const bf16_t*)src, (bf16_t*)dst, N, C, T, H, W, strides[0], strides[1], strides[2], strides[3], strides[4], cpitch);
+    else
+        GENIE_CHECK_ARG(false, "genie_to_channels_last: unsupported dtype %d", src_dtype);
+    GENIE_CHECK_LAUNCH();
+    return GENIE_OK;
+}
+
+extern "C" int genie_from_channels_last(const void* src, int cpitch, const int64_t* dims, void* dst, int dst_dtype,
+                                        const int64_t* strides, void* stream) {
+    GENIE_CHECK_ARG(src && dst && dims && strides, "genie_from_channels_last: null pointer");
+    GENIE_CHECK_ARG(cpitch % 8 == 0 && cpitch >= dims[1], "genie_from_channels_last: bad channel pitch %d", cpitch);
+    const int N = (int)dims[0], C = (int)dims[1], T = (int)dims[2], H = (int)dims[3], W = (int)dims[4];
+    const long long total = (long long)N * T * H * W * ((C + 7) / 8);
+    if (total == 0) return GENIE_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (dst_dtype == GENIE_F32)
+        from_cl_kernel<float><<<ew_grid(total), 256, 0, s>>>((const bf16_t*)src, (float*)dst, N, C, T, H, W, strides[0], strides[1], strides[2], strides[3], strides[4], cpitch);
+    else if (dst_dtype == GENIE_BF16)
+        from_cl_kernel<bf16_t><<<ew_grid(total), 256, 0, s>>>((const bf16_t*)src, (bf16_t*)dst, N, C, T, H, W, strides[0], strides[1], strides[2], strides[3], strides[4], cpitch);
+    else
+        GENIE_CHECK_ARG(false, "genie_from_channels_last: unsupported dtype %d", dst_dtype);
+    GENIE_CHECK_LAUNCH();
+    return GENIE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// SiLU forward / backward and a + b on flat bf16 buffers (numel multiple of 8)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) silu_fwd_kernel(const u32x4_t* __restrict__ x, u32x4_t* __restrict__ y, long long n16) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long long)gridDim.x * blockDim.x) {
+        float f[8];
+        unpack8(x[i], f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = silu_f(f[j]);
+        y[i] = pack8(f);
+    }
+}
+
+__global__ void __launch_bounds__(256) silu_bwd_kernel(const u32x4_t* __restrict__ x, const u32x4_t* __restrict__ dy,
+                                                       u32x4_t* __restrict__ dx, long long n16) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long long)gridDim.x * blockDim.x) {
+        float f[8], g[8];
+        unpack8(x[i], f);
+        unpack8(dy[i], g);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g[j] *= silu_grad_f(f[j]);
+        dx[i] = pack8(g);
+    }
+}
+
+__global__ void __launch_bounds__(256) add_kernel(const u32x4_t* __restrict__ a, const u32x4_t* __restrict__ b,
+                                                  u32x4_t* __restrict__ y, long long n16) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long long)gridDim.x * blockDim.x) {
+        float f[8], g[8];
+        unpack8(a[i], f);
+        unpack8(b[i], g);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] += g[j];
+        y[i] = pack8(f);
+    }
+}
+
+extern "C" int genie_silu_fwd(const void* x, void* y, int64_t numel, void* stream) {
+    GENIE_CHECK_ARG(numel % 8 == 0, "genie_silu_fwd: numel %lld not a multiple of 8", (long long)numel);
+    if (numel == 0) return GENIE_OK;
+    silu_fwd_kernel<<<ew_grid(numel / 8), 256, 0, (hipStream_t)stream>>>((const u32x4_t*)x, (u32x4_t*)y, numel / 8);
+    GENIE_CHECK_LAUNCH();
+    return GENIE_OK;
+}
+
+extern "C" int genie_silu_bwd(const void* x, const void* dy, void* dx, int64_t numel, void* stream) {
+    GENIE_CHECK_ARG(numel % 8 == 0, "genie_silu_bwd: numel %lld not a multiple of 8", (long long)numel);
+    if (numel == 0) return GENIE_OK;
+    silu_bwd_kernel<<<ew_grid(numel / 8), 256, 0, (hipStream_t)stream>>>((const u32x4_t*)x, (const u32x4_t*)dy, (u32x4_t*)dx, numel / 8);
+    GENIE_CHECK_LAUNCH();
+    return GENIE_OK;
+}
+
+extern "C" int genie_add(const void* a, const void* b, void* y, int64_t numel, void* stream) {
+    GENIE_CHECK_ARG(numel % 8 == 0, "genie_add: numel %lld not a multiple of 8", (long long)numel);
+    if (numel == 0) return GENIE_OK;
+    add_kernel<<<ew_grid(numel / 8), 256, 0, (hipStream_t)stream>>>((const u32x4_t*)a, (const u32x4_t*)b, (u32x4_t*)y, numel / 8);
+    GENIE_CHECK_LAUNCH();
+    return GENIE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// MSE:  loss = mean((rec - target)^2);  rec is CL bf16, target any strided fp32/bf16 NCTHW.
+// Deterministic two-stage reduction (fixed partial count, fixed order).
+// ------------------------------------------------------------------------------------------------
+#define MSE_PARTIALS 1024
+
+template <typename T>
+__global__ void __launch_bounds__(256) mse_partial_kernel(const bf16_t* __restrict__ rec, int Cp, const T* __restrict__ tgt,
+                                                          int N, int C, int T_, int H, int W, long long sN, long long sC,
+                                                          long long sT, long long sH, long long sW, float* __restrict__ partial) {
+    const long long npix = (long long)N * T_ * H * W;
+    const int nchunk = (C + 7) >> 3;
+    const long long total = npix * nchunk;
+    float acc = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long pix = i % npix;
+        const int chunk = (int)(i / npix);
+        long long r = pix;
+        const int w = (int)(r % W); r /= W;
+        const int h = (int)(r % H); r /= H;
+        const int t = (int)(r % T_); r /= T_;
+        const int n = (int)r;
+        float f[8];
+        unpack8(*reinterpret_cast<const u32x4_t*>(rec + pix * Cp + chunk * 8), f);
+        const T* base = tgt + n * sN + t * sT + h * sH + w * sW;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = chunk * 8 + j;
+            if (c < C) {
+                const float d = f[j] - load_as_f32<T>(base + c * sC);
+                acc += d * d;
+            }
+        }
+    }
+    __shared__ float red[4];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ void __launch_bounds__(256) mse_final_kernel(const float* __restrict__ partial, int np, float inv_count,
+                                                        float* __restrict__ loss) {
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < np; i += 256) acc += (double)partial[i];
+    __shared__ double red[256];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *loss = (float)(red[0] * (double)inv_count);
+}
+
+// drec = (rec - target) * 2/numel * (*gscale)
+template <typename T>
+__global__ void __launch_bounds__(256) mse_bwd_kernel(const bf16_t* __restrict__ rec, int Cp, const T* __restrict__ tgt, int N,
+                                                      int C, int T_, int H, int W, long long sN, long long sC, long long sT,
+                                                      long long sH, long long sW, const float* __restrict__ gscale,
+                                                      float coef, bf16_t* __restrict__ drec) {
+    const long long npix = (long long)N * T_ * H * W;
+    const int nchunk = Cp >> 3;
+    const long long total = npix * nchunk;
+    const float k = coef * (gscale ? *gscale : 1.f);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long pix = i % npix;
+        const int chunk = (int)(i / npix);
+        long long r = pix;
+        const int w = (int)(r % W); r /= W;
+        const int h = (int)(r % H); r /= H;
+        const int t = (int)(r % T_); r /= T_;
+        const int n = (int)r;
+        float f[8];
+        unpack8(*reinterpret_cast<const u32x4_t*>(rec + pix * Cp + chunk * 8), f);
+        const T* base = tgt + n * sN + t * sT + h * sH + w * sW;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = chunk * 8 + j;
+            f[j] = c < C ? (f[j] - load_as_f32<T>(base + c * sC)) * k : 0.f;
+        }
+        *reinterpret_cast<u32x4_t*>(drec + pix * Cp + chunk * 8) = pack8(f);
+    }
+}
+
+extern "C" int genie_mse_fwd(const void* rec, int cpitch, const void* target, int target_dtype, const int64_t* dims,
+                             const int64_t* strides, float* partial_ws, float* loss, void* stream) {
+    GENIE_CHECK_ARG(rec && target && partial_ws && loss, "genie_mse_fwd: null pointer");
+    const int N = (int)dims[0], C = (int)dims[1], T = (int)dims[2], H = (int)dims[3], W = (int)dims[4];
+    const long long count = (long long)N * C * T * H * W;
+    GENIE_CHECK_ARG(count > 0, "genie_mse_fwd: empty tensor");
+    hipStream_t s = (hipStream_t)stream;
+    const long long total = (long long)N * T * H * W * ((C + 7) / 8);
+    int grid = ew_grid(total);
+    if (grid > MSE_PARTIALS) grid = MSE_PARTIALS;
+    if (target_dtype == GENIE_F32)
+        mse_partial_kernel<float><<<grid, 256, 0, s>>>((const bf16_t*)rec, cpitch, (const float*)target, N, C, T, H, W, strides[0], strides[1], strides[2], strides[3], strides[4], partial_ws);
+    else if (target_dtype == GENIE_BF16)
+        mse_partial_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)rec, cpitch, (const bf16_t*)target, N, C, T, H, W, strides[0], strides[1], strides[2], strides[3], strides[4], partial_ws);
+    else
+        GENIE_CHECK_ARG(false, "genie_mse_fwd: unsupported dtype %d", target_dtype);
+    GENIE_CHECK_LAUNCH();
+    mse_final_kernel<<<1, 256, 0, s>>>(partial_ws, grid, 1.f / (float)count, loss);
+    GENIE_CHECK_LAUNCH();
+    return GENIE_OK;
+}
+
+extern "C" int genie_mse_bwd(const void* rec, int cpitch, const void* target, int target_dtype, const int64_t* dims,
+                             const int64_t* strides, const float* grad_loss, void* drec, void* stream) {
+    GENIE_CHECK_ARG(rec && target && drec, "genie_mse_bwd: null pointer");
+    const int N = (int)dims[0], C = (int)dims[1], T = (int)dims[2], H = (int)dims[3], W = (int)dims[4];
+    const long long count = (long long)N * C * T * H * W;
+    GENIE_CHECK_ARG(count > 0, "genie_mse_bwd: empty tensor");
+    hipStream_t s = (hipStream_t)stream;
+    const long long total = (long long)N * T * H * W * (cpitch / 8);
+    const float coef = 2.f / (float)count;
+    if (target_dtype == GENIE_F32)
+        mse_bwd_kernel<float><<<ew_grid(total), 256, 0, s>>>((const bf16_t*)rec, cpitch, (const float*)target, N, C, T, H, W, strides[0], strides[1], strides[2], strides[3], strides[4], grad_loss, coef, (bf16_t*)drec);
+    else if (target_dtype == GENIE_BF16)
+        mse_bwd_kernel<bf16_t><<<ew_grid(total), 256, 0, s>>>((const bf16_t*)rec, cpitch, (const bf16_t*)target, N, C, T, H, W, strides[0], strides[1], strides[2], strides[3], strides[4], grad_loss, coef, (bf16_t*)drec);
+    else
+        GENIE_CHECK_ARG(false, "genie_mse_bwd: unsupported dtype %d", target_dtype);
+    GENIE_CHECK_LAUNCH();
+    return GENIE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused AdamW over a flat fp32 arena (torch.optim.AdamW semantics, decoupled weight decay).
+// One pass: reads p, g, m, v; writes p, m, v (+ optionally zeroes g: the wgrad kernels accumulate
+// into g with atomics, so "consume and clear" saves a separate memset pass over 1.5 GB).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) adamw_kernel(float4* __restrict__ p, float4* __restrict__ g, float4* __restrict__ m,
+                                                    float4* __restrict__ v, long long n4, float lr, float beta1, float beta2,
+                                                    float eps, float wd, float bc1, float rsqrt_bc2, float gscale,
+                                                    int zero_grad) {
+    const float step = lr / bc1;
+    const float decay = 1.f - lr * wd;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        float4 pp = p[i], gg = g[i], mm = m[i], vv = v[i];
+        float* P = &pp.x; float* G = &gg.x; float* M = &mm.x; float* V = &vv.x;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float gr = G[j] * gscale;
+            P[j] *= decay;
+            M[j] = beta1 * M[j] + (1.f - beta1) * gr;
+            V[j] = beta2 * V[j] + (1.f - beta2) * gr * gr;
+            const float denom = sqrtf(V[j]) * rsqrt_bc2 + eps;
+            P[j] -= step * (M[j] / denom);
+        }
+        p[i] = pp; m[i] = mm; v[i] = vv;
+        if (zero_grad) g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+extern "C" int genie_adamw_step(float* p, float* g, float* m, float* v, int64_t numel, float lr, float beta1, float beta2,
+                                float eps, float weight_decay, int step, float grad_scale, int zero_grad, void* stream) {
+    GENIE_CHECK_ARG(p && g && m && v, "genie_adamw_step: null pointer");
+    GENIE_CHECK_ARG(numel % 4 == 0, "genie_adamw_step: arena numel %lld must be a multiple of 4", (long long)numel);
+    GENIE_CHECK_ARG(step >= 1, "genie_adamw_step: step must be >= 1");
+    if (numel == 0) return GENIE_OK;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    adamw_kernel<<<ew_grid(numel / 4), 256, 0, (hipStream_t)stream>>>((float4*)p, (float4*)g, (float4*)m, (float4*)v, numel / 4, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)(1.0 / sqrt(bc2)), grad_scale, zero_grad);
+    GENIE_CHECK_LAUNCH();
+    return GENIE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight packing: strided fp32 (R, J, K) -> dense bf16 [R][J][Kp], Kp = roundup8(K), zero padded.
+// Optional permutation of the K index: natural k = (k' % permC) * permF + k' / permC  (depth-to-space
+// column order, DESIGN.md "pixel shuffle").  Used for the forward pack (R=cout, K=cin) and the
+// transposed pack for dgrad (R=cin, K=cout).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) pack_weight_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int R, int J,
+                                                          int K, int Kp, long long sR, long long sJ, long long sK, int permC,
+                                                          int permF) {
+    const long long total = (long long)R * J * (Kp >> 3);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int kc = (int)(i % (Kp >> 3));
+        const long long rj = i / (Kp >> 3);
+        const int j = (int)(rj % J);
+        const int r = (int)(rj / J);
+        float f[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int kk = kc * 8 + e;
+            if (kk < K) {
+                const int kn = permF > 1 ? (kk % permC) * permF + kk / permC : kk;
+                f[e] = src[r * sR + j * sJ + kn * sK];
+            } else {
+                f[e] = 0.f;
+            }
+        }
+        *reinterpret_cast<u32x4_t*>(dst + i * 8) = pack8(f);
+    }
+}
+
+extern "C" int genie_pack_weight(const float* src, void* dst, int R, int J, int K, int64_t sR, int64_t sJ, int64_t sK, int perm_c,
+                                 int perm_f, void* stream) {
+    GENIE_CHECK_ARG(src && dst, "genie_pack_weight: null pointer");
+    GENIE_CHECK_ARG(R > 0 && J > 0 && K > 0, "genie_pack_weight: bad dims %d %d %d", R, J, K);
+    GENIE_CHECK_ARG(perm_f >= 1 && (perm_f == 1 || (perm_c >= 1 && perm_c * perm_f == K)), "genie_pack_weight: bad permutation %d x %d for K=%d", perm_c, perm_f, K);
+    const int Kp = (K + 7) & ~7;
+    const long long total = (long long)R * J * (Kp >> 3);
+    pack_weight_kernel<<<ew_grid(total), 256, 0, (hipStream_t)stream>>>(src, (bf16_t*)dst, R, J, K, Kp, sR, sJ, sK, perm_c, perm_f);
+    GENIE_CHECK_LAUNCH();
+    return GENIE_OK;
+}
+
+// fp32 -> bf16 flat cast (arena mirror)
+__global__ void __launch_bounds__(256) cast_bf16_kernel(const float4* __restrict__ src, u32x2_t* __restrict__ dst, long long n4) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const float4 f = src[i];
+        u32x2_t o;
+        o[0] = pack_bf16x2(f.x, f.y);
+        o[1] = pack_bf16x2(f.z, f.w);
+        dst[i] = o;
+    }
+}
+
+extern "C" int genie_cast_f32_to_bf16(const float* src, void* dst, int64_t numel, void* stream) {
+    GENIE_CHECK_ARG(numel % 4 == 0, "genie_cast_f32_to_bf16: numel %lld must be a multiple of 4", (long long)numel);
+    if (numel == 0) return GENIE_OK;
+    cast_bf16_kernel<<<ew_grid(numel / 4), 256, 0, (hipStream_t)stream>>>((const float4*)src, (u32x2_t*)dst, numel / 4);
+    GENIE_CHECK_LAUNCH();
+    return GENIE_OK;
+}

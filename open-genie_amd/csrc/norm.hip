@@ -1,0 +1,346 @@
+// GroupNorm (+ adaptive scale/shift, + SiLU) on CL bf16 tensors -- HBM-bound streaming kernels.
+//
+// Forward : stats pass (1 read) -> finalize (tiny) -> apply pass (1 read + 1 write)
+// Backward: reduce pass (reads x, dy) -> finalize (tiny) -> apply pass (reads x, dy; writes dx)
+//
+// Thread mapping shared by all passes: a block owns (sample n, a contiguous pixel range); inside it
+// thread -> (pixel row pr, 16-B channel chunk cc) with cc FIXED for the thread's lifetime, so the
+// per-channel coefficients live in registers and per-channel partial sums need no atomics.  All
+// reductions run in a fixed order (deterministic).  Statistics are fp32 per thread/block and fp64
+// across blocks.
+//
+// Reference semantics: torch.nn.GroupNorm / F.group_norm (biased variance, eps inside the sqrt) as used
+// at genie/module/video.py:578,612, genie/module/norm.py:58, genie/module/misc.py:92.
+#include "common.h"
+#include "genie_hip.h"
+
+#define GN_MAX_BLK 128
+
+struct GnGeom {
+    int N, C, Cp, G, CH;   // CH = Cp / 8
+    long long npix;
+    int nblk;              // blocks per sample
+    long long pix_per_blk;
+};
+
+static GnGeom gn_geom(int N, long long npix, int C, int Cp, int G) {
+    GnGeom g;
+    g.N = N; g.C = C; g.Cp = Cp; g.G = G; g.CH = Cp / 8; g.npix = npix;
+    long long want = (2048 + N - 1) / N;                 // ~2048 blocks in flight over the whole batch
+    long long by_size = (npix * g.CH + 2047) / 2048;     // at least ~8 x 16 B per thread
+    long long nb = want < by_size ? want : by_size;
+    if (nb > GN_MAX_BLK) nb = GN_MAX_BLK;
+    if (nb < 1) nb = 1;
+    g.pix_per_blk = (npix + nb - 1) / nb;
+    g.nblk = (int)((npix + g.pix_per_blk - 1) / g.pix_per_blk);
+    return g;
+}
+
+extern "C" int64_t genie_groupnorm_ws_floats(int N, int C, int G) {
+    const int Cp = (C + 7) & ~7;
+    return (int64_t)N * GN_MAX_BLK * Cp * 2 + (int64_t)N * G * 4 + 64;
+}
+
+// ---- stats: per (n, blk, channel) sum and sum of squares ------------------------------------------
+__global__ void __launch_bounds__(256) gn_stats_kernel(const bf16_t* __restrict__ x, GnGeom g, float* __restrict__ part) {
+    __shared__ float red[256 * 16];
+    const int n = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
+    const long long p0 = (long long)blk * g.pix_per_blk;
+    long long p1 = p0 + g.pix_per_blk;
+    if (p1 > g.npix) p1 = g.npix;
+    const bf16_t* xs = x + (long long)n * g.npix * g.Cp;
+    for (int cc0 = 0; cc0 < g.CH; cc0 += 256) {
+        const int chb = g.CH - cc0 < 256 ? g.CH - cc0 : 256;
+        const int R = 256 / chb;
+        const int pr = tid / chb, cc = cc0 + tid % chb;
+        float s[8], q[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] = q[j] = 0.f;
+        if (pr < R) {
+            for (long long p = p0 + pr; p < p1; p += R) {
+                float f[8];
+                unpack8(*reinterpret_cast<const u32x4_t*>(xs + p * g.Cp + cc * 8), f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { s[j] += f[j]; q[j] += f[j] * f[j]; }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { red[tid * 16 + j] = s[j]; red[tid * 16 + 8 + j] = q[j]; }
+        __syncthreads();
+        if (tid < chb) {
+            float ts[8], tq[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ts[j] = tq[j] = 0.f;
+            for (int r = 0; r < R; ++r) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { ts[j] += red[(r * chb + tid) * 16 + j]; tq[j] += red[(r * chb + tid) * 16 + 8 + j]; }
+            }
+            float* o = part + (((long long)n * g.nblk + blk) * g.Cp + (cc0 + tid) * 8) * 2;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { o[2 * j] = ts[j]; o[2 * j + 1] = tq[j]; }
+        }
+        __syncthreads();
+    }
+}
+
+// ---- finalize: one 64-lane block per (n, g) ------------------------------------------------------
+__global__ void __launch_bounds__(64) gn_finalize_kernel(const float* __restrict__ part, GnGeom g, float eps,
+                                                         float* __restrict__ mean, float* __restrict__ rstd) {
+    const int n = blockIdx.y, grp = blockIdx.x, lane = threadIdx.x;
+    const int cg = g.C / g.G;
+    double s = 0.0, q = 0.0;
+    for (int i = lane; i < g.nblk * cg; i += 64) {
+        const int blk = i / cg, c = grp * cg + i % cg;
+        const float* o = part + (((long long)n * g.nblk + blk) * g.Cp + c) * 2;
+        s += (double)o[0];
+        q += (double)o[1];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_xor(s, o, 64);
+        q += __shfl_xor(q, o, 64);
+    }
+    if (lane == 0) {
+        const double cnt = (double)cg * (double)g.npix;
+        const double m = s / cnt;
+        double var = q / cnt - m * m;
+        if (var < 0.0) var = 0.0;
+        mean[n * g.G + grp] = (float)m;
+        rstd[n * g.G + grp] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+
+// forward coefficients of one channel: z = x * a + b
+__device__ __forceinline__ void gn_coef(int n, int c, const GnGeom& g, const float* gamma, const float* beta,
+                                        const float* ada_s, const float* ada_b, const float* mean, const float* rstd,
+                                        float& a, float& b, float& mu, float& rs, float& gam_eff) {
+    if (c >= g.C) { a = b = mu = rs = gam_eff = 0.f; return; }
+    const int grp = c / (g.C / g.G);
+    mu = mean[n * g.G + grp];
+    rs = rstd[n * g.G + grp];
+    const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+    const float as = ada_s ? ada_s[(long long)n * g.C + c] : 1.f, ab = ada_b ? ada_b[(long long)n * g.C + c] : 0.f;
+    gam_eff = ga * as;
+    a = rs * gam_eff;
+    b = (be - mu * rs * ga) * as + ab;
+}
+
+__global__ void __launch_bounds__(256) gn_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, GnGeom g,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ ada_s, const float* __restrict__ ada_b,
+                                                       const float* __restrict__ mean, const float* __restrict__ rstd, int act) {
+    const int n = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
+    const long long p0 = (long long)blk * g.pix_per_blk;
+    long long p1 = p0 + g.pix_per_blk;
+    if (p1 > g.npix) p1 = g.npix;
+    const bf16_t* xs = x + (long long)n * g.npix * g.Cp;
+    bf16_t* ys = y + (long long)n * g.npix * g.Cp;
+    for (int cc0 = 0; cc0 < g.CH; cc0 += 256) {
+        const int chb = g.CH - cc0 < 256 ? g.CH - cc0 : 256;
+        const int R = 256 / chb;
+        const int pr = tid / chb, cc = cc0 + tid % chb;
+        if (pr >= R) continue;
+        float a[8], b[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float mu, rs, ge;
+            gn_coef(n, cc * 8 + j, g, gamma, beta, ada_s, ada_b, mean, rstd, a[j], b[j], mu, rs, ge);
+        }
+        for (long long p = p0 + pr; p < p1; p += R) {
+            float f[8];
+            unpack8(*reinterpret_cast<const u32x4_t*>(xs + p * g.Cp + cc * 8), f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float z = f[j] * a[j] + b[j];
+                f[j] = act == 1 ? silu_f(z) : z;
+            }
+            *reinterpret_cast<u32x4_t*>(ys + p * g.Cp + cc * 8) = pack8(f);
+        }
+    }
+}
+
+extern "C" int genie_groupnorm_fwd(const void* x, void* y, int N, int64_t npix, int C, int cpitch, int G, const float* gamma,
+                                   const float* beta, const float* ada_scale, const float* ada_shift, float eps, int act,
+                                   float* mean, float* rstd, float* ws, void* stream) {
+    GENIE_CHECK_ARG(x && y && mean && rstd && ws, "genie_groupnorm_fwd: null pointer");
+    GENIE_CHECK_ARG(G >= 1 && C % G == 0, "genie_groupnorm_fwd: num_channels %d must be divisible by num_groups %d", C, G);
+    GENIE_CHECK_ARG(cpitch % 8 == 0 && cpitch >= C, "genie_groupnorm_fwd: bad channel pitch %d for C=%d", cpitch, C);
+    if (N == 0 || npix == 0) return GENIE_OK;
+    const GnGeom g = gn_geom(N, npix, C, cpitch, G);
+    hipStream_t s = (hipStream_t)stream;
+    gn_stats_kernel<<<dim3(g.nblk, N), 256, 0, s>>>((const bf16_t*)x, g, ws);
+    GENIE_CHECK_LAUNCH();
+    gn_finalize_kernel<<<dim3(G, N), 64, 0, s>>>(ws, g, eps, mean, rstd);
+    GENIE_CHECK_LAUNCH();
+    gn_apply_kernel<<<dim3(g.nblk, N), 256, 0, s>>>((const bf16_t*)x, (bf16_t*)y, g, gamma, beta, ada_scale, ada_shift, mean, rstd, act);
+    GENIE_CHECK_LAUNCH();
+    return GENIE_OK;
+}
+
+// ---- backward -------------------------------------------------------------------------------------
+// z = xhat * gam_eff + b_eff,  dz = dy * act'(z);  S1[n,c] = sum dz,  S2[n,c] = sum dz * xhat
+__global__ void __launch_bounds__(256) gn_bwd_reduce_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, GnGeom g,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            const float* __restrict__ ada_s, const float* __restrict__ ada_b,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            int act, float* __restrict__ part) {
+    __shared__ float red[256 * 16];
+    const int n = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
+    const long long p0 = (long long)blk * g.pix_per_blk;
+    long long p1 = p0 + g.pix_per_blk;
+    if (p1 > g.npix) p1 = g.npix;
+    const bf16_t* xs = x + (long long)n * g.npix * g.Cp;
+    const bf16_t* ds = dy + (long long)n * g.npix * g.Cp;
+    for (int cc0 = 0; cc0 < g.CH; cc0 += 256) {
+        const int chb = g.CH - cc0 < 256 ? g.CH - cc0 : 256;
+        const int R = 256 / chb;
+        const int pr = tid / chb, cc = cc0 + tid % chb;
+        float s1[8], s2[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
+        if (pr < R) {
+            float a[8], b[8], mu[8], rs[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float ge;
+                gn_coef(n, cc * 8 + j, g, gamma, beta, ada_s, ada_b, mean, rstd, a[j], b[j], mu[j], rs[j], ge);
+            }
+            for (long long p = p0 + pr; p < p1; p += R) {
+                float f[8], d[8];
+                unpack8(*reinterpret_cast<const u32x4_t*>(xs + p * g.Cp + cc * 8), f);
+                unpack8(*reinterpret_cast<const u32x4_t*>(ds + p * g.Cp + cc * 8), d);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float z = f[j] * a[j] + b[j];
+                    const float dz = act == 1 ? d[j] * silu_grad_f(z) : d[j];
+                    s1[j] += dz;
+                    s2[j] += dz * (f[j] - mu[j]) * rs[j];
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { red[tid * 16 + j] = s1[j]; red[tid * 16 + 8 + j] = s2[j]; }
+        __syncthreads();
+        if (tid < chb) {
+            float t1[8], t2[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t1[j] = t2[j] = 0.f;
+            for (int r = 0; r < R; ++r) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { t1[j] += red[(r * chb + tid) * 16 + j]; t2[j] += red[(r * chb + tid) * 16 + 8 + j]; }
+            }
+            float* o = part + (((long long)n * g.nblk + blk) * g.Cp + (cc0 + tid) * 8) * 2;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { o[2 * j] = t1[j]; o[2 * j + 1] = t2[j]; }
+        }
+        __syncthreads();
+    }
+}
+
+// one block per (n, g): channel totals -> parameter grads, group totals -> k2, k3
+__global__ void __launch_bounds__(64) gn_bwd_finalize_kernel(const float* __restrict__ part, GnGeom g, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, const float* __restrict__ ada_s,
+                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                             float* __restrict__ dada_s, float* __restrict__ dada_b,
+                                                             float* __restrict__ kcoef) {
+    const int n = blockIdx.y, grp = blockIdx.x, lane = threadIdx.x;
+    const int cg = g.C / g.G;
+    double P1 = 0.0, P2 = 0.0;
+    for (int ci = lane; ci < cg; ci += 64) {
+        const int c = grp * cg + ci;
+        double s1 = 0.0, s2 = 0.0;
+        for (int blk = 0; blk < g.nblk; ++blk) {
+            const float* o = part + (((long long)n * g.nblk + blk) * g.Cp + c) * 2;
+            s1 += (double)o[0];
+            s2 += (double)o[1];
+        }
+        const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+        const float as = ada_s ? ada_s[(long long)n * g.C + c] : 1.f;
+        if (dgamma) atomicAdd(dgamma + c, (float)(s2 * as));
+        if (dbeta) atomicAdd(dbeta + c, (float)(s1 * as));
+        if (dada_s) dada_s[(long long)n * g.C + c] = (float)(ga * s2 + be * s1);
+        if (dada_b) dada_b[(long long)n * g.C + c] = (float)s1;
+        P1 += (double)(ga * as) * s1;
+        P2 += (double)(ga * as) * s2;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        P1 += __shfl_xor(P1, o, 64);
+        P2 += __shfl_xor(P2, o, 64);
+    }
+    if (lane == 0) {
+        const double M = (double)cg * (double)g.npix;
+        const double rs = (double)rstd[n * g.G + grp], mu = (double)mean[n * g.G + grp];
+        // dx = k1 * dz + k2 * x + k3,  k1 = rstd * gam_eff (per channel)
+        kcoef[(n * g.G + grp) * 2 + 0] = (float)(-rs * rs * P2 / M);
+        kcoef[(n * g.G + grp) * 2 + 1] = (float)(-rs * P1 / M + rs * rs * mu * P2 / M);
+    }
+}
+
+__global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                           bf16_t* __restrict__ dx, GnGeom g, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const float* __restrict__ ada_s,
+                                                           const float* __restrict__ ada_b, const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd, const float* __restrict__ kcoef, int act) {
+    const int n = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
+    const long long p0 = (long long)blk * g.pix_per_blk;
+    long long p1 = p0 + g.pix_per_blk;
+    if (p1 > g.npix) p1 = g.npix;
+    const bf16_t* xs = x + (long long)n * g.npix * g.Cp;
+    const bf16_t* ds = dy + (long long)n * g.npix * g.Cp;
+    bf16_t* os = dx + (long long)n * g.npix * g.Cp;
+    for (int cc0 = 0; cc0 < g.CH; cc0 += 256) {
+        const int chb = g.CH - cc0 < 256 ? g.CH - cc0 : 256;
+        const int R = 256 / chb;
+        const int pr = tid / chb, cc = cc0 + tid % chb;
+        if (pr >= R) continue;
+        float a[8], b[8], k1[8], k2[8], k3[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float mu, rs, ge;
+            const int c = cc * 8 + j;
+            gn_coef(n, c, g, gamma, beta, ada_s, ada_b, mean, rstd, a[j], b[j], mu, rs, ge);
+            if (c < g.C) {
+                const int grp = c / (g.C / g.G);
+                k1[j] = rs * ge;
+                k2[j] = kcoef[(n * g.G + grp) * 2 + 0];
+                k3[j] = kcoef[(n * g.G + grp) * 2 + 1];
+            } else {
+                k1[j] = k2[j] = k3[j] = 0.f;
+            }
+        }
+        for (long long p = p0 + pr; p < p1; p += R) {
+            float f[8], d[8];
+            unpack8(*reinterpret_cast<const u32x4_t*>(xs + p * g.Cp + cc * 8), f);
+            unpack8(*reinterpret_cast<const u32x4_t*>(ds + p * g.Cp + cc * 8), d);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float z = f[j] * a[j] + b[j];
+                const float dz = act == 1 ? d[j] * silu_grad_f(z) : d[j];
+                d[j] = k1[j] * dz + k2[j] * f[j] + k3[j];
+            }
+            *reinterpret_cast<u32x4_t*>(os + p * g.Cp + cc * 8) = pack8(d);
+        }
+    }
+}
+
+extern "C" int genie_groupnorm_bwd(const void* x, const void* dy, void* dx, int N, int64_t npix, int C, int cpitch, int G,
+                                   const float* gamma, const float* beta, const float* ada_scale, const float* ada_shift, int act,
+                                   const float* mean, const float* rstd, float* dgamma, float* dbeta, float* dada_scale,
+                                   float* dada_shift, float* ws, void* stream) {
+    GENIE_CHECK_ARG(x && dy && dx && mean && rstd && ws, "genie_groupnorm_bwd: null pointer");
+    GENIE_CHECK_ARG(G >= 1 && C % G == 0, "genie_groupnorm_bwd: num_channels %d must be divisible by num_groups %d", C, G);
+    GENIE_CHECK_ARG(cpitch % 8 == 0 && cpitch >= C, "genie_groupnorm_bwd: bad channel pitch %d for C=%d", cpitch, C);
+    if (N == 0 || npix == 0) return GENIE_OK;
+    const GnGeom g = gn_geom(N, npix, C, cpitch, G);
+    hipStream_t s = (hipStream_t)stream;
+    float* kcoef = ws + (long long)N * GN_MAX_BLK * cpitch * 2;
+    gn_bwd_reduce_kernel<<<dim3(g.nblk, N), 256, 0, s>>>((const bf16_t*)x, (const bf16_t*)dy, g, gamma, beta, ada_scale, ada_shift, mean, rstd, act, ws);
+    GENIE_CHECK_LAUNCH();
+    gn_bwd_finalize_kernel<<<dim3(G, N), 64, 0, s>>>(ws, g, gamma, beta, ada_scale, mean, rstd, dgamma, dbeta, dada_scale, dada_shift, kcoef);
+    GENIE_CHECK_LAUNCH();
+    gn_bwd_apply_kernel<<<dim3(g.nblk, N), 256, 0, s>>>((const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, g, gamma, beta, ada_scale, ada_shift, mean, rstd, kcoef, act);
+    GENIE_CHECK_LAUNCH();
+    return GENIE_OK;
+}

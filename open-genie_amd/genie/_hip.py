@@ -1,0 +1,120 @@
+"""ctypes binding of ``libgenie_hip.so`` (C ABI declared in ``include/genie_hip.h``).
+
+There is NO fallback: if the library is missing or a call fails this module raises.  A GPU box that
+silently computed on some other path would void every parity claim ("boundary").
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get('GENIE_HIP_LIB', os.path.join(os.path.dirname(_HERE), 'lib', 'libgenie_hip.so'))
+
+GENIE_F32, GENIE_BF16 = 0, 1
+ABI_VERSION = 1
+
+
+class GenieTap(C.Structure):
+    _fields_ = [('dt', C.c_int32), ('dh', C.c_int32), ('dw', C.c_int32), ('wofs', C.c_int32),
+                ('c0', C.c_int32), ('nch', C.c_int32), ('pad0', C.c_int32), ('pad1', C.c_int32)]
+
+
+class GenieConvDesc(C.Structure):
+    _fields_ = [('src', C.c_void_p), ('wgt', C.c_void_p), ('dst', C.c_void_p), ('resid', C.c_void_p),
+                ('bias', C.c_void_p), ('taps', C.c_void_p),
+                ('ntaps', C.c_int32), ('nk', C.c_int32), ('small_c', C.c_int32),
+                ('N', C.c_int32), ('Ts', C.c_int32), ('Hs', C.c_int32), ('Ws', C.c_int32), ('Cs', C.c_int32),
+                ('To', C.c_int32), ('Ho', C.c_int32), ('Wo', C.c_int32),
+                ('st', C.c_int32), ('sh', C.c_int32), ('sw', C.c_int32),
+                ('Ncols', C.c_int32), ('w_row_stride', C.c_int32), ('perm_c', C.c_int32), ('perm_f', C.c_int32),
+                ('Td', C.c_int32), ('Hd', C.c_int32), ('Wd', C.c_int32), ('Cd', C.c_int32),
+                ('dmt', C.c_int32), ('dmh', C.c_int32), ('dmw', C.c_int32),
+                ('dot', C.c_int32), ('doh', C.c_int32), ('dow', C.c_int32),
+                ('shuf_c', C.c_int32), ('shuf_q', C.c_int32), ('shuf_r', C.c_int32), ('act', C.c_int32)]
+
+
+class GenieWgradDesc(C.Structure):
+    _fields_ = [('src', C.c_void_p), ('dy', C.c_void_p), ('dw', C.c_void_p), ('dbias', C.c_void_p), ('taps', C.c_void_p),
+                ('ntaps', C.c_int32),
+                ('N', C.c_int32), ('Ts', C.c_int32), ('Hs', C.c_int32), ('Ws', C.c_int32), ('Cs', C.c_int32), ('Cin', C.c_int32),
+                ('To', C.c_int32), ('Ho', C.c_int32), ('Wo', C.c_int32), ('st', C.c_int32), ('sh', C.c_int32), ('sw', C.c_int32),
+                ('Td', C.c_int32), ('Hd', C.c_int32), ('Wd', C.c_int32), ('Cd', C.c_int32), ('Cout', C.c_int32),
+                ('dmt', C.c_int32), ('dmh', C.c_int32), ('dmw', C.c_int32),
+                ('dot', C.c_int32), ('doh', C.c_int32), ('dow', C.c_int32),
+                ('shuf_c', C.c_int32), ('shuf_q', C.c_int32), ('shuf_r', C.c_int32),
+                ('s_cout', C.c_int64), ('s_tap', C.c_int64), ('s_cin', C.c_int64), ('split_k', C.c_int32)]
+
+
+_lib: Optional[C.CDLL] = None
+
+# name -> (restype, argtypes); the single source for the symbol-export test as well
+_P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
+_PL = C.POINTER(C.c_int64)
+SIGNATURES = {
+    'genie_abi_version': (C.c_int, []),
+    'genie_last_error': (C.c_char_p, []),
+    'genie_to_channels_last': (C.c_int, [_P, _I, _PL, _PL, _P, _I, _P]),
+    'genie_from_channels_last': (C.c_int, [_P, _I, _PL, _P, _I, _PL, _P]),
+    'genie_conv_igemm': (C.c_int, [C.POINTER(GenieConvDesc), _P]),
+    'genie_conv_wgrad': (C.c_int, [C.POINTER(GenieWgradDesc), _P]),
+    'genie_pack_weight': (C.c_int, [_P, _P, _I, _I, _I, _L, _L, _L, _I, _I, _P]),
+    'genie_cast_f32_to_bf16': (C.c_int, [_P, _P, _L, _P]),
+    'genie_groupnorm_ws_floats': (C.c_int64, [_I, _I, _I]),
+    'genie_groupnorm_fwd': (C.c_int, [_P, _P, _I, _L, _I, _I, _I, _P, _P, _P, _P, _F, _I, _P, _P, _P, _P]),
+    'genie_groupnorm_bwd': (C.c_int, [_P, _P, _P, _I, _L, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'genie_silu_fwd': (C.c_int, [_P, _P, _L, _P]),
+    'genie_silu_bwd': (C.c_int, [_P, _P, _P, _L, _P]),
+    'genie_add': (C.c_int, [_P, _P, _P, _L, _P]),
+    'genie_lfq_quantize': (C.c_int, [_P, _I, _L, _I, _I, _L, _P, _P, _P]),
+    'genie_mse_fwd': (C.c_int, [_P, _I, _P, _I, _PL, _PL, _P, _P, _P]),
+    'genie_mse_bwd': (C.c_int, [_P, _I, _P, _I, _PL, _PL, _P, _P, _P]),
+    'genie_adamw_step': (C.c_int, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _I, _P]),
+    'genie_probe_ds_read_tr16': (C.c_int, [_P, _P, _P, _P]),
+}
+
+
+def load_library() -> C.CDLL:
+    """Load libgenie_hip.so; raises (never falls back) when it is missing or stale."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f'genie: HIP library not found at {LIB_PATH}. Build it with `make -C open-genie_amd` '
+            f'(or `python -c "import __graft_entry__ as g; g.build()"`). There is no CPU/PyTorch fallback.')
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError -> missing export: fail loudly
+        fn.restype, fn.argtypes = res, args
+    if lib.genie_abi_version() != ABI_VERSION:
+        raise RuntimeError(f'genie: {LIB_PATH} has ABI {lib.genie_abi_version()}, expected {ABI_VERSION}; rebuild')
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load_library().genie_last_error().decode('utf-8', 'replace')
+        raise RuntimeError(f'{what} failed (code {rc}): {msg}')
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def i64(vals) -> C.Array:
+    return (C.c_int64 * len(vals))(*[int(v) for v in vals])
+
+
+def require_gpu(t: torch.Tensor, what: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(f'{what}: tensor is on {t.device}; the genie hot path runs on the MI355X only '
+                           f'(there is no CPU fallback -- use oracle/ for CPU reference results in tests)')

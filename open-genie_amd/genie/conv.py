@@ -1,0 +1,297 @@
+"""Host side of the Conv3d family: geometry -> tap tables -> ``genie_conv_igemm`` / ``genie_conv_wgrad``.
+
+One gather-GEMM kernel serves forward, backward-data (stride 1; strided, one launch per input parity
+class; and through the depth-to-space-time shuffle) and the 1x1x1 convolutions -- only the tap table,
+the weight pack and the destination mapping differ (DESIGN.md section "Conv3d").
+
+Reference semantics:
+  CausalConv3d      genie/module/video.py:154-192   time pad (kt-1)*dil + (1 - stride), all in front
+  nn.Conv3d(pad=p)  genie/module/video.py:580-620   symmetric zero padding
+  depth-to-space    genie/module/video.py:403-408   'b (c p q r) t h w -> b c (t p) (h q) (w r)'
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from functools import lru_cache
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _hip
+from .cl import cpitch, empty_cl, is_cl, pitch_of
+
+Triple = Tuple[int, int, int]
+
+
+@dataclass(frozen=True)
+class ConvSpec:
+    cin: int
+    cout: int                 # number of weight rows (for an upsample conv: Cf * P * Q * R)
+    kernel: Triple
+    stride: Triple = (1, 1, 1)
+    dilation: Triple = (1, 1, 1)
+    pad_front: Triple = (0, 0, 0)
+    pad_back: Triple = (0, 0, 0)
+    shuffle: Optional[Triple] = None   # (P, Q, R) depth-to-space-time factors applied to the output
+
+    @property
+    def ntaps(self) -> int:
+        return self.kernel[0] * self.kernel[1] * self.kernel[2]
+
+    @property
+    def cinp(self) -> int:
+        return cpitch(self.cin)
+
+    @property
+    def coutp(self) -> int:
+        return cpitch(self.cout)
+
+    def out_size(self, size: Triple) -> Triple:
+        return tuple((size[i] + self.pad_front[i] + self.pad_back[i] - self.dilation[i] * (self.kernel[i] - 1) - 1)
+                     // self.stride[i] + 1 for i in range(3))
+
+    @property
+    def cfinal(self) -> int:
+        if self.shuffle is None:
+            return self.cout
+        p, q, r = self.shuffle
+        return self.cout // (p * q * r)
+
+
+def causal_spec(cin: int, cout: int, kernel: Triple, stride: Triple = (1, 1, 1), dilation: Triple = (1, 1, 1),
+                space_pad=(None, None), shuffle=None) -> ConvSpec:
+    """video.py:154-164."""
+    kt, kh, kw = kernel
+    tp = (kt - 1) * dilation[0] + (1 - stride[0])
+    hp = space_pad[0] if space_pad[0] is not None else (kh - 1) // 2
+    wp = space_pad[1] if space_pad[1] is not None else (kw - 1) // 2
+    if tp < 0:
+        raise ValueError(f'CausalConv3d: negative causal padding {tp} (kernel {kernel}, stride {stride})')
+    return ConvSpec(cin, cout, tuple(kernel), tuple(stride), tuple(dilation), (tp, hp, wp), (0, hp, wp), shuffle)
+
+
+def same_spec(cin: int, cout: int, kernel: Triple) -> ConvSpec:
+    """nn.Conv3d(kernel, padding=(k-1)//2), stride 1."""
+    pad = tuple((k - 1) // 2 for k in kernel)
+    return ConvSpec(cin, cout, tuple(kernel), (1, 1, 1), (1, 1, 1), pad, pad, None)
+
+
+# ------------------------------------------------------------------------------------------------
+# tap tables (cached on the device)
+# ------------------------------------------------------------------------------------------------
+_tap_cache = {}
+
+
+def _upload_taps(key, taps):
+    dev = torch.cuda.current_device()
+    hit = _tap_cache.get((dev, key))
+    if hit is not None:
+        return hit
+    arr = torch.tensor([[t[0], t[1], t[2], t[3], t[4], t[5], 0, 0] for t in taps], dtype=torch.int32).reshape(-1, 8)
+    dev_arr = arr.cuda()
+    nk = sum((t[5] + 63) // 64 for t in taps)
+    _tap_cache[(dev, key)] = (dev_arr, len(taps), nk)
+    return _tap_cache[(dev, key)]
+
+
+def fwd_taps(spec: ConvSpec):
+    taps = []
+    kt, kh, kw = spec.kernel
+    j = 0
+    for a in range(kt):
+        for b in range(kh):
+            for c in range(kw):
+                taps.append((a * spec.dilation[0] - spec.pad_front[0], b * spec.dilation[1] - spec.pad_front[1],
+                             c * spec.dilation[2] - spec.pad_front[2], j * spec.cinp, 0, spec.cinp))
+                j += 1
+    return _upload_taps(('fwd', spec), taps)
+
+
+def dgrad_taps(spec: ConvSpec, parity: Triple, hi_pitch: int):
+    """Taps of the backward-data gather for the input positions i = a * stride + parity.
+
+    Plain conv: source (dy) coordinate = a + (parity + pad - k*dil) / stride for the k that divide.
+    Shuffled conv (stride 1): dy lives at high resolution; low-res coordinate o and sub-pixel (p,q,r)
+    sit at o * (P,Q,R) + (p,q,r), K segment = the Cf channels of that sub-pixel."""
+    taps = []
+    kt, kh, kw = spec.kernel
+    P, Q, R = spec.shuffle if spec.shuffle is not None else (1, 1, 1)
+    cf = spec.cfinal
+    j = 0
+    for a in range(kt):
+        for b in range(kh):
+            for c in range(kw):
+                num = tuple(parity[i] + spec.pad_front[i] - (a, b, c)[i] * spec.dilation[i] for i in range(3))
+                if all(num[i] % spec.stride[i] == 0 for i in range(3)):
+                    d = tuple(num[i] // spec.stride[i] for i in range(3))
+                    if spec.shuffle is None:
+                        taps.append((d[0], d[1], d[2], j * spec.coutp, 0, spec.coutp))
+                    else:
+                        for p in range(P):
+                            for q in range(Q):
+                                for r in range(R):
+                                    sub = (p * Q + q) * R + r
+                                    taps.append((d[0] * P + p, d[1] * Q + q, d[2] * R + r, j * spec.coutp + sub * cf, 0, cf))
+                j += 1
+    return _upload_taps(('dgrad', spec, parity, hi_pitch), taps) if taps else (None, 0, 0)
+
+
+# ------------------------------------------------------------------------------------------------
+# weight packs
+# ------------------------------------------------------------------------------------------------
+def _weight_view(weight: Tensor):
+    """(cout, cin, kt, kh, kw) fp32 -> strides (cout, tap, cin) with the taps flattened."""
+    co, ci, kt, kh, kw = weight.shape
+    s = weight.stride()
+    if kt * kh * kw > 1 and not (s[3] == kw * s[4] and s[2] == kh * s[3]):
+        weight = weight.contiguous()
+        s = weight.stride()
+    return weight, s[0], s[4], s[1]
+
+
+def pack_weight_fwd(weight: Tensor, spec: ConvSpec) -> Tensor:
+    """bf16 [cout][tap][cinp] (K = input channels contiguous)."""
+    w, s_co, s_tap, s_ci = _weight_view(weight.detach())
+    out = torch.empty((spec.cout, spec.ntaps, spec.cinp), dtype=torch.bfloat16, device=weight.device)
+    lib = _hip.load_library()
+    _hip.check(lib.genie_pack_weight(w.data_ptr(), out.data_ptr(), spec.cout, spec.ntaps, spec.cin, s_co, s_tap, s_ci,
+                                     0, 1, _hip.stream_ptr()), 'genie_pack_weight')
+    return out
+
+
+def pack_weight_bwd(weight: Tensor, spec: ConvSpec) -> Tensor:
+    """bf16 [cin][tap][coutp] (K = output channels contiguous; sub-pixel-major order for shuffled convs)."""
+    w, s_co, s_tap, s_ci = _weight_view(weight.detach())
+    out = torch.empty((spec.cin, spec.ntaps, spec.coutp), dtype=torch.bfloat16, device=weight.device)
+    if spec.shuffle is not None:
+        p, q, r = spec.shuffle
+        perm_c, perm_f = spec.cfinal, p * q * r
+    else:
+        perm_c, perm_f = 0, 1
+    lib = _hip.load_library()
+    _hip.check(lib.genie_pack_weight(w.data_ptr(), out.data_ptr(), spec.cin, spec.ntaps, spec.cout, s_ci, s_tap, s_co,
+                                     perm_c, perm_f, _hip.stream_ptr()), 'genie_pack_weight')
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# launches
+# ------------------------------------------------------------------------------------------------
+def _check_cl(x: Tensor, c: int, what: str):
+    if not is_cl(x):
+        raise ValueError(f'{what}: expected a CL (bf16 channels-last) tensor')
+    if x.shape[1] != c:
+        raise ValueError(f'{what}: expected {c} channels, got {x.shape[1]}')
+
+
+def conv_forward(x: Tensor, wpack: Tensor, bias: Optional[Tensor], spec: ConvSpec, resid: Optional[Tensor] = None,
+                 act: int = 0) -> Tensor:
+    _check_cl(x, spec.cin, 'conv_forward')
+    n, _, t, h, w = x.shape
+    to, ho, wo = spec.out_size((t, h, w))
+    if min(to, ho, wo) <= 0:
+        raise ValueError(f'conv_forward: input {(t, h, w)} too small for kernel {spec.kernel}')
+    P, Q, R = spec.shuffle if spec.shuffle is not None else (1, 1, 1)
+    cf = spec.cfinal
+    out = empty_cl(n, cf, to * P, ho * Q, wo * R, x.device)
+    if resid is not None:
+        _check_cl(resid, cf, 'conv_forward(resid)')
+        assert resid.shape == out.shape and pitch_of(resid) == pitch_of(out)
+    taps, ntaps, nk = fwd_taps(spec)
+    d = _hip.GenieConvDesc()
+    d.src, d.wgt, d.dst = x.data_ptr(), wpack.data_ptr(), out.data_ptr()
+    d.resid = _hip.ptr(resid)
+    d.bias = _hip.ptr(bias)
+    d.taps, d.ntaps, d.nk = taps.data_ptr(), ntaps, nk
+    d.small_c = 1 if (spec.cinp in (8, 16, 32) and ntaps <= 32 and pitch_of(x) == spec.cinp) else 0
+    d.N, d.Ts, d.Hs, d.Ws, d.Cs = n, t, h, w, pitch_of(x)
+    d.To, d.Ho, d.Wo = to, ho, wo
+    d.st, d.sh, d.sw = spec.stride
+    d.Ncols, d.w_row_stride = spec.cout, spec.ntaps * spec.cinp
+    d.Td, d.Hd, d.Wd, d.Cd = to * P, ho * Q, wo * R, pitch_of(out)
+    d.dmt, d.dmh, d.dmw = P, Q, R
+    d.dot = d.doh = d.dow = 0
+    if spec.shuffle is not None:
+        d.perm_c, d.perm_f = cf, P * Q * R
+        d.shuf_c, d.shuf_q, d.shuf_r = cf, Q, R
+    else:
+        d.perm_c, d.perm_f = 0, 1
+        d.shuf_c, d.shuf_q, d.shuf_r = spec.cout, 1, 1
+    d.act = act
+    _hip.check(_hip.load_library().genie_conv_igemm(C.byref(d), _hip.stream_ptr()), 'genie_conv_igemm(fwd)')
+    return out
+
+
+def conv_dgrad(dy: Tensor, wpack_bwd: Tensor, spec: ConvSpec, in_size: Triple, resid: Optional[Tensor] = None) -> Tensor:
+    """Gradient w.r.t. the conv input.  dy is the CL gradient of the (shuffled) output."""
+    _check_cl(dy, spec.cfinal, 'conv_dgrad')
+    n = dy.shape[0]
+    t, h, w = in_size
+    P, Q, R = spec.shuffle if spec.shuffle is not None else (1, 1, 1)
+    if spec.shuffle is not None and spec.cfinal % 8 != 0:
+        raise NotImplementedError('conv_dgrad through a depth-to-space shuffle needs out_channels % 8 == 0')
+    dx = empty_cl(n, spec.cin, t, h, w, dy.device)
+    lib = _hip.load_library()
+    st = spec.stride
+    first = True
+    for rt in range(st[0]):
+        for rh in range(st[1]):
+            for rw in range(st[2]):
+                ao, bo, co = -(-(t - rt) // st[0]), -(-(h - rh) // st[1]), -(-(w - rw) // st[2])
+                if min(ao, bo, co) <= 0:
+                    continue
+                taps, ntaps, nk = dgrad_taps(spec, (rt, rh, rw), pitch_of(dy))
+                if ntaps == 0:
+                    dx[:, :, rt::st[0], rh::st[1], rw::st[2]] = 0 if resid is None else resid[:, :, rt::st[0], rh::st[1], rw::st[2]]
+                    continue
+                d = _hip.GenieConvDesc()
+                d.src, d.wgt, d.dst = dy.data_ptr(), wpack_bwd.data_ptr(), dx.data_ptr()
+                d.resid = _hip.ptr(resid)
+                d.bias = None
+                d.taps, d.ntaps, d.nk, d.small_c = taps.data_ptr(), ntaps, nk, 0
+                d.N, d.Ts, d.Hs, d.Ws, d.Cs = n, dy.shape[2], dy.shape[3], dy.shape[4], pitch_of(dy)
+                d.To, d.Ho, d.Wo = ao, bo, co
+                d.st, d.sh, d.sw = P, Q, R
+                d.Ncols, d.w_row_stride = spec.cin, spec.ntaps * spec.coutp
+                d.perm_c, d.perm_f = 0, 1
+                d.Td, d.Hd, d.Wd, d.Cd = t, h, w, pitch_of(dx)
+                d.dmt, d.dmh, d.dmw = st
+                d.dot, d.doh, d.dow = rt, rh, rw
+                d.shuf_c, d.shuf_q, d.shuf_r = spec.cin, 1, 1
+                d.act = 0
+                _hip.check(lib.genie_conv_igemm(C.byref(d), _hip.stream_ptr()), 'genie_conv_igemm(dgrad)')
+                first = False
+    return dx
+
+
+def conv_wgrad(x: Tensor, dy: Tensor, spec: ConvSpec, dweight: Tensor, dbias: Optional[Tensor]) -> None:
+    """Accumulate dW (fp32, any strides, shape (cout, cin, kt, kh, kw)) and dbias (fp32 [cout])."""
+    _check_cl(x, spec.cin, 'conv_wgrad(x)')
+    _check_cl(dy, spec.cfinal, 'conv_wgrad(dy)')
+    n, _, t, h, w = x.shape
+    to, ho, wo = spec.out_size((t, h, w))
+    P, Q, R = spec.shuffle if spec.shuffle is not None else (1, 1, 1)
+    assert tuple(dy.shape[2:]) == (to * P, ho * Q, wo * R)
+    assert dweight.dtype == torch.float32 and tuple(dweight.shape) == (spec.cout, spec.cin, *spec.kernel)
+    s = dweight.stride()
+    kt, kh, kw = spec.kernel
+    if kt * kh * kw > 1 and not (s[3] == kw * s[4] and s[2] == kh * s[3]):
+        raise ValueError('conv_wgrad: weight-gradient taps must be flattenable (contiguous or channels_last_3d)')
+    taps, ntaps, _ = fwd_taps(spec)
+    d = _hip.GenieWgradDesc()
+    d.src, d.dy, d.dw, d.dbias, d.taps, d.ntaps = x.data_ptr(), dy.data_ptr(), dweight.data_ptr(), _hip.ptr(dbias), taps.data_ptr(), ntaps
+    d.N, d.Ts, d.Hs, d.Ws, d.Cs, d.Cin = n, t, h, w, pitch_of(x), spec.cin
+    d.To, d.Ho, d.Wo = to, ho, wo
+    d.st, d.sh, d.sw = spec.stride
+    d.Td, d.Hd, d.Wd, d.Cd, d.Cout = dy.shape[2], dy.shape[3], dy.shape[4], pitch_of(dy), spec.cout
+    d.dmt, d.dmh, d.dmw = P, Q, R
+    d.dot = d.doh = d.dow = 0
+    if spec.shuffle is not None:
+        d.shuf_c, d.shuf_q, d.shuf_r = spec.cfinal, Q, R
+    else:
+        d.shuf_c, d.shuf_q, d.shuf_r = spec.cout, 1, 1
+    d.s_cout, d.s_tap, d.s_cin = s[0], s[4], s[1]
+    d.split_k = 0
+    _hip.check(_hip.load_library().genie_conv_wgrad(C.byref(d), _hip.stream_ptr()), 'genie_conv_wgrad')

@@ -1,0 +1,270 @@
+"""Operator-level parity of the HIP kernels against the CPU oracle (run on the MI355X: -m gpu).
+
+Every comparison feeds the oracle the SAME bf16-representable inputs/weights the kernel sees, computes
+in fp32 on the CPU and bounds the difference by one bf16 rounding of the result (tests/util.py)."""
+import json
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from util import ROOT, assert_close_bf16, bf16_round
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def G():
+    from genie import _hip, cl, conv
+    _hip.load_library()
+    class NS: pass
+    ns = NS(); ns.hip, ns.cl, ns.conv = _hip, cl, conv
+    return ns
+
+
+def test_probe_ds_read_tr16(G):
+    """Pin the lane semantics of ds_read_b64_tr_b16 the wgrad kernel relies on: within each 16-lane group the
+    lanes' 8-byte rows form a 16x4 matrix M[i][j] (i = lane in group); lane i receives ... (recorded)."""
+    img = torch.arange(2048, dtype=torch.int16, device='cuda')
+    res = {}
+    for name, addr in {
+        'linear8': [l * 8 for l in range(64)],
+        'rows64B': [(l >> 2) * 64 + (l & 3) * 8 for l in range(64)],
+    }.items():
+        a = torch.tensor(addr, dtype=torch.int32, device='cuda')
+        out = torch.zeros(64 * 4, dtype=torch.int16, device='cuda')
+        G.hip.check(G.hip.load_library().genie_probe_ds_read_tr16(img.data_ptr(), a.data_ptr(), out.data_ptr(), G.hip.stream_ptr()), 'probe')
+        torch.cuda.synchronize()
+        res[name] = out.cpu().reshape(64, 4).tolist()
+    os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+    with open(os.path.join(ROOT, 'gpurun_out', 'probe_tr16.json'), 'w') as f:
+        json.dump(res, f)
+    # semantics assumed by conv_wgrad.hip: lane (16g + i) supplies row i of its group's 16x4 (u16) matrix and
+    # receives column-of-blocks: element j of lane (16g + i) = M[4*(i//4)... ] -- see the kernel header; here:
+    lin = res['linear8']
+    # with addr = 8*lane, u16 index = 4*lane + j before the transpose; group g holds u16 [64g, 64g+64)
+    # viewed as a 4 x 16 row-major block B[r][c] = 64g + 16r + c; the transposed read gives lane i column i
+    for l in range(64):
+        g, i = l // 16, l % 16
+        assert lin[l] == [64 * g + 16 * r + i for r in range(4)], (l, lin[l])
+
+
+def test_layout_roundtrip(G):
+    torch.manual_seed(0)
+    for shape in [(2, 3, 4, 8, 8), (1, 18, 2, 4, 4), (2, 32, 3, 5, 7), (1, 128, 2, 8, 8)]:
+        x = torch.randn(shape, device='cuda')
+        y = G.cl.to_cl(x)
+        assert G.cl.is_cl(y) and y.shape == x.shape
+        assert torch.equal(y.float(), x.to(torch.bfloat16).float())
+        cp = G.cl.pitch_of(y)
+        if cp != shape[1]:   # pad channels are zero
+            base = torch.as_strided(y, (shape[0], shape[2], shape[3], shape[4], cp), (y.stride(0), y.stride(2), y.stride(3), y.stride(4), 1))
+            assert (base[..., shape[1]:] == 0).all()
+        back = G.cl.from_cl(y)
+        assert torch.equal(back, x.to(torch.bfloat16).float())
+        # non-contiguous source
+        xt = x.permute(0, 1, 2, 4, 3)
+        assert torch.equal(G.cl.to_cl(xt).float(), xt.to(torch.bfloat16).float())
+
+
+@pytest.mark.parametrize('d,ncb', [(18, 1), (8, 1), (6, 3), (10, 1)])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_lfq_quantize_bit_exact(G, d, ncb, dtype):
+    from oracle import genie_oracle as O
+    torch.manual_seed(1)
+    ntok = 1000
+    z = torch.randn(ntok, ncb * d) * 0.5
+    z[3, :] = 0.
+    z[5, 0] = -0.
+    z = z.to(dtype)
+    pitch = (ncb * d + 7) & ~7
+    zz = torch.zeros(ntok, pitch, dtype=dtype, device='cuda')
+    zz[:, :ncb * d] = z.cuda()
+    quant = torch.full_like(zz, 7.)
+    idx = torch.zeros(ntok, ncb, dtype=torch.int64, device='cuda')
+    lib = G.hip.load_library()
+    G.hip.check(lib.genie_lfq_quantize(zz.data_ptr(), G.hip.GENIE_F32 if dtype == torch.float32 else G.hip.GENIE_BF16, ntok, ncb, d,
+                                       pitch, quant.data_ptr(), idx.data_ptr(), G.hip.stream_ptr()), 'lfq')
+    ref_idx = O.lfq_indices_numpy(z.float().reshape(ntok, ncb, d).numpy())
+    assert (idx.cpu().numpy() == ref_idx).all()
+    assert torch.equal(quant[:, :ncb * d].float().cpu(), torch.sign(z.float()))
+
+
+def _gn_ref(x, G_, gamma, beta, ada_s, ada_b, act):
+    from oracle import genie_oracle as O
+    y = O.group_norm(x, G_, gamma, beta)
+    if ada_s is not None:
+        shape = ada_s.shape + (1, 1, 1)
+        y = y * ada_s.reshape(shape) + ada_b.reshape(shape)
+    return O.silu(y) if act else y
+
+
+@pytest.mark.parametrize('N,C,G_,thw,ada,act', [
+    (2, 128, 1, (4, 16, 16), False, True), (2, 512, 8, (2, 8, 8), True, False), (1, 24, 3, (3, 5, 7), False, True),
+    (3, 64, 64, (2, 4, 4), True, True), (2, 16, 8, (1, 4, 4), False, False),
+])
+def test_groupnorm_fwd_bwd(G, N, C, G_, thw, ada, act):
+    torch.manual_seed(2)
+    x = bf16_round(torch.randn(N, C, *thw) * 1.5 + 0.3)
+    dy = bf16_round(torch.randn(N, C, *thw))
+    gamma, beta = torch.randn(C), torch.randn(C)
+    ada_s = torch.randn(N, C) if ada else None
+    ada_b = torch.randn(N, C) if ada else None
+    leaves = [t.clone().requires_grad_(True) for t in (x, gamma, beta)] + ([ada_s.clone().requires_grad_(True), ada_b.clone().requires_grad_(True)] if ada else [])
+    ref = _gn_ref(leaves[0], G_, leaves[1], leaves[2], leaves[3] if ada else None, leaves[4] if ada else None, act)
+    ref.backward(dy)
+
+    lib = G.hip.load_library()
+    xc, dyc = G.cl.to_cl(x.cuda()), G.cl.to_cl(dy.cuda())
+    y, dx = G.cl.empty_like_cl(xc), G.cl.empty_like_cl(xc)
+    cp, npix = G.cl.pitch_of(xc), thw[0] * thw[1] * thw[2]
+    dev = lambda t: None if t is None else t.cuda().contiguous()
+    g_, b_, as_, ab_ = dev(gamma), dev(beta), dev(ada_s), dev(ada_b)
+    mean = torch.empty(N * G_, device='cuda'); rstd = torch.empty(N * G_, device='cuda')
+    ws = torch.empty(lib.genie_groupnorm_ws_floats(N, C, G_), device='cuda')
+    P = G.hip.ptr
+    G.hip.check(lib.genie_groupnorm_fwd(P(xc), P(y), N, npix, C, cp, G_, P(g_), P(b_), P(as_), P(ab_), 1e-5, int(act), P(mean), P(rstd), P(ws), G.hip.stream_ptr()), 'gn fwd')
+    assert_close_bf16(y, ref, 'gn fwd')
+    dgamma, dbeta = torch.zeros(C, device='cuda'), torch.zeros(C, device='cuda')
+    das = torch.empty(N, C, device='cuda') if ada else None
+    dab = torch.empty(N, C, device='cuda') if ada else None
+    G.hip.check(lib.genie_groupnorm_bwd(P(xc), P(dyc), P(dx), N, npix, C, cp, G_, P(g_), P(b_), P(as_), P(ab_), int(act), P(mean), P(rstd),
+                                        P(dgamma), P(dbeta), P(das), P(dab), P(ws), G.hip.stream_ptr()), 'gn bwd')
+    assert_close_bf16(dx, leaves[0].grad, 'gn dx', rms_frac=5e-3)
+    for got, want, nm in [(dgamma, leaves[1].grad, 'dgamma'), (dbeta, leaves[2].grad, 'dbeta')] + ([(das, leaves[3].grad, 'dada_s'), (dab, leaves[4].grad, 'dada_b')] if ada else []):
+        torch.testing.assert_close(got.cpu(), want, rtol=2e-3, atol=2e-3 * want.abs().max().item(), msg=nm)
+
+
+CONV_CASES = [
+    # cin, cout, kernel, stride, causal, size
+    (64, 128, (3, 3, 3), (1, 1, 1), False, (2, 4, 8, 8)),
+    (128, 64, (3, 3, 3), (1, 1, 1), True, (1, 3, 6, 10)),
+    (64, 64, (3, 3, 3), (2, 2, 2), True, (2, 4, 8, 8)),
+    (64, 96, (3, 3, 3), (1, 2, 2), True, (1, 3, 9, 7)),
+    (128, 256, (1, 1, 1), (1, 1, 1), True, (2, 2, 4, 4)),
+    (3, 128, (3, 3, 3), (1, 1, 1), True, (2, 4, 16, 16)),       # stem: small_c path
+    (16, 32, (3, 3, 3), (1, 1, 1), False, (1, 2, 5, 5)),        # small_c, cpt = 2
+    (32, 16, (3, 3, 3), (2, 2, 2), True, (1, 4, 6, 6)),
+    (128, 3, (3, 3, 3), (1, 1, 1), True, (1, 2, 8, 8)),         # head: narrow N tile
+    (18, 64, (3, 3, 3), (1, 1, 1), True, (2, 2, 4, 4)),         # dec0: cin pitch 24
+    (512, 18, (1, 1, 1), (1, 1, 1), True, (2, 2, 4, 4)),        # enc26
+    (40, 72, (1, 3, 3), (1, 1, 1), False, (1, 2, 5, 6)),
+]
+
+
+def _conv_ref(x, w, b, stride, causal):
+    from oracle import genie_oracle as O
+    return O.causal_conv3d(x, w, b, stride=stride) if causal else O.conv3d_same(x, w, b)
+
+
+@pytest.mark.parametrize('cin,cout,kernel,stride,causal,size', CONV_CASES)
+def test_conv_forward_dgrad(G, cin, cout, kernel, stride, causal, size):
+    torch.manual_seed(3)
+    n, t, h, w = size
+    x = bf16_round(torch.randn(n, cin, t, h, w))
+    wt = bf16_round(torch.randn(cout, cin, *kernel) / (cin * kernel[0] * kernel[1] * kernel[2]) ** 0.5)
+    b = torch.randn(cout)
+    xr = x.clone().requires_grad_(True)
+    ref = _conv_ref(xr, wt, b, stride, causal)
+    dy = bf16_round(torch.randn_like(ref))
+    ref.backward(dy)
+    spec = G.conv.causal_spec(cin, cout, kernel, stride) if causal else G.conv.same_spec(cin, cout, kernel)
+    wd = wt.cuda()
+    wf, wb = G.conv.pack_weight_fwd(wd, spec), G.conv.pack_weight_bwd(wd, spec)
+    out = G.conv.conv_forward(G.cl.to_cl(x.cuda()), wf, b.cuda(), spec)
+    assert tuple(out.shape) == tuple(ref.shape)
+    assert_close_bf16(out, ref, 'conv fwd')
+    dx = G.conv.conv_dgrad(G.cl.to_cl(dy.cuda()), wb, spec, (t, h, w))
+    assert_close_bf16(dx, xr.grad, 'conv dgrad')
+    # channels_last_3d weights pack to the same thing
+    wcl = wd.contiguous(memory_format=torch.channels_last_3d)
+    assert torch.equal(G.conv.pack_weight_fwd(wcl, spec), wf)
+
+
+@pytest.mark.parametrize('cin,cf,fac,size', [(64, 32, (2, 2, 2), (1, 2, 4, 4)), (128, 64, (1, 2, 2), (2, 2, 3, 5)), (64, 3, (1, 4, 4), (1, 2, 4, 4))])
+def test_conv_shuffle_forward_dgrad(G, cin, cf, fac, size):
+    from oracle import genie_oracle as O
+    torch.manual_seed(4)
+    n, t, h, w = size
+    P, Q, R = fac
+    cout = cf * P * Q * R
+    x = bf16_round(torch.randn(n, cin, t, h, w))
+    wt = bf16_round(torch.randn(cout, cin, 3, 3, 3) / (cin * 27) ** 0.5)
+    b = torch.randn(cout)
+    xr = x.clone().requires_grad_(True)
+    ref = O.depth_to_spacetime(O.causal_conv3d(xr, wt, b), P, Q)
+    dy = bf16_round(torch.randn_like(ref))
+    ref.backward(dy)
+    spec = G.conv.causal_spec(cin, cout, (3, 3, 3), shuffle=fac)
+    wf = G.conv.pack_weight_fwd(wt.cuda(), spec)
+    out = G.conv.conv_forward(G.cl.to_cl(x.cuda()), wf, b.cuda(), spec)
+    assert_close_bf16(out, ref, 'shuffle fwd')
+    if cf % 8 == 0:
+        wb = G.conv.pack_weight_bwd(wt.cuda(), spec)
+        dx = G.conv.conv_dgrad(G.cl.to_cl(dy.cuda()), wb, spec, (t, h, w))
+        assert_close_bf16(dx, xr.grad, 'shuffle dgrad')
+
+
+def test_conv_residual_epilogue(G):
+    torch.manual_seed(5)
+    x = bf16_round(torch.randn(2, 64, 3, 6, 6))
+    r = bf16_round(torch.randn(2, 128, 3, 6, 6))
+    wt = bf16_round(torch.randn(128, 64, 3, 3, 3) / 42.)
+    from oracle import genie_oracle as O
+    ref = O.conv3d_same(x, wt, None) + r
+    spec = G.conv.same_spec(64, 128, (3, 3, 3))
+    out = G.conv.conv_forward(G.cl.to_cl(x.cuda()), G.conv.pack_weight_fwd(wt.cuda(), spec), None, spec, resid=G.cl.to_cl(r.cuda()))
+    assert_close_bf16(out, ref, 'conv + resid')
+
+
+WGRAD_CASES = CONV_CASES + [
+    (128, 128, (3, 3, 3), (1, 1, 1), False, (2, 4, 16, 16)),
+    (256, 128, (3, 3, 3), (1, 1, 1), True, (1, 3, 8, 8)),
+]
+
+
+@pytest.mark.parametrize('cin,cout,kernel,stride,causal,size', WGRAD_CASES)
+@pytest.mark.parametrize('wfmt', ['contiguous', 'channels_last_3d'])
+def test_conv_wgrad(G, cin, cout, kernel, stride, causal, size, wfmt):
+    torch.manual_seed(6)
+    n, t, h, w = size
+    x = bf16_round(torch.randn(n, cin, t, h, w))
+    wt = torch.randn(cout, cin, *kernel, requires_grad=True)
+    b = torch.randn(cout, requires_grad=True)
+    ref = _conv_ref(x, wt, b, stride, causal)
+    dy = bf16_round(torch.randn_like(ref))
+    ref.backward(dy)
+    spec = G.conv.causal_spec(cin, cout, kernel, stride) if causal else G.conv.same_spec(cin, cout, kernel)
+    dw = torch.zeros(cout, cin, *kernel, device='cuda')
+    if wfmt == 'channels_last_3d':
+        dw = dw.contiguous(memory_format=torch.channels_last_3d)
+    db = torch.zeros(cout, device='cuda')
+    G.conv.conv_wgrad(G.cl.to_cl(x.cuda()), G.cl.to_cl(dy.cuda()), spec, dw, db)
+    scale = wt.grad.abs().max().item()
+    torch.testing.assert_close(dw.cpu(), wt.grad, rtol=1e-3, atol=1e-3 * scale)
+    torch.testing.assert_close(db.cpu(), b.grad, rtol=1e-3, atol=1e-3 * b.grad.abs().max().item())
+    # accumulation semantics
+    G.conv.conv_wgrad(G.cl.to_cl(x.cuda()), G.cl.to_cl(dy.cuda()), spec, dw, None)
+    torch.testing.assert_close(dw.cpu(), 2 * wt.grad, rtol=1e-3, atol=2e-3 * scale)
+
+
+@pytest.mark.parametrize('cin,cf,fac,size', [(64, 32, (2, 2, 2), (1, 2, 4, 4)), (128, 64, (1, 2, 2), (2, 2, 3, 5)), (64, 256, (2, 2, 2), (1, 2, 4, 4))])
+def test_conv_shuffle_wgrad(G, cin, cf, fac, size):
+    from oracle import genie_oracle as O
+    torch.manual_seed(7)
+    n, t, h, w = size
+    P, Q, R = fac
+    cout = cf * P * Q * R
+    x = bf16_round(torch.randn(n, cin, t, h, w))
+    wt = torch.randn(cout, cin, 3, 3, 3, requires_grad=True)
+    b = torch.randn(cout, requires_grad=True)
+    ref = O.depth_to_spacetime(O.causal_conv3d(x, wt, b), P, Q)
+    dy = bf16_round(torch.randn_like(ref))
+    ref.backward(dy)
+    spec = G.conv.causal_spec(cin, cout, (3, 3, 3), shuffle=fac)
+    dw = torch.zeros(cout, cin, 3, 3, 3, device='cuda').contiguous(memory_format=torch.channels_last_3d)
+    db = torch.zeros(cout, device='cuda')
+    G.conv.conv_wgrad(G.cl.to_cl(x.cuda()), G.cl.to_cl(dy.cuda()), spec, dw, db)
+    torch.testing.assert_close(dw.cpu(), wt.grad, rtol=1e-3, atol=1e-3 * wt.grad.abs().max().item())
+    torch.testing.assert_close(db.cpu(), b.grad, rtol=1e-3, atol=1e-3 * b.grad.abs().max().item())
