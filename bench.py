@@ -1,0 +1,200 @@
+#!/usr/bin/env python
+"""Headline benchmark: VideoTokenizer (MAGVIT2 blueprint, d_codebook=18) TRAINING on 16x64x64 clips.
+
+  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+One step = one full pass of the hot path over one batch of synthetic clips per GPU, inputs resident in HBM:
+encode -> LFQ (training mode: quantise + entropy/commit loss over 2^18 codes) -> decode -> MSE + quant loss
+-> backward through everything -> gradient all-reduce (N > 1) -> fused AdamW on all 375.6 M parameters.
+(R-fwd loss, SURVEY.md 8c: the GAN and VGG16-perceptual critics cannot run offline and are outside the hot path.)
+
+Prints ONE JSON line (rank 0): metric video-frames/sec over ALL GPUs, plus
+  roofline     -- the dominant kernel (the 128x128 gather-GEMM behind Conv3d fwd/dgrad) priced against the dense bf16
+                  MFMA peak: algorithmic FLOPs of every launch / HIP-event time of every launch, timed region only
+  cpu_baseline -- the oracle (a port of the reference's algorithm, oracle/genie_oracle.py) doing the same training step
+                  on this box's host cores, bounded to one B=1 step.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, 'open-genie_amd')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch
+import torch.distributed as dist
+
+BF16_MFMA_PEAK_TFLOPS = 2500.0      # dense bf16, MI355X_MICROARCH.md
+CLIP = (3, 16, 64, 64)
+TRAIN_GFLOP_PER_CLIP = 7518.0       # 3 x 2506.1 GFLOP forward
+
+
+def effective_cpus() -> int:
+    """CPUs this process may actually use: affinity mask, capped by the cgroup CPU quota (os.cpu_count() reports the host)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+def _cpu_baseline_worker(threads: int, frames: int, q) -> None:
+    import torch as T
+    from genie import MAGVIT2_DEC_DESC, MAGVIT2_ENC_DESC, VideoTokenizer
+    from oracle import genie_oracle as O
+    T.manual_seed(0)
+    T.set_num_threads(threads)
+    m = VideoTokenizer(MAGVIT2_ENC_DESC, MAGVIT2_DEC_DESC, d_codebook=18, gan_loss_weight=0., perc_loss_weight=0.)
+    sd = {k: (v.detach().contiguous().clone().requires_grad_(v.is_floating_point())) for k, v in m.state_dict().items()}
+    del m
+    opt = T.optim.AdamW([v for v in sd.values() if v.requires_grad], lr=1e-3, weight_decay=0.01)
+    x = T.randn(1, CLIP[0], frames, CLIP[2], CLIP[3])
+    t0 = time.perf_counter()
+    loss, _, _, _ = O.tokenizer_forward_hotpath(x, sd, MAGVIT2_ENC_DESC, MAGVIT2_DEC_DESC, 18)
+    loss.backward()
+    opt.step()
+    q.put(time.perf_counter() - t0)
+
+
+def cpu_baseline(budget_s: float = 150.0):
+    """One B=1 training step of the oracle (a port of the reference's algorithm) on the host cores: fwd + bwd + torch AdamW.
+    Runs in a child process with a hard time budget; the sample is one 16x64x64 clip (4 frames if the first try is too slow)."""
+    import multiprocessing as mp
+    threads = min(effective_cpus(), 64)
+    ctx = mp.get_context('spawn')
+    for frames in (CLIP[1], 4):
+        q = ctx.Queue()
+        p = ctx.Process(target=_cpu_baseline_worker, args=(threads, frames, q))
+        p.start()
+        p.join(budget_s)
+        if p.is_alive():
+            p.kill()
+            p.join()
+            continue
+        if p.exitcode == 0:
+            dt = q.get()
+            return {'value': round(frames / dt, 4), 'unit': 'video-frames/sec', 'cores': threads, 'kind': 'port',
+                    'sample': f'1 training step (fwd+bwd+AdamW) of the MAGVIT2 tokenizer on one {frames}x64x64 clip, fp32, torch CPU '
+                              f'({threads} threads of {os.cpu_count()} host CPUs), {dt:.1f} s'}
+    return {'value': None, 'unit': 'video-frames/sec', 'cores': threads, 'kind': 'port', 'sample': f'did not finish within {budget_s:.0f} s'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=8)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--batch', type=int, default=int(os.environ.get('GENIE_BENCH_BATCH', 8)), help='clips per GPU per step')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-events', action='store_true')
+    ap.add_argument('--dump', type=str, default='')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs the MI355X (no CPU fallback for the product path)')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+    assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+
+    from genie import MAGVIT2_DEC_DESC, MAGVIT2_ENC_DESC, VideoTokenizer, conv as gconv
+    from genie.trainer import DataParallel, ParamArena
+
+    torch.manual_seed(0)                                   # identical initial weights on every rank
+    model = VideoTokenizer(MAGVIT2_ENC_DESC, MAGVIT2_DEC_DESC, d_codebook=18, gan_loss_weight=0., perc_loss_weight=0.).to(dev).train()
+    arena = ParamArena(model)
+    dp = DataParallel(arena.grads)
+    if world > 1:                                          # decoder gradients reduce while the encoder is still in backward
+        cuts = [model.dec_layers[i] for i in (0, 6, 12, 18)] + [model.enc_layers[i] for i in (6, 12)]
+        dp.install_overlap_hooks(arena, model, sorted(cuts, key=lambda mm: arena.offset_of(mm, model) or 0))
+    B = args.batch
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)      # rank r holds clips r::world of the synthetic stream
+    clips = [torch.randn(B, *CLIP, device=dev, generator=gen) for _ in range(2)]
+
+    def step(i):
+        loss, aux = model(clips[i % len(clips)])
+        loss.backward()
+        dp.finish()
+        arena.adamw_step(lr=1e-3, weight_decay=0.01)
+        return loss, aux
+
+    for i in range(args.warmup):
+        loss, aux = step(i)
+    torch.cuda.synchronize()
+    prof = None
+    if not args.no_kernel_events:
+        prof = gconv.PROFILER = gconv.LaunchProfiler()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss, aux = step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    gconv.PROFILER = None
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = t.item()
+    scal = dp.reduce_scalars([loss, aux[0], aux[4]])
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = elapsed / args.steps * 1e3
+    frames = world * B * CLIP[1] * args.steps
+    value = frames / elapsed
+    out = {
+        'metric': 'video-frames/sec (VideoTokenizer train step, MAGVIT2 blueprint, 16x64x64 clips)',
+        'value': round(value, 2), 'unit': 'video-frames/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'bf16', 'data': 'synthetic',
+        'config': {'workload': 'configs[1]: VideoTokenizer (MAGVIT2_ENC/DEC_DESC, d_codebook=18) training, 16x64x64 random clips, bf16 activations / fp32 master weights; '
+                               'step = encode + LFQ(train) + decode + MSE + quant loss + backward + AdamW (R-fwd loss)',
+                   'clips_per_gpu': B, 'global_batch': B * world, 'clip': list(CLIP), 'params': 375554837, 'parallelism': f'dp{world}',
+                   'final_loss': round(scal[0].item(), 5)},
+        'model_tflops_per_gpu': round(TRAIN_GFLOP_PER_CLIP * B * args.steps / elapsed / 1e3, 2),
+    }
+    if prof is not None:
+        summ = prof.summary()
+        dom = 'igemm_kernel<128,generic>'
+        if dom in summ:
+            d = summ[dom]
+            ach = d['flops'] / (d['ms'] * 1e-3) / 1e12
+            out['roofline'] = {'kernel': dom, 'bound': 'mfma', 'achieved': round(ach, 2), 'peak': BF16_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                               'frac': round(ach / BF16_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
+                               'launches': d['launches'], 'avg_launch_ms': round(d['ms'] / d['launches'], 4),
+                               'share_of_step_time': round(d['ms'] / (elapsed * 1e3), 4)}
+        kern = {k: {'launches': v['launches'], 'ms_per_step': round(v['ms'] / args.steps, 3),
+                    'tflops': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2) if v['ms'] > 0 else None} for k, v in summ.items()}
+        out['conv_kernels'] = kern
+        if args.dump:
+            os.makedirs(os.path.dirname(args.dump) or '.', exist_ok=True)
+            with open(args.dump, 'w') as f:
+                json.dump(summ, f, indent=1)
+    if world == 1 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline()
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

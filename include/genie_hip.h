@@ -89,6 +89,8 @@ typedef struct GenieConvDesc {
     int32_t shuf_c, shuf_q, shuf_r; /* column n -> sub-pixel (p,q,r) = unravel(n / shuf_c, (P, shuf_q, shuf_r)), channel n % shuf_c;
                                        no shuffle: shuf_c >= Ncols, shuf_q = shuf_r = 1          */
     int32_t act;          /* epilogue activation: 0 none, 1 SiLU                               */
+    void* splitk_ws;      /* optional fp32 scratch: enables split-K when the output has too few tiles to fill the chip */
+    int64_t splitk_ws_bytes;
 } GenieConvDesc;
 
 int genie_conv_igemm(const GenieConvDesc* desc, void* stream);
@@ -150,6 +152,17 @@ int genie_add(const void* a, const void* b, void* y, int64_t numel, void* stream
 int genie_lfq_quantize(const void* z, int dtype, int64_t ntok, int num_codebook, int codebook_dim, int64_t pitch,
                        void* quant, int64_t* idx, void* stream);
 
+/* Training loss of LFQ, forward AND gradient in one sweep (quantization.py:116-131).
+ * loss4 = {total, per-token entropy, entropy of the mean distribution, commit MSE}; dz_loss = d total / d z as
+ * fp32 dense [ntok][num_codebook * codebook_dim].  ws: genie_lfq_loss_ws_floats() floats. */
+int64_t genie_lfq_loss_ws_floats(int64_t ntok, int num_codebook, int codebook_dim);
+int genie_lfq_loss(const void* z, int dtype, int64_t ntok, int num_codebook, int codebook_dim, int64_t pitch, float beta,
+                   float commit_weight, float entropy_weight, float diversity_weight, float* ws, float* loss4, float* dz_loss,
+                   void* stream);
+/* out = dy (straight-through, may be NULL) + (*grad_loss) * dz_loss (may be NULL), in z's dtype/pitch; pad columns zeroed */
+int genie_lfq_bwd(const void* dy, const float* dz_loss, const float* grad_loss, void* out, int dtype, int64_t ntok, int width,
+                  int64_t pitch, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Losses and optimiser (elementwise.hip).
  * replaces: F.mse_loss (tokenizer.py:364, action.py:166) and torch.optim.AdamW (tokenizer.py:437-442).
@@ -161,6 +174,34 @@ int genie_mse_bwd(const void* rec_cl, int cpitch, const void* target, int target
                   void* stream);
 int genie_adamw_step(float* p, float* g, float* m, float* v, int64_t numel, float lr, float beta1, float beta2, float eps,
                      float weight_decay, int step, float grad_scale, int zero_grad, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Space-time transformer attention (attention.hip).
+ * replaces: RotaryEmbedding + nn.LayerNorm + Adapter head split + F.scaled_dot_product_attention + head merge in
+ *           Attention.forward (attention.py:199-239) and the rearrange/pack/unpack of SpatialAttention.forward
+ *           (:279-307) / TemporalAttention.forward (:347-371), forward and backward.
+ *
+ * Token rows are [C] bf16; a token of sequence `seq` at position `pos` lives at element offset
+ *     (seq / map[0]) * map[1] + (seq % map[0]) * map[2] + pos * map[3]        map = {n_inner, stride_outer, stride_inner, pos_stride}
+ * cos_sin: fp32 [npos][C], pairs (cos, sin) of angle pos * freq_i in slots (2i, 2i+1); position of token row r is
+ * (r / pos_div) % pos_mod.  stats: fp32 [ntok][2] (mean, rstd of the rotated row) saved for backward.
+ * ------------------------------------------------------------------------------------------- */
+int genie_rotary_layernorm_fwd(const void* x, void* u, int64_t ntok, int C, int64_t pitch, const float* cos_sin, int64_t pos_div,
+                               int pos_mod, const float* gamma, const float* beta, float eps, float* stats, void* stream);
+/* dx = d/dx [LN(rot(x))](du) (+ dres); dgamma / dbeta (fp32 [C]) are ACCUMULATED */
+int genie_rotary_layernorm_bwd(const void* x, const void* du, const void* dres, void* dx, int64_t ntok, int C, int64_t pitch,
+                               const float* cos_sin, int64_t pos_div, int pos_mod, const float* gamma, const float* stats,
+                               float* dgamma, float* dbeta, void* stream);
+/* out = softmax(scale * q k^T [causal]) v (+ resid); lse: fp32 [out tokens][nhead] (token = element offset / out_channels) */
+int genie_attention_fwd(const void* q, const void* k, const void* v, const void* resid, void* out, float* lse, int nseq, int nhead,
+                        int d_head, int Sq, int Sk, const int64_t* q_map, const int64_t* kv_map, const int64_t* out_map, float scale,
+                        int causal, int out_channels, void* stream);
+/* Self-attention (q == k == v): dq receives dQ + dK + dV.  Otherwise dq gets dQ and dk / dv (addressed by dkv_map, which must
+ * not alias across sequences) get dK / dV.  D_ws: fp32 [out_tokens][nhead] scratch. */
+int genie_attention_bwd(const void* q, const void* k, const void* v, const void* out, const void* resid, const void* dO,
+                        const float* lse, float* D_ws, void* dq, void* dk, void* dv, int nseq, int nhead, int d_head, int Sq, int Sk,
+                        const int64_t* q_map, const int64_t* kv_map, const int64_t* out_map, const int64_t* dkv_map, float scale,
+                        int causal, int out_channels, int64_t out_tokens, void* stream);
 
 /* Debug / bring-up probes (used by tests only). */
 int genie_probe_ds_read_tr16(const void* lds_image_u16_2048, const int32_t* lane_byte_addr_64, void* out_u16_64x4,

@@ -1,0 +1,783 @@
+// Space-time transformer attention on gfx950 MFMA (reference genie/module/attention.py:154-371).
+//
+//   prologue : u = LayerNorm(rotary(x))              one pass, fp32 angles from a host table (attention.py:219-220)
+//   core     : out = softmax(scale * Q K^T [causal]) V + resid,  Q = K = V = u unless a condition supplies K, V
+//
+// One flash-style kernel serves the spatial case (sequence = the H*W pixels of one frame, non-causal) and the
+// temporal case (sequence = the T frames of one pixel, causal): a token's address is
+//     base(seq) + pos * pos_stride + head * DH,   base(seq) = (seq / n_inner) * stride_outer + (seq % n_inner) * stride_inner
+// so the reference's rearranges/pack/unpack (attention.py:289-306, 357-371) are pure address arithmetic.
+//
+// MFMA formulation ("swapped" operands, so that softmax is lane-local):
+//   S^T[key][query] = mfma(A = K rows (ds_read_b128), B = Q rows (registers))       lane & 31 = query
+//   P^T is already laid out as the B operand of the second product when V^T is read with the matching key
+//   permutation, which is exactly what two ds_read_b64_tr_b16 per fragment deliver:
+//   O^T[d][query]   = mfma(A = V^T (transposing LDS reads), B = P^T (registers))
+// One wave = 32 queries; a workgroup of 1..4 waves shares the K/V tiles (64 keys) in LDS.
+#include "common.h"
+#include "genie_hip.h"
+
+static __device__ __attribute__((aligned(256))) uint32_t g_zero_page_a[64];
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+// ------------------------------------------------------------------------------------------------
+// rotary + LayerNorm prologue: one wave per token, C <= 2048
+// x, u: [ntok][C] bf16 rows (row pitch = pitch elements); pos(token) = (token / pos_div) % pos_mod
+// cs: fp32 table [npos][C] holding cos in even slots and sin in odd slots of each feature PAIR:
+//     cs[p][2i] = cos(p * freq_i), cs[p][2i+1] = sin(p * freq_i)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) rotary_ln_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ u, long long ntok, int C,
+                                                            long long pitch, const float* __restrict__ cs, long long pos_div, int pos_mod,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                            float* __restrict__ stats /* [ntok][2] mean, rstd of the rotated row */) {
+    const int lane = threadIdx.x & 63;
+    const long long tok = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tok >= ntok) return;
+    const int pos = (int)((tok / pos_div) % pos_mod);
+    const bf16_t* xr = x + tok * pitch;
+    const float* csr = cs ? cs + (long long)pos * C : nullptr;
+    float v[32];                      // up to 4 chunks of 8 per lane (C <= 2048)
+    float s = 0.f, q = 0.f;
+    const int nch = C >> 3;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int ch = lane + it * 64;
+        if (ch < nch) {
+            float f[8];
+            unpack8(*reinterpret_cast<const u32x4_t*>(xr + ch * 8), f);
+            if (csr) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float c = csr[ch * 8 + 2 * j], sn = csr[ch * 8 + 2 * j + 1];
+                    const float a = f[2 * j], b = f[2 * j + 1];
+                    f[2 * j] = a * c - b * sn;          // x1 cos - x2 sin
+                    f[2 * j + 1] = b * c + a * sn;      // x2 cos + x1 sin
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { v[it * 8 + j] = f[j]; s += f[j]; q += f[j] * f[j]; }
+        }
+    }
+    s = wave_sum(s);
+    q = wave_sum(q);
+    const float mean = s / (float)C;
+    float var = q / (float)C - mean * mean;
+    var = var < 0.f ? 0.f : var;
+    const float rstd = rsqrtf(var + eps);
+    if (lane == 0 && stats) { stats[tok * 2] = mean; stats[tok * 2 + 1] = rstd; }
+    bf16_t* ur = u + tok * pitch;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int ch = lane + it * 64;
+        if (ch < nch) {
+            float f[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = ch * 8 + j;
+                f[j] = (v[it * 8 + j] - mean) * rstd * (gamma ? gamma[c] : 1.f) + (beta ? beta[c] : 0.f);
+            }
+            *reinterpret_cast<u32x4_t*>(ur + ch * 8) = pack8(f);
+        }
+    }
+}
+
+// backward of u = LN(rot(x)):  dx = rot^T( LN'(du) ), dgamma += sum du * xhat, dbeta += sum du
+__global__ void __launch_bounds__(256) rotary_ln_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ du,
+                                                            const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx, long long ntok,
+                                                            int C, long long pitch, const float* __restrict__ cs, long long pos_div,
+                                                            int pos_mod, const float* __restrict__ gamma, const float* __restrict__ stats,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    extern __shared__ float sm[];     // [2][C] block-level partial sums of dgamma / dbeta
+    const int lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < 2 * C; i += 256) sm[i] = 0.f;
+    __syncthreads();
+    const int nch = C >> 3;
+    for (long long tok = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); tok < ntok; tok += (long long)gridDim.x * 4) {
+        const int pos = (int)((tok / pos_div) % pos_mod);
+        const float* csr = cs ? cs + (long long)pos * C : nullptr;
+        const float mean = stats[tok * 2], rstd = stats[tok * 2 + 1];
+        float xh[32], g[32];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int ch = lane + it * 64;
+            if (ch < nch) {
+                float f[8], d[8];
+                unpack8(*reinterpret_cast<const u32x4_t*>(x + tok * pitch + ch * 8), f);
+                unpack8(*reinterpret_cast<const u32x4_t*>(du + tok * pitch + ch * 8), d);
+                if (csr) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float c = csr[ch * 8 + 2 * j], sn = csr[ch * 8 + 2 * j + 1];
+                        const float a = f[2 * j], b = f[2 * j + 1];
+                        f[2 * j] = a * c - b * sn;
+                        f[2 * j + 1] = b * c + a * sn;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int c = ch * 8 + j;
+                    const float h = (f[j] - mean) * rstd;
+                    const float gg = d[j] * (gamma ? gamma[c] : 1.f);
+                    xh[it * 8 + j] = h; g[it * 8 + j] = gg;
+                    s1 += gg; s2 += gg * h;
+                    atomicAdd(&sm[c], d[j] * h);
+                    atomicAdd(&sm[C + c], d[j]);
+                }
+            }
+        }
+        s1 = wave_sum(s1) / (float)C;
+        s2 = wave_sum(s2) / (float)C;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int ch = lane + it * 64;
+            if (ch < nch) {
+                float f[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) f[j] = rstd * (g[it * 8 + j] - s1 - xh[it * 8 + j] * s2);      // d/d(rotated x)
+                if (csr) {                                                                               // transpose of the rotation
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float c = csr[ch * 8 + 2 * j], sn = csr[ch * 8 + 2 * j + 1];
+                        const float a = f[2 * j], b = f[2 * j + 1];
+                        f[2 * j] = a * c + b * sn;
+                        f[2 * j + 1] = b * c - a * sn;
+                    }
+                }
+                if (dres) {
+                    float r[8];
+                    unpack8(*reinterpret_cast<const u32x4_t*>(dres + tok * pitch + ch * 8), r);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) f[j] += r[j];
+                }
+                *reinterpret_cast<u32x4_t*>(dx + tok * pitch + ch * 8) = pack8(f);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C; i += 256) {
+        if (dgamma) atomicAdd(dgamma + i, sm[i]);
+        if (dbeta) atomicAdd(dbeta + i, sm[C + i]);
+    }
+}
+
+extern "C" int genie_rotary_layernorm_fwd(const void* x, void* u, int64_t ntok, int C, int64_t pitch, const float* cos_sin, int64_t pos_div,
+                                          int pos_mod, const float* gamma, const float* beta, float eps, float* stats, void* stream) {
+    GENIE_CHECK_ARG(x && u, "genie_rotary_layernorm_fwd: null pointer");
+    GENIE_CHECK_ARG(C % 8 == 0 && C <= 2048 && pitch >= C && pitch % 8 == 0, "genie_rotary_layernorm_fwd: C=%d must be a multiple of 8, <= 2048, pitch %lld", C, (long long)pitch);
+    GENIE_CHECK_ARG(pos_div >= 1 && pos_mod >= 1, "genie_rotary_layernorm_fwd: bad position spec");
+    if (ntok == 0) return GENIE_OK;
+    rotary_ln_fwd_kernel<<<(unsigned)((ntok + 3) / 4), 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, (bf16_t*)u, ntok, C, pitch, cos_sin, pos_div, pos_mod, gamma, beta, eps, stats);
+    GENIE_CHECK_LAUNCH();
+    return GENIE_OK;
+}
+
+extern "C" int genie_rotary_layernorm_bwd(const void* x, const void* du, const void* dres, void* dx, int64_t ntok, int C, int64_t pitch,
+                                          const float* cos_sin, int64_t pos_div, int pos_mod, const float* gamma, const float* stats,
+                                          float* dgamma, float* dbeta, void* stream) {
+    GENIE_CHECK_ARG(x && du && dx && stats, "genie_rotary_layernorm_bwd: null pointer");
+    GENIE_CHECK_ARG(C % 8 == 0 && C <= 2048 && pitch >= C && pitch % 8 == 0, "genie_rotary_layernorm_bwd: bad C=%d / pitch", C);
+    if (ntok == 0) return GENIE_OK;
+    long long blocks = (ntok + 3) / 4;
+    if (blocks > 1024) blocks = 1024;
+    rotary_ln_bwd_kernel<<<(unsigned)blocks, 256, 2 * C * sizeof(float), (hipStream_t)stream>>>((const bf16_t*)x, (const bf16_t*)du, (const bf16_t*)dres, (bf16_t*)dx, ntok, C, pitch, cos_sin, pos_div, pos_mod, gamma, stats, dgamma, dbeta);
+    GENIE_CHECK_LAUNCH();
+    return GENIE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// attention core
+// ------------------------------------------------------------------------------------------------
+struct SeqMap {
+    int n_inner;
+    long long stride_outer, stride_inner, pos_stride;
+};
+
+__device__ __forceinline__ long long seq_base(const SeqMap& m, int seq) {
+    return (long long)(seq / m.n_inner) * m.stride_outer + (long long)(seq % m.n_inner) * m.stride_inner;
+}
+
+struct AttnArgs {
+    const bf16_t* q; const bf16_t* k; const bf16_t* v; const bf16_t* resid; bf16_t* out;
+    float* lse;                 // [token][nhead], token = (element offset of the token row) / C  (may be null)
+    int C;                      // channels per token row (= nhead * DH for the q/out tensor)
+    SeqMap qm, km, om;          // q/out/resid share qm for addressing of q; om for out & resid
+    int nseq, nhead, Sq, Sk;
+    float scale;
+    int causal;
+    int kv_same;                // k == v tile (one LDS image)
+};
+
+template <int DH>
+__global__ void __launch_bounds__(256) attn_fwd_kernel(const AttnArgs a) {
+    constexpr int KT = 64;                       // keys per tile
+    constexpr int ROWB = DH * 2;                 // bytes per LDS row
+    constexpr int CPR = DH / 8;                  // 16-B chunks per row
+    constexpr int TILE = KT * ROWB;
+    constexpr int KS = DH / 16;                  // MFMA k-steps of the QK^T product
+    constexpr int DT = DH / 32;                  // 32-row tiles of O^T
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ktile = smem;
+    char* vtile = a.kv_same ? smem : smem + TILE;
+
+    const int tid = threadIdx.x, lane = tid & 63, nw = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qtiles = (a.Sq + 32 * nw - 1) / (32 * nw);
+    const int seq = blockIdx.x / qtiles, qtile = blockIdx.x % qtiles, head = blockIdx.y;
+    const int q0 = qtile * (32 * nw) + wave * 32;
+    const int qi = q0 + (lane & 31);             // this lane's query
+    const int h = lane >> 5;
+    const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page_a);
+
+    // swizzle of a 16-B chunk inside an LDS row (bank-conflict-free ds_read_b128 over 32 rows)
+    auto swz = [&](int row, int chunk) -> int {
+        if (CPR >= 8) return chunk ^ ((row >> 1) & 7);
+        if (CPR == 4) return chunk ^ ((row >> 2) & 3);
+        return chunk;
+    };
+
+    // Q fragments (B operand): Q[query][16 ks + 8 h .. + 7]
+    bf16x8_t qf[KS];
+    {
+        const bf16_t* qrow = a.q + seq_base(a.qm, seq) + (long long)(qi < a.Sq ? qi : 0) * a.qm.pos_stride + head * DH;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (qi < a.Sq) qf[ks] = *reinterpret_cast<const bf16x8_t*>(qrow + ks * 16 + h * 8);
+            else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) qf[ks][e] = 0;
+            }
+        }
+    }
+
+    f32x16_t oacc[DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
+    float m_run = -1e30f, l_run = 0.f;
+
+    const long long kbase = seq_base(a.km, seq) + head * DH;
+    const int blk_q_max = qtile * (32 * nw) + 32 * nw - 1;   // causal: no key beyond the block's last query contributes
+    int k_end = a.Sk;
+    if (a.causal && blk_q_max + 1 < k_end) k_end = blk_q_max + 1;
+
+    for (int k0 = 0; k0 < k_end; k0 += KT) {
+        // ---- stage K (and V) tile: 64 rows x DH, DMA 16 B per lane, source-side swizzle ----
+        __syncthreads();
+        for (int slab = wave; slab < TILE / 1024; slab += nw) {
+            const int idx = slab * 64 + lane;                // 16-B unit index inside the tile
+            const int row = idx / CPR, pc = idx % CPR;
+            const int lc = swz(row, pc);
+            const int key = k0 + row;
+            const bf16_t* pk = zero;
+            const bf16_t* pv = zero;
+            if (key < a.Sk) {
+                const long long off = kbase + (long long)key * a.km.pos_stride + lc * 8;
+                pk = a.k + off;
+                pv = a.v + off;
+            }
+            __builtin_amdgcn_global_load_lds(GLB_PTR(pk), LDS_PTR(ktile + slab * 1024), 16, 0, 0);
+            if (!a.kv_same) __builtin_amdgcn_global_load_lds(GLB_PTR(pv), LDS_PTR(vtile + slab * 1024), 16, 0, 0);
+        }
+        __syncthreads();
+
+        // ---- S^T = K Q^T for two 32-key tiles ----
+        f32x16_t sacc[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[kt][r] = 0.f;
+            const int row = kt * 32 + (lane & 31);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(ktile + row * ROWB + (swz(row, ks * 2 + h) << 4));
+                sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[kt], 0, 0, 0);
+            }
+        }
+        // ---- mask, online softmax (lane-local + one cross-half exchange) ----
+        float tmax = -1e30f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = k0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                float s = sacc[kt][r] * a.scale;
+                if (key >= a.Sk || (a.causal && key > qi)) s = -INFINITY;
+                sacc[kt][r] = s;
+                tmax = fmaxf(tmax, s);
+            }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m_run, tmax);
+        const float alpha = __expf(m_run - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __expf(sacc[kt][r] - m_new);
+                sacc[kt][r] = p;
+                psum += p;
+            }
+        psum += __shfl_xor(psum, 32, 64);
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+
+        // ---- O^T += V^T P^T ----
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                bf16x8_t pf;
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                    const uint32_t pk2 = pack_bf16x2(sacc[kt][8 * s + e], sacc[kt][8 * s + e + 1]);
+                    pf[e] = (short)(pk2 & 0xffff);
+                    pf[e + 1] = (short)(pk2 >> 16);
+                }
+                // V^T fragment: lane = 16 g + 4 r + q reads keys (base + r), d columns 16 (g & 1) + 4 q .. + 3
+                const int g16 = lane >> 4, rr = (lane >> 2) & 3, qq = lane & 3;
+                const int keyrow0 = kt * 32 + 16 * s + 4 * (g16 >> 1) + rr;
+#pragma unroll
+                for (int d = 0; d < DT; ++d) {
+                    const int col = d * 32 + 16 * (g16 & 1) + 4 * qq;
+                    const int r0 = keyrow0, r1 = keyrow0 + 8;
+                    const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) bf16x4_t*)(vtile + r0 * ROWB + (swz(r0, col >> 3) << 4) + (col & 7) * 2));
+                    const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) bf16x4_t*)(vtile + r1 * ROWB + (swz(r1, col >> 3) << 4) + (col & 7) * 2));
+                    const bf16x8_t vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[d], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: O / l (+ resid); lane holds, for its query, d = 32 dt + (r & 3) + 8 (r >> 2) + 4 h ----
+    if (qi < a.Sq) {
+        const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+        const long long obase = seq_base(a.om, seq) + (long long)qi * a.om.pos_stride + head * DH;
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int dd = d * 32 + 8 * g + 4 * h;
+                float f[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) f[e] = oacc[d][4 * g + e] * inv;
+                if (a.resid) {
+                    const u32x2_t rv = *reinterpret_cast<const u32x2_t*>(a.resid + obase + dd);
+                    f[0] += __uint_as_float(rv[0] << 16); f[1] += __uint_as_float(rv[0] & 0xffff0000u);
+                    f[2] += __uint_as_float(rv[1] << 16); f[3] += __uint_as_float(rv[1] & 0xffff0000u);
+                }
+                u32x2_t ov;
+                ov[0] = pack_bf16x2(f[0], f[1]);
+                ov[1] = pack_bf16x2(f[2], f[3]);
+                *reinterpret_cast<u32x2_t*>(a.out + obase + dd) = ov;
+            }
+        if (a.lse && h == 0) a.lse[((obase - head * DH) / a.C) * a.nhead + head] = m_run + __logf(l_run);
+    }
+}
+
+static SeqMap mk_map(const int64_t* m) {
+    SeqMap s;
+    s.n_inner = (int)m[0]; s.stride_outer = m[1]; s.stride_inner = m[2]; s.pos_stride = m[3];
+    return s;
+}
+
+extern "C" int genie_attention_fwd(const void* q, const void* k, const void* v, const void* resid, void* out, float* lse, int nseq, int nhead,
+                                   int d_head, int Sq, int Sk, const int64_t* q_map, const int64_t* kv_map, const int64_t* out_map, float scale,
+                                   int causal, int out_channels, void* stream) {
+    GENIE_CHECK_ARG(q && k && v && out && q_map && kv_map && out_map, "genie_attention_fwd: null pointer");
+    GENIE_CHECK_ARG(d_head == 32 || d_head == 64 || d_head == 128, "genie_attention_fwd: d_head %d not in {32, 64, 128}", d_head);
+    GENIE_CHECK_ARG(nseq >= 1 && nhead >= 1 && Sq >= 1 && Sk >= 1, "genie_attention_fwd: empty problem");
+    AttnArgs a;
+    a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.resid = (const bf16_t*)resid; a.out = (bf16_t*)out; a.lse = lse;
+    a.qm = mk_map(q_map); a.km = mk_map(kv_map); a.om = mk_map(out_map);
+    GENIE_CHECK_ARG(a.qm.n_inner >= 1 && a.km.n_inner >= 1 && a.om.n_inner >= 1, "genie_attention_fwd: bad sequence map");
+    a.nseq = nseq; a.nhead = nhead; a.Sq = Sq; a.Sk = Sk; a.scale = scale; a.causal = causal; a.kv_same = (k == v) ? 1 : 0;
+    a.C = out_channels;
+    GENIE_CHECK_ARG(out_channels >= nhead * d_head, "genie_attention_fwd: out_channels %d < nhead * d_head", out_channels);
+    int nw = (Sq + 31) / 32;
+    if (nw > 4) nw = 4;
+    const int qtiles = (Sq + 32 * nw - 1) / (32 * nw);
+    GENIE_CHECK_ARG((long long)nseq * qtiles < (1ll << 31) && nhead <= 65535, "genie_attention_fwd: grid too large");
+    const int tile = 64 * d_head * 2;
+    const int lds = a.kv_same ? tile : 2 * tile;
+    dim3 grid((unsigned)(nseq * qtiles), nhead, 1);
+    hipStream_t s = (hipStream_t)stream;
+    if (d_head == 32) attn_fwd_kernel<32><<<grid, 64 * nw, lds, s>>>(a);
+    else if (d_head == 64) attn_fwd_kernel<64><<<grid, 64 * nw, lds, s>>>(a);
+    else attn_fwd_kernel<128><<<grid, 64 * nw, lds, s>>>(a);
+    GENIE_CHECK_LAUNCH();
+    return GENIE_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// backward
+//   D[token][head] = sum_d dO * (out - resid)                                   (preprocess)
+//   dQ kernel  : per query tile, loop over key tiles   (lane = query, as forward)
+//   dKV kernel : per key tile, loop over query tiles   (lane = key)
+// ------------------------------------------------------------------------------------------------
+template <int DH>
+__global__ void __launch_bounds__(256) attn_bwd_prep_kernel(const bf16_t* __restrict__ dO, const bf16_t* __restrict__ out,
+                                                            const bf16_t* __restrict__ resid, float* __restrict__ D, long long ntok, int C,
+                                                            int nhead) {
+    const int lane = threadIdx.x & 63;
+    const long long tok = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tok >= ntok) return;
+    constexpr int LPH = DH / 8;                   // lanes per head
+    const int nch = (nhead * DH) >> 3;
+    for (int ch = lane; ch < ((nch + 63) / 64) * 64; ch += 64) {
+        float acc = 0.f;
+        if (ch < nch) {
+            float a[8], b[8];
+            unpack8(*reinterpret_cast<const u32x4_t*>(dO + tok * C + ch * 8), a);
+            unpack8(*reinterpret_cast<const u32x4_t*>(out + tok * C + ch * 8), b);
+            if (resid) {
+                float r[8];
+                unpack8(*reinterpret_cast<const u32x4_t*>(resid + tok * C + ch * 8), r);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) b[j] -= r[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc += a[j] * b[j];
+        }
+#pragma unroll
+        for (int o = 1; o < LPH; o <<= 1) acc += __shfl_xor(acc, o, 64);
+        if (ch < nch && (ch % LPH) == 0) D[tok * nhead + ch / LPH] = acc;
+    }
+}
+
+struct AttnBwdArgs {
+    const bf16_t* q; const bf16_t* k; const bf16_t* v; const bf16_t* dO;
+    const float* lse; const float* D;
+    bf16_t* dq; bf16_t* dk; bf16_t* dv;      // dq: q-map addressing; dk/dv: kv-map addressing (dkv kernel)
+    const bf16_t* dq_in;                      // dkv kernel, fused self-attention: dk row += dq_in row (then dk holds dQ + dK + dV)
+    SeqMap qm, km, om, dkm;
+    int nseq, nhead, Sq, Sk, C, Ckv;
+    float scale;
+    int causal, kv_same, fuse_self;
+};
+
+template <int DH>
+__global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const AttnBwdArgs a) {
+    constexpr int KT = 64, ROWB = DH * 2, CPR = DH / 8, TILE = KT * ROWB, KS = DH / 16, DT = DH / 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ktile = smem;
+    char* vtile = a.kv_same ? smem : smem + TILE;
+    const int tid = threadIdx.x, lane = tid & 63, nw = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qtiles = (a.Sq + 32 * nw - 1) / (32 * nw);
+    const int seq = blockIdx.x / qtiles, qtile = blockIdx.x % qtiles, head = blockIdx.y;
+    const int q0 = qtile * (32 * nw) + wave * 32;
+    const int qi = q0 + (lane & 31), h = lane >> 5;
+    const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page_a);
+    auto swz = [&](int row, int chunk) -> int {
+        if (CPR >= 8) return chunk ^ ((row >> 1) & 7);
+        if (CPR == 4) return chunk ^ ((row >> 2) & 3);
+        return chunk;
+    };
+    bf16x8_t qf[KS], dof[KS];
+    float lse_q = 0.f, D_q = 0.f;
+    {
+        const bool ok = qi < a.Sq;
+        const long long qoff = seq_base(a.qm, seq) + (long long)(ok ? qi : 0) * a.qm.pos_stride;
+        const long long ooff = seq_base(a.om, seq) + (long long)(ok ? qi : 0) * a.om.pos_stride;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (ok) {
+                qf[ks] = *reinterpret_cast<const bf16x8_t*>(a.q + qoff + head * DH + ks * 16 + h * 8);
+                dof[ks] = *reinterpret_cast<const bf16x8_t*>(a.dO + ooff + head * DH + ks * 16 + h * 8);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { qf[ks][e] = 0; dof[ks][e] = 0; }
+            }
+        }
+        if (ok) {
+            const long long tok = ooff / a.C;
+            lse_q = a.lse[tok * a.nhead + head];
+            D_q = a.D[tok * a.nhead + head];
+        }
+    }
+    f32x16_t dq[DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[d][r] = 0.f;
+    const long long kbase = seq_base(a.km, seq) + head * DH;
+    const int blk_q_max = qtile * (32 * nw) + 32 * nw - 1;
+    int k_end = a.Sk;
+    if (a.causal && blk_q_max + 1 < k_end) k_end = blk_q_max + 1;
+    const int g16 = lane >> 4, rr = (lane >> 2) & 3, qq = lane & 3;
+
+    for (int k0 = 0; k0 < k_end; k0 += KT) {
+        __syncthreads();
+        for (int slab = wave; slab < TILE / 1024; slab += nw) {
+            const int idx = slab * 64 + lane;
+            const int row = idx / CPR, pc = idx % CPR;
+            const int lc = swz(row, pc);
+            const int key = k0 + row;
+            const bf16_t* pk = zero;
+            const bf16_t* pv = zero;
+            if (key < a.Sk) {
+                const long long off = kbase + (long long)key * a.km.pos_stride + lc * 8;
+                pk = a.k + off;
+                pv = a.v + off;
+            }
+            __builtin_amdgcn_global_load_lds(GLB_PTR(pk), LDS_PTR(ktile + slab * 1024), 16, 0, 0);
+            if (!a.kv_same) __builtin_amdgcn_global_load_lds(GLB_PTR(pv), LDS_PTR(vtile + slab * 1024), 16, 0, 0);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            f32x16_t sacc, pacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; pacc[r] = 0.f; }
+            const int row = kt * 32 + (lane & 31);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int off = row * ROWB + (swz(row, ks * 2 + h) << 4);
+                const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(ktile + off);
+                const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(vtile + off);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc, 0, 0, 0);      // S^T
+                pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks], pacc, 0, 0, 0);     // dP^T
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = k0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const bool dead = key >= a.Sk || (a.causal && key > qi) || qi >= a.Sq;
+                const float p = dead ? 0.f : __expf(sacc[r] * a.scale - lse_q);
+                sacc[r] = p * (pacc[r] - D_q) * a.scale;                                         // dS^T
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                bf16x8_t df;
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                    const uint32_t pk2 = pack_bf16x2(sacc[8 * s + e], sacc[8 * s + e + 1]);
+                    df[e] = (short)(pk2 & 0xffff);
+                    df[e + 1] = (short)(pk2 >> 16);
+                }
+                const int r0 = kt * 32 + 16 * s + 4 * (g16 >> 1) + rr, r1 = r0 + 8;
+#pragma unroll
+                for (int d = 0; d < DT; ++d) {
+                    const int col = d * 32 + 16 * (g16 & 1) + 4 * qq;
+                    const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) bf16x4_t*)(ktile + r0 * ROWB + (swz(r0, col >> 3) << 4) + (col & 7) * 2));
+                    const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) bf16x4_t*)(ktile + r1 * ROWB + (swz(r1, col >> 3) << 4) + (col & 7) * 2));
+                    const bf16x8_t kT = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    dq[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kT, df, dq[d], 0, 0, 0);       // dQ^T += K^T dS^T
+                }
+            }
+        }
+    }
+    if (qi < a.Sq) {
+        const long long obase = seq_base(a.qm, seq) + (long long)qi * a.qm.pos_stride + head * DH;
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                u32x2_t ov;
+                ov[0] = pack_bf16x2(dq[d][4 * g], dq[d][4 * g + 1]);
+                ov[1] = pack_bf16x2(dq[d][4 * g + 2], dq[d][4 * g + 3]);
+                *reinterpret_cast<u32x2_t*>(a.dq + obase + d * 32 + 8 * g + 4 * h) = ov;
+            }
+    }
+}
+
+template <int DH>
+__global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const AttnBwdArgs a) {
+    constexpr int QT = 64, ROWB = DH * 2, CPR = DH / 8, TILE = QT * ROWB, KS = DH / 16, DT = DH / 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* qtile_l = smem;
+    char* dotile = smem + TILE;
+    float* lse_l = reinterpret_cast<float*>(smem + 2 * TILE);
+    float* D_l = lse_l + QT;
+    const int tid = threadIdx.x, lane = tid & 63, nw = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ktiles = (a.Sk + 32 * nw - 1) / (32 * nw);
+    const int seq = blockIdx.x / ktiles, ktile_i = blockIdx.x % ktiles, head = blockIdx.y;
+    const int key0 = ktile_i * (32 * nw) + wave * 32;
+    const int ki = key0 + (lane & 31), h = lane >> 5;
+    const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page_a);
+    auto swz = [&](int row, int chunk) -> int {
+        if (CPR >= 8) return chunk ^ ((row >> 1) & 7);
+        if (CPR == 4) return chunk ^ ((row >> 2) & 3);
+        return chunk;
+    };
+    bf16x8_t kf[KS], vf[KS];
+    {
+        const bool ok = ki < a.Sk;
+        const long long off = seq_base(a.km, seq) + (long long)(ok ? ki : 0) * a.km.pos_stride + head * DH;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (ok) {
+                kf[ks] = *reinterpret_cast<const bf16x8_t*>(a.k + off + ks * 16 + h * 8);
+                vf[ks] = *reinterpret_cast<const bf16x8_t*>(a.v + off + ks * 16 + h * 8);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { kf[ks][e] = 0; vf[ks][e] = 0; }
+            }
+        }
+    }
+    f32x16_t dk[DT], dv[DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[d][r] = 0.f; dv[d][r] = 0.f; }
+    const long long qbase = seq_base(a.qm, seq) + head * DH;
+    const long long obase_s = seq_base(a.om, seq) + head * DH;
+    const int blk_key_min = ktile_i * (32 * nw);
+    const int q_begin = a.causal ? (blk_key_min / QT) * QT : 0;      // queries before the first key of the block see none of its keys
+    const int g16 = lane >> 4, rr = (lane >> 2) & 3, qq = lane & 3;
+
+    for (int qs = q_begin; qs < a.Sq; qs += QT) {
+        __syncthreads();
+        for (int slab = wave; slab < TILE / 1024; slab += nw) {
+            const int idx = slab * 64 + lane;
+            const int row = idx / CPR, pc = idx % CPR;
+            const int lc = swz(row, pc);
+            const int qrow = qs + row;
+            const bf16_t* pq = zero;
+            const bf16_t* pd = zero;
+            if (qrow < a.Sq) {
+                pq = a.q + qbase + (long long)qrow * a.qm.pos_stride + lc * 8;
+                pd = a.dO + obase_s + (long long)qrow * a.om.pos_stride + lc * 8;
+            }
+            __builtin_amdgcn_global_load_lds(GLB_PTR(pq), LDS_PTR(qtile_l + slab * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(pd), LDS_PTR(dotile + slab * 1024), 16, 0, 0);
+        }
+        if (tid < QT) {
+            const int qrow = qs + tid;
+            float l = 0.f, dd = 0.f;
+            if (qrow < a.Sq) {
+                const long long tok = (seq_base(a.om, seq) + (long long)qrow * a.om.pos_stride) / a.C;
+                l = a.lse[tok * a.nhead + head];
+                dd = a.D[tok * a.nhead + head];
+            }
+            lse_l[tid] = l; D_l[tid] = dd;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            f32x16_t sacc, pacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; pacc[r] = 0.f; }
+            const int row = qt * 32 + (lane & 31);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int off = row * ROWB + (swz(row, ks * 2 + h) << 4);
+                const bf16x8_t qfr = *reinterpret_cast<const bf16x8_t*>(qtile_l + off);
+                const bf16x8_t dofr = *reinterpret_cast<const bf16x8_t*>(dotile + off);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr, kf[ks], sacc, 0, 0, 0);       // S[q][key]
+                pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dofr, vf[ks], pacc, 0, 0, 0);      // dP[q][key]
+            }
+            f32x16_t ds;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ql = qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int qg = qs + ql;
+                const bool dead = qg >= a.Sq || ki >= a.Sk || (a.causal && ki > qg);
+                const float p = dead ? 0.f : __expf(sacc[r] * a.scale - lse_l[ql]);
+                sacc[r] = p;
+                ds[r] = p * (pacc[r] - D_l[ql]) * a.scale;
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                bf16x8_t pf, df;
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                    const uint32_t a2 = pack_bf16x2(sacc[8 * s + e], sacc[8 * s + e + 1]);
+                    const uint32_t b2 = pack_bf16x2(ds[8 * s + e], ds[8 * s + e + 1]);
+                    pf[e] = (short)(a2 & 0xffff); pf[e + 1] = (short)(a2 >> 16);
+                    df[e] = (short)(b2 & 0xffff); df[e + 1] = (short)(b2 >> 16);
+                }
+                const int r0 = qt * 32 + 16 * s + 4 * (g16 >> 1) + rr, r1 = r0 + 8;
+#pragma unroll
+                for (int d = 0; d < DT; ++d) {
+                    const int col = d * 32 + 16 * (g16 & 1) + 4 * qq;
+                    const int o0 = r0 * ROWB + (swz(r0, col >> 3) << 4) + (col & 7) * 2;
+                    const int o1 = r1 * ROWB + (swz(r1, col >> 3) << 4) + (col & 7) * 2;
+                    const bf16x4_t dlo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4_t*)(dotile + o0));
+                    const bf16x4_t dhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4_t*)(dotile + o1));
+                    const bf16x4_t qlo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4_t*)(qtile_l + o0));
+                    const bf16x4_t qhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4_t*)(qtile_l + o1));
+                    const bf16x8_t doT = __builtin_shufflevector(dlo, dhi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    const bf16x8_t qT = __builtin_shufflevector(qlo, qhi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    dv[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(doT, pf, dv[d], 0, 0, 0);       // dV^T += dO^T P
+                    dk[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qT, df, dk[d], 0, 0, 0);        // dK^T += Q^T dS
+                }
+            }
+        }
+    }
+    if (ki < a.Sk) {
+        const long long kb = seq_base(a.dkm, seq) + (long long)ki * a.dkm.pos_stride + head * DH;
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const long long o = kb + d * 32 + 8 * g + 4 * h;
+                float fk[4], fv[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { fk[e] = dk[d][4 * g + e]; fv[e] = dv[d][4 * g + e]; }
+                if (a.fuse_self) {
+                    const u32x2_t rv = *reinterpret_cast<const u32x2_t*>(a.dq_in + o);
+                    fk[0] += fv[0] + __uint_as_float(rv[0] << 16); fk[1] += fv[1] + __uint_as_float(rv[0] & 0xffff0000u);
+                    fk[2] += fv[2] + __uint_as_float(rv[1] << 16); fk[3] += fv[3] + __uint_as_float(rv[1] & 0xffff0000u);
+                    u32x2_t ov; ov[0] = pack_bf16x2(fk[0], fk[1]); ov[1] = pack_bf16x2(fk[2], fk[3]);
+                    *reinterpret_cast<u32x2_t*>(a.dk + o) = ov;
+                } else {
+                    u32x2_t ok_, ov_;
+                    ok_[0] = pack_bf16x2(fk[0], fk[1]); ok_[1] = pack_bf16x2(fk[2], fk[3]);
+                    ov_[0] = pack_bf16x2(fv[0], fv[1]); ov_[1] = pack_bf16x2(fv[2], fv[3]);
+                    *reinterpret_cast<u32x2_t*>(a.dk + o) = ok_;
+                    *reinterpret_cast<u32x2_t*>(a.dv + o) = ov_;
+                }
+            }
+    }
+}
+
+// q, k, v, dO: as forward (dO / out / resid share out_map).  Self-attention (q == k == v): du receives dQ + dK + dV.
+// Otherwise dq gets dQ (q-map) and dk / dv (kv-map addressing, caller-provided buffers) get dK / dV.
+extern "C" int genie_attention_bwd(const void* q, const void* k, const void* v, const void* out, const void* resid, const void* dO,
+                                   const float* lse, float* D_ws, void* dq, void* dk, void* dv, int nseq, int nhead, int d_head, int Sq,
+                                   int Sk, const int64_t* q_map, const int64_t* kv_map, const int64_t* out_map, const int64_t* dkv_map,
+                                   float scale, int causal, int out_channels, int64_t out_tokens, void* stream) {
+    GENIE_CHECK_ARG(q && k && v && out && dO && lse && D_ws && dq, "genie_attention_bwd: null pointer");
+    GENIE_CHECK_ARG(d_head == 32 || d_head == 64 || d_head == 128, "genie_attention_bwd: d_head %d not in {32, 64, 128}", d_head);
+    const bool self = (q == k && k == v);
+    GENIE_CHECK_ARG(self || (dk && dv), "genie_attention_bwd: dk/dv required when k/v differ from q");
+    AttnBwdArgs a;
+    a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.dO = (const bf16_t*)dO; a.lse = lse; a.D = D_ws;
+    a.dq = (bf16_t*)dq; a.dk = self ? (bf16_t*)dq : (bf16_t*)dk; a.dv = (bf16_t*)dv; a.dq_in = (const bf16_t*)dq;
+    a.qm = mk_map(q_map); a.km = mk_map(kv_map); a.om = mk_map(out_map); a.dkm = dkv_map ? mk_map(dkv_map) : a.km;
+    a.nseq = nseq; a.nhead = nhead; a.Sq = Sq; a.Sk = Sk; a.C = out_channels; a.Ckv = 0; a.scale = scale; a.causal = causal;
+    a.kv_same = (k == v) ? 1 : 0; a.fuse_self = self ? 1 : 0;
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned pblocks = (unsigned)((out_tokens + 3) / 4);
+    if (d_head == 32) attn_bwd_prep_kernel<32><<<pblocks, 256, 0, s>>>((const bf16_t*)dO, (const bf16_t*)out, (const bf16_t*)resid, D_ws, out_tokens, out_channels, nhead);
+    else if (d_head == 64) attn_bwd_prep_kernel<64><<<pblocks, 256, 0, s>>>((const bf16_t*)dO, (const bf16_t*)out, (const bf16_t*)resid, D_ws, out_tokens, out_channels, nhead);
+    else attn_bwd_prep_kernel<128><<<pblocks, 256, 0, s>>>((const bf16_t*)dO, (const bf16_t*)out, (const bf16_t*)resid, D_ws, out_tokens, out_channels, nhead);
+    GENIE_CHECK_LAUNCH();
+    int nwq = (Sq + 31) / 32; if (nwq > 4) nwq = 4;
+    int nwk = (Sk + 31) / 32; if (nwk > 4) nwk = 4;
+    const int qtiles = (Sq + 32 * nwq - 1) / (32 * nwq), ktiles = (Sk + 32 * nwk - 1) / (32 * nwk);
+    const int tile = 64 * d_head * 2;
+    const int lds_q = a.kv_same ? tile : 2 * tile;
+    const int lds_k = 2 * tile + 2 * 64 * 4;
+    dim3 gq((unsigned)(nseq * qtiles), nhead), gk((unsigned)(nseq * ktiles), nhead);
+    if (d_head == 32) { attn_bwd_dq_kernel<32><<<gq, 64 * nwq, lds_q, s>>>(a); attn_bwd_dkv_kernel<32><<<gk, 64 * nwk, lds_k, s>>>(a); }
+    else if (d_head == 64) { attn_bwd_dq_kernel<64><<<gq, 64 * nwq, lds_q, s>>>(a); attn_bwd_dkv_kernel<64><<<gk, 64 * nwk, lds_k, s>>>(a); }
+    else { attn_bwd_dq_kernel<128><<<gq, 64 * nwq, lds_q, s>>>(a); attn_bwd_dkv_kernel<128><<<gk, 64 * nwk, lds_k, s>>>(a); }
+    GENIE_CHECK_LAUNCH();
+    return GENIE_OK;
+}

@@ -38,6 +38,10 @@ struct IgemmArgs {
     int tiles_m, tiles_n;
     int nk;           // total K chunks
     int act;          // 0 none, 1 silu (epilogue)
+    int split_k;      // > 1: blockIdx.y = K split; partial tiles go to ws (fp32 [split][M][ws_ld]) and a second kernel finishes
+    int chunks_per_split;
+    float* ws;
+    int ws_ld;
 };
 
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
@@ -69,16 +73,19 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmArgs a) {
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page);
 
-    // SMALLC: the tap table lives in LDS behind the two stages
+    // the tap table lives in LDS behind the two stages; pad0 <- linear element offset of the tap inside the source
     GenieTap* lds_taps = reinterpret_cast<GenieTap*>(smem + 2 * STAGE);
-    if (SMALLC) {
-        for (int i = tid; i < a.ntaps * (int)(sizeof(GenieTap) / 4); i += 256)
-            reinterpret_cast<int*>(lds_taps)[i] = reinterpret_cast<const int*>(a.taps)[i];
-        __syncthreads();
+    for (int i = tid; i < a.ntaps; i += 256) {
+        GenieTap t = a.taps[i];
+        t.pad0 = ((t.dt * a.Hs + t.dh) * a.Ws + t.dw) * a.Cs + t.c0;
+        lds_taps[i] = t;
     }
+    __syncthreads();
 
     // ---- per-thread gather state for the A rows this lane stages ----
+    // a_t/a_h/a_w: source coordinate of tap (0,0,0); a_base: its linear element offset (+ this lane's 16-B sub-chunk)
     int a_n[A_LOADS], a_t[A_LOADS], a_h[A_LOADS], a_w[A_LOADS], a_lc[A_LOADS];
+    unsigned a_base[A_LOADS];
 #pragma unroll
     for (int i = 0; i < A_LOADS; ++i) {
         const int row = (i * 4 + wave) * 8 + (lane >> 3);
@@ -89,46 +96,73 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmArgs a) {
             const int ho = m % a.Ho; m /= a.Ho;
             const int to = m % a.To; m /= a.To;
             a_n[i] = m; a_t[i] = to * a.st; a_h[i] = ho * a.sh; a_w[i] = wo * a.sw;
+            a_base[i] = (((unsigned)(m * a.Ts + a_t[i]) * a.Hs + a_h[i]) * a.Ws + a_w[i]) * a.Cs + a_lc[i] * 8;
         } else {
-            a_n[i] = -1; a_t[i] = a_h[i] = a_w[i] = 0;
+            a_n[i] = -1; a_t[i] = a_h[i] = a_w[i] = 0; a_base[i] = 0;
+            a_t[i] = -(1 << 20);      // fails every range check below
         }
     }
     int b_row[B_LOADS], b_lc[B_LOADS];
+    const bf16_t* b_ptr[B_LOADS];   // weight row start + this lane's 16-B sub-chunk
 #pragma unroll
     for (int i = 0; i < B_LOADS; ++i) {
         const int row = (i * 4 + wave) * 8 + (lane >> 3);
         b_lc[i] = (lane & 7) ^ ((row >> 1) & 7);
         const int n = n0 + row;
         b_row[i] = n < a.Ncols ? (a.perm_f > 1 ? (n % a.perm_c) * a.perm_f + n / a.perm_c : n) : -1;
+        b_ptr[i] = a.wgt + (size_t)(b_row[i] < 0 ? 0 : b_row[i]) * a.w_row_stride + b_lc[i] * 8;
     }
 
     const int cpt = a.Cs >> 3;   // SMALLC: 16-B sub-chunks per tap
     int s_tap = 0, s_cb = 0;     // (tap, channel block) of the NEXT chunk to stage (uniform)
+    int kc_begin = 0, kc_end = a.nk;
+    if (a.split_k > 1) {
+        kc_begin = blockIdx.y * a.chunks_per_split;
+        kc_end = kc_begin + a.chunks_per_split;
+        if (kc_end > a.nk) kc_end = a.nk;
+        if (!SMALLC) {               // advance the (tap, channel block) cursor to chunk kc_begin
+            int left = kc_begin;
+            while (s_tap < a.ntaps) {
+                const int n = (a.taps[s_tap].nch + 63) >> 6;
+                if (left < n) break;
+                left -= n;
+                ++s_tap;
+            }
+            s_cb = left;
+        }
+    }
+    GenieTap cur_tap = lds_taps[s_tap < a.ntaps ? s_tap : 0];
 
     auto stage = [&](int kc, int buf) {
         char* abase = smem + buf * STAGE;
         char* bbase = abase + A_BYTES;
         if (!SMALLC) {
-            const GenieTap tp = a.taps[s_tap];
+            // current tap (wave-uniform, kept in SGPRs); branch-free validity: out-of-range lanes read the zero page
+            const int t_dt = __builtin_amdgcn_readfirstlane(cur_tap.dt), t_dh = __builtin_amdgcn_readfirstlane(cur_tap.dh);
+            const int t_dw = __builtin_amdgcn_readfirstlane(cur_tap.dw), t_wofs = __builtin_amdgcn_readfirstlane(cur_tap.wofs);
+            const int t_delta = __builtin_amdgcn_readfirstlane(cur_tap.pad0), t_nch = __builtin_amdgcn_readfirstlane(cur_tap.nch);
             const int cbase = s_cb * 64;
 #pragma unroll
             for (int i = 0; i < A_LOADS; ++i) {
-                const int t = a_t[i] + tp.dt, h = a_h[i] + tp.dh, w = a_w[i] + tp.dw;
-                const int c = cbase + a_lc[i] * 8;
-                const bool ok = a_n[i] >= 0 && (unsigned)t < (unsigned)a.Ts && (unsigned)h < (unsigned)a.Hs &&
-                                (unsigned)w < (unsigned)a.Ws && c < tp.nch;
-                const unsigned off = (((unsigned)(a_n[i] * a.Ts + t) * a.Hs + h) * a.Ws + w) * a.Cs + tp.c0 + c;
-                const bf16_t* p = ok ? a.src + off : zero;
+                const int t = a_t[i] + t_dt, h = a_h[i] + t_dh, w = a_w[i] + t_dw;
+                const bool ok = ((unsigned)t < (unsigned)a.Ts) & ((unsigned)h < (unsigned)a.Hs) & ((unsigned)w < (unsigned)a.Ws) &
+                                (cbase + a_lc[i] * 8 < t_nch);
+                const bf16_t* p = a.src + (a_base[i] + (unsigned)(t_delta + cbase));
+                p = ok ? p : zero;
                 __builtin_amdgcn_global_load_lds(GLB_PTR(p), LDS_PTR(abase + (i * 4 + wave) * 1024), 16, 0, 0);
             }
 #pragma unroll
             for (int i = 0; i < B_LOADS; ++i) {
-                const int c = cbase + b_lc[i] * 8;
-                const bool ok = b_row[i] >= 0 && c < tp.nch;
-                const bf16_t* p = ok ? a.wgt + (size_t)b_row[i] * a.w_row_stride + tp.wofs + c : zero;
+                const bool ok = (b_row[i] >= 0) & (cbase + b_lc[i] * 8 < t_nch);
+                const bf16_t* p = b_ptr[i] + (t_wofs + cbase);
+                p = ok ? p : zero;
                 __builtin_amdgcn_global_load_lds(GLB_PTR(p), LDS_PTR(bbase + (i * 4 + wave) * 1024), 16, 0, 0);
             }
-            if (++s_cb * 64 >= tp.nch) { s_cb = 0; ++s_tap; }
+            if (++s_cb * 64 >= t_nch) {
+                s_cb = 0;
+                ++s_tap;
+                cur_tap = lds_taps[s_tap < a.ntaps ? s_tap : 0];      // LDS read overlaps the MFMA phase that follows
+            }
         } else {
             // several taps per 64-wide K chunk: each 16-B sub-chunk g = kc*8 + lc belongs to tap g / cpt
 #pragma unroll
@@ -180,11 +214,11 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmArgs a) {
     }
     const int khalf = lane >> 5;
 
-    stage(0, 0);
+    if (kc_begin < kc_end) stage(kc_begin, 0);
     __syncthreads();
-    for (int kc = 0; kc < a.nk; ++kc) {
-        const int cur = kc & 1;
-        if (kc + 1 < a.nk) stage(kc + 1, cur ^ 1);
+    for (int kc = kc_begin; kc < kc_end; ++kc) {
+        const int cur = (kc - kc_begin) & 1;
+        if (kc + 1 < kc_end) stage(kc + 1, cur ^ 1);
         const char* base = smem + cur * STAGE;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -205,6 +239,23 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmArgs a) {
         __syncthreads();
     }
 
+    // ---- split-K: dump the fp32 partial tile, the finish kernel does bias / resid / act / layout ----
+    if (a.split_k > 1) {
+        float* wsp = a.ws + (size_t)blockIdx.y * a.M * a.ws_ld;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * (TN * 32) + j * 32 + (lane & 31);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r16 = 0; r16 < 16; ++r16) {
+                    const int m = m0 + wm * (TM * 32) + i * 32 + (r16 & 3) + 8 * (r16 >> 2) + 4 * khalf;
+                    if (m < a.M && n < a.ws_ld) wsp[(size_t)m * a.ws_ld + n] = acc[i][j][r16];
+                }
+        }
+        return;
+    }
+
     // ---- epilogue: dest offset = rowoff[m] + coloff[n]; rowoff staged through LDS ----
     int* rowoff = reinterpret_cast<int*>(smem);
     if (tid < BM) {
@@ -219,6 +270,71 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmArgs a) {
         rowoff[tid] = off;
     }
     __syncthreads();
+    const bool vec4 = (a.shuf_c & 3) == 0 && (a.Nstore & 3) == 0 && (a.Cd & 3) == 0;
+    if (vec4) {
+        // 4x4 transposes inside lane quads (DPP quad_perm): lane j of a quad ends up with ONE row and FOUR consecutive
+        // columns -> 8-byte stores instead of 2-byte ones (4x fewer store instructions)
+        const int jq = lane & 3;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int nq = n0 + wn * (TN * 32) + j * 32 + (lane & 28);         // first of this quad's 4 columns
+            const bool colok = nq < a.Nstore;
+            const int sub = nq / a.shuf_c, ch = nq - sub * a.shuf_c;
+            const int r_ = sub % a.shuf_r, q_ = (sub / a.shuf_r) % a.shuf_q, p_ = sub / (a.shuf_r * a.shuf_q);
+            const int coloff = ((p_ * a.Hd + q_) * a.Wd + r_) * a.Cd + ch;
+            float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+            if (a.bias && colok) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int n = nq + e;
+                    if (n < a.Ncols) bias4[e] = a.bias[a.perm_f > 1 ? (n % a.perm_c) * a.perm_f + n / a.perm_c : n];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
+                    // round 1: partner lane ^ 1 swaps the off-diagonal of each 2x2
+#pragma unroll
+                    for (int k = 0; k < 4; k += 2) {
+                        const float send = (jq & 1) ? v[k] : v[k + 1];
+                        const float recv = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0xB1, 0xF, 0xF, true));
+                        if (jq & 1) v[k] = recv; else v[k + 1] = recv;
+                    }
+                    // round 2: partner lane ^ 2
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const float send = (jq & 2) ? v[k] : v[k + 2];
+                        const float recv = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0x4E, 0xF, 0xF, true));
+                        if (jq & 2) v[k] = recv; else v[k + 2] = recv;
+                    }
+                    // now v[e] = value of row (8 g + 4 khalf + jq), column nq + e
+                    const int row = wm * (TM * 32) + i * 32 + 8 * g + 4 * khalf + jq;
+                    const int ro = rowoff[row];
+                    if (ro < 0 || !colok) continue;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += bias4[e];
+                    if (a.resid) {
+                        const u32x2_t rv = *reinterpret_cast<const u32x2_t*>(a.resid + (unsigned)ro + coloff);
+                        v[0] += __uint_as_float(rv[0] << 16); v[1] += __uint_as_float(rv[0] & 0xffff0000u);
+                        v[2] += __uint_as_float(rv[1] << 16); v[3] += __uint_as_float(rv[1] & 0xffff0000u);
+                    }
+                    if (a.act == 1) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+                    }
+                    u32x2_t ov;
+                    ov[0] = pack_bf16x2(v[0], v[1]);
+                    ov[1] = pack_bf16x2(v[2], v[3]);
+                    *reinterpret_cast<u32x2_t*>(a.dst + (unsigned)ro + coloff) = ov;
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn * (TN * 32) + j * 32 + (lane & 31);
@@ -244,10 +360,32 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmArgs a) {
     }
 }
 
+// split-K finish: sum the partial tiles, then the same epilogue (bias, resid, act, destination mapping)
+__global__ void __launch_bounds__(256) igemm_splitk_finish_kernel(const IgemmArgs a) {
+    const long long total = (long long)a.M * a.Nstore;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        int m = (int)(i / a.Nstore);
+        const int n = (int)(i - (long long)m * a.Nstore);
+        float v = 0.f;
+        for (int s = 0; s < a.split_k; ++s) v += a.ws[((size_t)s * a.M + m) * a.ws_ld + n];
+        if (a.bias && n < a.Ncols) v += a.bias[a.perm_f > 1 ? (n % a.perm_c) * a.perm_f + n / a.perm_c : n];
+        const int wo = m % a.Wo; m /= a.Wo;
+        const int ho = m % a.Ho; m /= a.Ho;
+        const int to = m % a.To; m /= a.To;
+        const unsigned ro = (((unsigned)(m * a.Td + to * a.dmt + a.dot) * a.Hd + ho * a.dmh + a.doh) * a.Wd + wo * a.dmw + a.dow) * a.Cd;
+        const int sub = n / a.shuf_c, ch = n - sub * a.shuf_c;
+        const int r = sub % a.shuf_r, q = (sub / a.shuf_r) % a.shuf_q, p = sub / (a.shuf_r * a.shuf_q);
+        const unsigned off = ro + ((p * a.Hd + q) * a.Wd + r) * a.Cd + ch;
+        if (a.resid) v += bf16_to_f32(a.resid[off]);
+        if (a.act == 1) v = silu_f(v);
+        a.dst[off] = f32_to_bf16(v);
+    }
+}
+
 template <int BN, int WM, int WN, bool SMALLC>
 static int launch_igemm(const IgemmArgs& a, hipStream_t s) {
     constexpr int STAGE = 128 * 128 + BN * 128;
-    const int lds = 2 * STAGE + (SMALLC ? 32 * (int)sizeof(GenieTap) : 0);
+    const int lds = 2 * STAGE + 256 * (int)sizeof(GenieTap);
     auto k = igemm_kernel<BN, WM, WN, SMALLC>;
     static bool configured = false;
     if (!configured) {
@@ -258,15 +396,22 @@ static int launch_igemm(const IgemmArgs& a, hipStream_t s) {
         }
         configured = true;
     }
-    hipLaunchKernelGGL(k, dim3(a.tiles_m * a.tiles_n), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(k, dim3(a.tiles_m * a.tiles_n, a.split_k > 1 ? a.split_k : 1), dim3(256), lds, s, a);
     GENIE_CHECK_LAUNCH();
+    if (a.split_k > 1) {
+        long long total = (long long)a.M * a.Nstore;
+        int grid = (int)((total + 255) / 256);
+        if (grid > 4096) grid = 4096;
+        hipLaunchKernelGGL(igemm_splitk_finish_kernel, dim3(grid), dim3(256), 0, s, a);
+        GENIE_CHECK_LAUNCH();
+    }
     return GENIE_OK;
 }
 
 extern "C" int genie_conv_igemm(const GenieConvDesc* d, void* stream) {
     GENIE_CHECK_ARG(d, "genie_conv_igemm: null descriptor");
     GENIE_CHECK_ARG(d->src && d->wgt && d->dst && d->taps, "genie_conv_igemm: null tensor pointer");
-    GENIE_CHECK_ARG(d->ntaps >= 1, "genie_conv_igemm: ntaps %d", d->ntaps);
+    GENIE_CHECK_ARG(d->ntaps >= 1 && d->ntaps <= 256, "genie_conv_igemm: ntaps %d out of range [1, 256]", d->ntaps);
     GENIE_CHECK_ARG(d->Cs % 8 == 0 && d->w_row_stride % 8 == 0, "genie_conv_igemm: Cs=%d and w_row_stride=%d must be multiples of 8", d->Cs, d->w_row_stride);
     GENIE_CHECK_ARG(d->N > 0 && d->To > 0 && d->Ho > 0 && d->Wo > 0 && d->Ncols > 0, "genie_conv_igemm: empty problem");
     GENIE_CHECK_ARG((long long)d->N * d->Ts * d->Hs * d->Ws * d->Cs < (1ll << 31), "genie_conv_igemm: source tensor exceeds 2^31 elements");
@@ -300,10 +445,25 @@ extern "C" int genie_conv_igemm(const GenieConvDesc* d, void* stream) {
     }
     a.tiles_m = cdiv(M, 128);
     hipStream_t s = (hipStream_t)stream;
+    a.split_k = 1; a.chunks_per_split = a.nk; a.ws = nullptr; a.ws_ld = 0;
     if (a.Nstore <= 32) {
         a.tiles_n = cdiv(a.Nstore, 32);
         return smallc ? launch_igemm<32, 4, 1, true>(a, s) : launch_igemm<32, 4, 1, false>(a, s);
     }
     a.tiles_n = cdiv(a.Nstore, 128);
+    // split-K: too few output tiles to fill 256 CUs and a long reduction (low-resolution layers, upsample dgrad)
+    if (!smallc && d->splitk_ws && a.tiles_m * a.tiles_n < 192 && a.nk >= 8) {
+        const int tiles = a.tiles_m * a.tiles_n;
+        int sk = (768 + tiles - 1) / tiles;              // aim at ~3 blocks per CU
+        if (sk > a.nk / 4) sk = a.nk / 4;                // >= 4 chunks (256 k) per split
+        const long long per = (long long)M * a.Nstore * 4;
+        if ((long long)sk * per > d->splitk_ws_bytes) sk = (int)(d->splitk_ws_bytes / per);
+        if (sk >= 2) {
+            a.chunks_per_split = cdiv(a.nk, sk);
+            a.split_k = cdiv(a.nk, a.chunks_per_split);
+            a.ws = (float*)d->splitk_ws;
+            a.ws_ld = a.Nstore;
+        }
+    }
     return smallc ? launch_igemm<128, 2, 2, true>(a, s) : launch_igemm<128, 2, 2, false>(a, s);
 }

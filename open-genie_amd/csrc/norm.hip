@@ -38,7 +38,7 @@ static GnGeom gn_geom(int N, long long npix, int C, int Cp, int G) {
 
 extern "C" int64_t genie_groupnorm_ws_floats(int N, int C, int G) {
     const int Cp = (C + 7) & ~7;
-    return (int64_t)N * GN_MAX_BLK * Cp * 2 + (int64_t)N * G * 4 + 64;
+    return (int64_t)N * GN_MAX_BLK * Cp * 2 + (int64_t)N * Cp * 4 + (int64_t)N * G * 4 + 64;
 }
 
 // ---- stats: per (n, blk, channel) sum and sum of squares ------------------------------------------
@@ -83,17 +83,31 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const bf16_t* __restrict_
     }
 }
 
-// ---- finalize: one 64-lane block per (n, g) ------------------------------------------------------
-__global__ void __launch_bounds__(64) gn_finalize_kernel(const float* __restrict__ part, GnGeom g, float eps,
+// ---- finalize, stage A: one thread per (n, channel) sums the per-block partials (coalesced over channels) ----
+__global__ void __launch_bounds__(256) gn_chan_reduce_kernel(const float* __restrict__ part, GnGeom g, double* __restrict__ chan) {
+    const int n = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= g.Cp) return;
+    double s = 0.0, q = 0.0;
+    const float* o = part + ((long long)n * g.nblk * g.Cp + c) * 2;
+    for (int blk = 0; blk < g.nblk; ++blk) {
+        s += (double)o[0];
+        q += (double)o[1];
+        o += (long long)g.Cp * 2;
+    }
+    chan[((long long)n * g.Cp + c) * 2] = s;
+    chan[((long long)n * g.Cp + c) * 2 + 1] = q;
+}
+
+// ---- finalize, stage B: one 64-lane block per (n, g) ----
+__global__ void __launch_bounds__(64) gn_finalize_kernel(const double* __restrict__ chan, GnGeom g, float eps,
                                                          float* __restrict__ mean, float* __restrict__ rstd) {
     const int n = blockIdx.y, grp = blockIdx.x, lane = threadIdx.x;
     const int cg = g.C / g.G;
     double s = 0.0, q = 0.0;
-    for (int i = lane; i < g.nblk * cg; i += 64) {
-        const int blk = i / cg, c = grp * cg + i % cg;
-        const float* o = part + (((long long)n * g.nblk + blk) * g.Cp + c) * 2;
-        s += (double)o[0];
-        q += (double)o[1];
+    for (int i = lane; i < cg; i += 64) {
+        const int c = grp * cg + i;
+        s += chan[((long long)n * g.Cp + c) * 2];
+        q += chan[((long long)n * g.Cp + c) * 2 + 1];
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -170,7 +184,10 @@ extern "C" int genie_groupnorm_fwd(const void* x, void* y, int N, int64_t npix, 
     hipStream_t s = (hipStream_t)stream;
     gn_stats_kernel<<<dim3(g.nblk, N), 256, 0, s>>>((const bf16_t*)x, g, ws);
     GENIE_CHECK_LAUNCH();
-    gn_finalize_kernel<<<dim3(G, N), 64, 0, s>>>(ws, g, eps, mean, rstd);
+    double* chan = reinterpret_cast<double*>(ws + (long long)N * GN_MAX_BLK * cpitch * 2);
+    gn_chan_reduce_kernel<<<dim3(cdiv(cpitch, 256), N), 256, 0, s>>>(ws, g, chan);
+    GENIE_CHECK_LAUNCH();
+    gn_finalize_kernel<<<dim3(G, N), 64, 0, s>>>(chan, g, eps, mean, rstd);
     GENIE_CHECK_LAUNCH();
     gn_apply_kernel<<<dim3(g.nblk, N), 256, 0, s>>>((const bf16_t*)x, (bf16_t*)y, g, gamma, beta, ada_scale, ada_shift, mean, rstd, act);
     GENIE_CHECK_LAUNCH();
@@ -237,32 +254,40 @@ __global__ void __launch_bounds__(256) gn_bwd_reduce_kernel(const bf16_t* __rest
     }
 }
 
-// one block per (n, g): channel totals -> parameter grads, group totals -> k2, k3
-__global__ void __launch_bounds__(64) gn_bwd_finalize_kernel(const float* __restrict__ part, GnGeom g, const float* __restrict__ gamma,
-                                                             const float* __restrict__ beta, const float* __restrict__ ada_s,
-                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                             float* __restrict__ dada_s, float* __restrict__ dada_b,
-                                                             float* __restrict__ kcoef) {
+// backward finalize, stage A: one thread per (n, channel): totals over blocks -> parameter grads, weighted totals for stage B
+__global__ void __launch_bounds__(256) gn_bwd_chan_kernel(const float* __restrict__ part, GnGeom g, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, const float* __restrict__ ada_s,
+                                                          float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                          float* __restrict__ dada_s, float* __restrict__ dada_b, float* __restrict__ chan) {
+    const int n = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= g.C) return;
+    double s1 = 0.0, s2 = 0.0;
+    const float* o = part + ((long long)n * g.nblk * g.Cp + c) * 2;
+    for (int blk = 0; blk < g.nblk; ++blk) {
+        s1 += (double)o[0];
+        s2 += (double)o[1];
+        o += (long long)g.Cp * 2;
+    }
+    const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+    const float as = ada_s ? ada_s[(long long)n * g.C + c] : 1.f;
+    if (dgamma) atomicAdd(dgamma + c, (float)(s2 * as));
+    if (dbeta) atomicAdd(dbeta + c, (float)(s1 * as));
+    if (dada_s) dada_s[(long long)n * g.C + c] = (float)(ga * s2 + be * s1);
+    if (dada_b) dada_b[(long long)n * g.C + c] = (float)s1;
+    chan[((long long)n * g.Cp + c) * 2] = (float)((double)(ga * as) * s1);
+    chan[((long long)n * g.Cp + c) * 2 + 1] = (float)((double)(ga * as) * s2);
+}
+
+// stage B: one 64-lane block per (n, g): group totals -> k2, k3
+__global__ void __launch_bounds__(64) gn_bwd_finalize_kernel(const float* __restrict__ chan, GnGeom g, const float* __restrict__ mean,
+                                                             const float* __restrict__ rstd, float* __restrict__ kcoef) {
     const int n = blockIdx.y, grp = blockIdx.x, lane = threadIdx.x;
     const int cg = g.C / g.G;
     double P1 = 0.0, P2 = 0.0;
     for (int ci = lane; ci < cg; ci += 64) {
         const int c = grp * cg + ci;
-        double s1 = 0.0, s2 = 0.0;
-        for (int blk = 0; blk < g.nblk; ++blk) {
-            const float* o = part + (((long long)n * g.nblk + blk) * g.Cp + c) * 2;
-            s1 += (double)o[0];
-            s2 += (double)o[1];
-        }
-        const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
-        const float as = ada_s ? ada_s[(long long)n * g.C + c] : 1.f;
-        if (dgamma) atomicAdd(dgamma + c, (float)(s2 * as));
-        if (dbeta) atomicAdd(dbeta + c, (float)(s1 * as));
-        if (dada_s) dada_s[(long long)n * g.C + c] = (float)(ga * s2 + be * s1);
-        if (dada_b) dada_b[(long long)n * g.C + c] = (float)s1;
-        P1 += (double)(ga * as) * s1;
-        P2 += (double)(ga * as) * s2;
+        P1 += (double)chan[((long long)n * g.Cp + c) * 2];
+        P2 += (double)chan[((long long)n * g.Cp + c) * 2 + 1];
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -335,10 +360,13 @@ extern "C" int genie_groupnorm_bwd(const void* x, const void* dy, void* dx, int 
     if (N == 0 || npix == 0) return GENIE_OK;
     const GnGeom g = gn_geom(N, npix, C, cpitch, G);
     hipStream_t s = (hipStream_t)stream;
-    float* kcoef = ws + (long long)N * GN_MAX_BLK * cpitch * 2;
+    float* chan = ws + (long long)N * GN_MAX_BLK * cpitch * 2;
+    float* kcoef = chan + (long long)N * cpitch * 4;
     gn_bwd_reduce_kernel<<<dim3(g.nblk, N), 256, 0, s>>>((const bf16_t*)x, (const bf16_t*)dy, g, gamma, beta, ada_scale, ada_shift, mean, rstd, act, ws);
     GENIE_CHECK_LAUNCH();
-    gn_bwd_finalize_kernel<<<dim3(G, N), 64, 0, s>>>(ws, g, gamma, beta, ada_scale, mean, rstd, dgamma, dbeta, dada_scale, dada_shift, kcoef);
+    gn_bwd_chan_kernel<<<dim3(cdiv(C, 256), N), 256, 0, s>>>(ws, g, gamma, beta, ada_scale, dgamma, dbeta, dada_scale, dada_shift, chan);
+    GENIE_CHECK_LAUNCH();
+    gn_bwd_finalize_kernel<<<dim3(G, N), 64, 0, s>>>(chan, g, mean, rstd, kcoef);
     GENIE_CHECK_LAUNCH();
     gn_bwd_apply_kernel<<<dim3(g.nblk, N), 256, 0, s>>>((const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, g, gamma, beta, ada_scale, ada_shift, mean, rstd, kcoef, act);
     GENIE_CHECK_LAUNCH();

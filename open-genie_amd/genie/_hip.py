@@ -34,7 +34,8 @@ class GenieConvDesc(C.Structure):
                 ('Td', C.c_int32), ('Hd', C.c_int32), ('Wd', C.c_int32), ('Cd', C.c_int32),
                 ('dmt', C.c_int32), ('dmh', C.c_int32), ('dmw', C.c_int32),
                 ('dot', C.c_int32), ('doh', C.c_int32), ('dow', C.c_int32),
-                ('shuf_c', C.c_int32), ('shuf_q', C.c_int32), ('shuf_r', C.c_int32), ('act', C.c_int32)]
+                ('shuf_c', C.c_int32), ('shuf_q', C.c_int32), ('shuf_r', C.c_int32), ('act', C.c_int32),
+                ('splitk_ws', C.c_void_p), ('splitk_ws_bytes', C.c_int64)]
 
 
 class GenieWgradDesc(C.Structure):
@@ -70,9 +71,16 @@ SIGNATURES = {
     'genie_silu_bwd': (C.c_int, [_P, _P, _P, _L, _P]),
     'genie_add': (C.c_int, [_P, _P, _P, _L, _P]),
     'genie_lfq_quantize': (C.c_int, [_P, _I, _L, _I, _I, _L, _P, _P, _P]),
+    'genie_lfq_loss_ws_floats': (C.c_int64, [_L, _I, _I]),
+    'genie_lfq_loss': (C.c_int, [_P, _I, _L, _I, _I, _L, _F, _F, _F, _F, _P, _P, _P, _P]),
+    'genie_lfq_bwd': (C.c_int, [_P, _P, _P, _P, _I, _L, _I, _L, _P]),
     'genie_mse_fwd': (C.c_int, [_P, _I, _P, _I, _PL, _PL, _P, _P, _P]),
     'genie_mse_bwd': (C.c_int, [_P, _I, _P, _I, _PL, _PL, _P, _P, _P]),
     'genie_adamw_step': (C.c_int, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _I, _P]),
+    'genie_rotary_layernorm_fwd': (C.c_int, [_P, _P, _L, _I, _L, _P, _L, _I, _P, _P, _F, _P, _P]),
+    'genie_rotary_layernorm_bwd': (C.c_int, [_P, _P, _P, _P, _L, _I, _L, _P, _L, _I, _P, _P, _P, _P, _P]),
+    'genie_attention_fwd': (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _PL, _PL, _PL, _F, _I, _I, _P]),
+    'genie_attention_bwd': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _PL, _PL, _PL, _PL, _F, _I, _I, _L, _P]),
     'genie_probe_ds_read_tr16': (C.c_int, [_P, _P, _P, _P]),
 }
 

@@ -51,8 +51,30 @@ def empty_like_cl(x: Tensor) -> Tensor:
     return empty_cl(n, c, t, h, w, x.device)
 
 
+class _ToClFn(torch.autograd.Function):
+    """Differentiable layout conversion: the gradient comes back as a dense tensor of the input's dtype."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor) -> Tensor:
+        ctx.dtype = x.dtype
+        return _to_cl_impl(x)
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        g = _to_cl_impl(g)
+        return from_cl(g, dtype=ctx.dtype if ctx.dtype in (torch.float32, torch.bfloat16) else torch.float32).to(ctx.dtype)
+
+
 def to_cl(x: Tensor) -> Tensor:
     """Any (N, C, T, H, W) fp32/bf16 CUDA tensor -> CL (no-op if it already is)."""
+    if is_cl(x):
+        return x
+    if x.requires_grad and torch.is_grad_enabled():
+        return _ToClFn.apply(x)
+    return _to_cl_impl(x)
+
+
+def _to_cl_impl(x: Tensor) -> Tensor:
     if is_cl(x):
         return x
     if x.dim() != 5:

@@ -25,6 +25,45 @@ from .cl import cpitch, empty_cl, is_cl, pitch_of
 Triple = Tuple[int, int, int]
 
 
+class LaunchProfiler:
+    """Optional per-launch HIP-event timing of the conv kernels (bench.py's roofline leg).  Events are recorded
+    on the stream the kernels are launched on; nothing is synchronised until ``summary()``."""
+
+    def __init__(self) -> None:
+        self.records = []          # (variant, label, flops, start_event, end_event)
+
+    def begin(self):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(torch.cuda.current_stream())
+        return ev
+
+    def end(self, variant: str, label: str, flops: float, start) -> None:
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(torch.cuda.current_stream())
+        self.records.append((variant, label, flops, start, ev))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for variant, label, flops, s, e in self.records:
+            ms = s.elapsed_time(e)
+            v = out.setdefault(variant, {'launches': 0, 'ms': 0.0, 'flops': 0.0, 'by_label': {}})
+            v['launches'] += 1; v['ms'] += ms; v['flops'] += flops
+            b = v['by_label'].setdefault(label, {'launches': 0, 'ms': 0.0, 'flops': 0.0})
+            b['launches'] += 1; b['ms'] += ms; b['flops'] += flops
+        return out
+
+
+PROFILER: Optional[LaunchProfiler] = None
+
+
+def _variant(kind: str, spec: 'ConvSpec', ncols: int, small_c: bool) -> str:
+    if kind == 'wgrad':
+        return 'wgrad_kernel<128,32>' if spec.cin <= 32 else ('wgrad_kernel<32,128>' if spec.cout <= 32 else 'wgrad_kernel<128,128>')
+    tile = '32' if cpitch(ncols) <= 32 else '128'
+    return f'igemm_kernel<{tile},{"smallc" if small_c else "generic"}>'
+
+
 @dataclass(frozen=True)
 class ConvSpec:
     cin: int
@@ -179,6 +218,18 @@ def pack_weight_bwd(weight: Tensor, spec: ConvSpec) -> Tensor:
 # ------------------------------------------------------------------------------------------------
 # launches
 # ------------------------------------------------------------------------------------------------
+_splitk_cache = {}
+SPLITK_WS_FLOATS = 16 << 20          # 64 MiB of fp32 partial tiles per device
+
+
+def _splitk_ws(device) -> Tensor:
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    buf = _splitk_cache.get(key)
+    if buf is None:
+        buf = _splitk_cache[key] = torch.empty(SPLITK_WS_FLOATS, dtype=torch.float32, device=device)
+    return buf
+
+
 def _check_cl(x: Tensor, c: int, what: str):
     if not is_cl(x):
         raise ValueError(f'{what}: expected a CL (bf16 channels-last) tensor')
@@ -220,7 +271,14 @@ def conv_forward(x: Tensor, wpack: Tensor, bias: Optional[Tensor], spec: ConvSpe
         d.perm_c, d.perm_f = 0, 1
         d.shuf_c, d.shuf_q, d.shuf_r = spec.cout, 1, 1
     d.act = act
+    ws = _splitk_ws(x.device)
+    d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), ws.numel() * 4
+    t0 = PROFILER.begin() if PROFILER is not None else None
     _hip.check(_hip.load_library().genie_conv_igemm(C.byref(d), _hip.stream_ptr()), 'genie_conv_igemm(fwd)')
+    if t0 is not None:
+        flops = 2.0 * n * to * ho * wo * spec.cout * spec.cin * spec.ntaps
+        PROFILER.end(_variant('fwd', spec, spec.cout if spec.shuffle is not None else spec.cout, bool(d.small_c)),
+                     f'fwd {spec.cin}->{spec.cout} k{spec.kernel} s{spec.stride} @{(t, h, w)}', flops, t0)
     return out
 
 
@@ -236,6 +294,7 @@ def conv_dgrad(dy: Tensor, wpack_bwd: Tensor, spec: ConvSpec, in_size: Triple, r
     lib = _hip.load_library()
     st = spec.stride
     first = True
+    t0 = PROFILER.begin() if PROFILER is not None else None
     for rt in range(st[0]):
         for rh in range(st[1]):
             for rw in range(st[2]):
@@ -261,8 +320,14 @@ def conv_dgrad(dy: Tensor, wpack_bwd: Tensor, spec: ConvSpec, in_size: Triple, r
                 d.dot, d.doh, d.dow = rt, rh, rw
                 d.shuf_c, d.shuf_q, d.shuf_r = spec.cin, 1, 1
                 d.act = 0
+                ws = _splitk_ws(dy.device)
+                d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), ws.numel() * 4
                 _hip.check(lib.genie_conv_igemm(C.byref(d), _hip.stream_ptr()), 'genie_conv_igemm(dgrad)')
                 first = False
+    if t0 is not None:
+        to, ho, wo = spec.out_size((t, h, w))
+        flops = 2.0 * n * to * ho * wo * spec.cout * spec.cin * spec.ntaps
+        PROFILER.end(_variant('dgrad', spec, spec.cin, False), f'dgrad {spec.cin}->{spec.cout} k{spec.kernel} s{spec.stride} @{(t, h, w)}', flops, t0)
     return dx
 
 
@@ -294,4 +359,8 @@ def conv_wgrad(x: Tensor, dy: Tensor, spec: ConvSpec, dweight: Tensor, dbias: Op
         d.shuf_c, d.shuf_q, d.shuf_r = spec.cout, 1, 1
     d.s_cout, d.s_tap, d.s_cin = s[0], s[4], s[1]
     d.split_k = 0
+    t0 = PROFILER.begin() if PROFILER is not None else None
     _hip.check(_hip.load_library().genie_conv_wgrad(C.byref(d), _hip.stream_ptr()), 'genie_conv_wgrad')
+    if t0 is not None:
+        flops = 2.0 * n * to * ho * wo * spec.cout * spec.cin * spec.ntaps
+        PROFILER.end(_variant('wgrad', spec, 0, False), f'wgrad {spec.cin}->{spec.cout} k{spec.kernel} s{spec.stride} @{(t, h, w)}', flops, t0)

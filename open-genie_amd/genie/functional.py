@@ -1,0 +1,282 @@
+"""Autograd bindings of the HIP kernels (the only place torch.autograd meets libgenie_hip.so).
+
+Every Function takes/returns CL tensors (genie/cl.py) and enqueues kernels on the current stream;
+nothing here synchronises, so a whole training step can be captured in one hipGraph.
+
+Weight gradients: by default (``DIRECT_PARAM_GRADS = True``) the wgrad kernels accumulate straight
+into ``param.grad`` with fp32 atomics and the Function returns ``None`` for the parameter -- no
+per-step allocation/memset/add per weight, and ``param.grad`` can be a view into one flat arena that
+the optimiser and the RCCL all-reduce work on (genie/trainer.py).  Set it to ``False`` to get the
+classic "return the gradient" behaviour (needed for torch.autograd.grad / hooks on parameters).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch import Tensor
+
+from . import _hip
+from .cl import empty_like_cl, is_cl, pitch_of, to_cl
+from .conv import ConvSpec, conv_dgrad, conv_forward, conv_wgrad, pack_weight_bwd, pack_weight_fwd
+
+DIRECT_PARAM_GRADS = True
+
+_ws_cache = {}
+
+
+def workspace(nfloats: int, device, tag: str = 'ws') -> Tensor:
+    """Grow-only fp32 scratch per (device, tag); stream-ordered reuse on one stream is safe."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), tag)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nfloats:
+        buf = torch.empty(max(int(nfloats), 1 << 16), dtype=torch.float32, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def _grad_buffer(p: Tensor) -> Tensor:
+    if p.grad is None:
+        p.grad = torch.zeros_like(p, memory_format=torch.preserve_format)
+    return p.grad
+
+
+# ------------------------------------------------------------------------------------------------
+# Conv3d
+# ------------------------------------------------------------------------------------------------
+class ConvOp:
+    """Geometry + bf16 weight packs of one convolution (packs refresh when the parameter changes)."""
+
+    def __init__(self, spec: ConvSpec):
+        self.spec = spec
+        self._fwd = (None, None)
+        self._bwd = (None, None)
+
+    def pack_fwd(self, weight: Tensor) -> Tensor:
+        key = (weight._version, weight.data_ptr())
+        if self._fwd[0] != key:
+            self._fwd = (key, pack_weight_fwd(weight, self.spec))
+        return self._fwd[1]
+
+    def pack_bwd(self, weight: Tensor) -> Tensor:
+        key = (weight._version, weight.data_ptr())
+        if self._bwd[0] != key:
+            self._bwd = (key, pack_weight_bwd(weight, self.spec))
+        return self._bwd[1]
+
+
+class _Conv3dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x: Tensor, weight: Tensor, bias: Optional[Tensor], op: ConvOp, resid: Optional[Tensor]):
+        out = conv_forward(x, op.pack_fwd(weight), bias, op.spec, resid=resid)
+        ctx.op = op
+        ctx.in_size = tuple(x.shape[2:])
+        ctx.has_resid = resid is not None
+        ctx.save_for_backward(x, weight, bias)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        x, weight, bias = ctx.saved_tensors
+        op: ConvOp = ctx.op
+        dy = to_cl(dy)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = conv_dgrad(dy, op.pack_bwd(weight), op.spec, ctx.in_size)
+        need_w = ctx.needs_input_grad[1]
+        need_b = bias is not None and ctx.needs_input_grad[2]
+        if need_w or need_b:
+            if DIRECT_PARAM_GRADS and weight.is_leaf and (bias is None or bias.is_leaf):
+                gw = _grad_buffer(weight)
+                gb = _grad_buffer(bias) if need_b else None
+                conv_wgrad(x, dy, op.spec, gw, gb)
+            else:
+                dw = torch.zeros(weight.shape, dtype=torch.float32, device=weight.device)
+                db = torch.zeros_like(bias) if need_b else None
+                conv_wgrad(x, dy, op.spec, dw, db)
+        dres = dy if ctx.has_resid and ctx.needs_input_grad[4] else None
+        return dx, dw, db, None, dres
+
+
+def conv3d(x: Tensor, weight: Tensor, bias: Optional[Tensor], op: ConvOp, resid: Optional[Tensor] = None) -> Tensor:
+    """x: any (N, C, T, H, W) CUDA tensor (converted to CL once); returns a CL tensor.
+    `resid` (CL, output-shaped) is added in the GEMM epilogue."""
+    return _Conv3dFn.apply(to_cl(x), weight, bias, op, None if resid is None else to_cl(resid))
+
+
+# ------------------------------------------------------------------------------------------------
+# GroupNorm (+ adaptive scale/shift) (+ SiLU)
+# ------------------------------------------------------------------------------------------------
+def _f32(t: Optional[Tensor]) -> Optional[Tensor]:
+    if t is None:
+        return None
+    return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
+
+
+class _GroupNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x: Tensor, gamma, beta, ada_s, ada_b, groups: int, eps: float, act: int):
+        n, c, t, h, w = x.shape
+        lib = _hip.load_library()
+        y = empty_like_cl(x)
+        mean = torch.empty(n * groups, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        ws = workspace(lib.genie_groupnorm_ws_floats(n, c, groups), x.device, 'gn')
+        g_, b_, as_, ab_ = _f32(gamma), _f32(beta), _f32(ada_s), _f32(ada_b)
+        P = _hip.ptr
+        _hip.check(lib.genie_groupnorm_fwd(P(x), P(y), n, t * h * w, c, pitch_of(x), groups, P(g_), P(b_), P(as_), P(ab_),
+                                           eps, act, P(mean), P(rstd), P(ws), _hip.stream_ptr()), 'genie_groupnorm_fwd')
+        ctx.groups, ctx.act = groups, act
+        ctx.save_for_backward(x, gamma, beta, ada_s, ada_b, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        x, gamma, beta, ada_s, ada_b, mean, rstd = ctx.saved_tensors
+        n, c, t, h, w = x.shape
+        dy = to_cl(dy)
+        if pitch_of(dy) != pitch_of(x):
+            raise RuntimeError('group_norm backward: gradient pitch mismatch')
+        lib = _hip.load_library()
+        dx = empty_like_cl(x)
+        ws = workspace(lib.genie_groupnorm_ws_floats(n, c, ctx.groups), x.device, 'gn')
+        need_g = gamma is not None and ctx.needs_input_grad[1]
+        need_b = beta is not None and ctx.needs_input_grad[2]
+        dgamma = dbeta = None
+        ret_g = ret_b = None
+        if need_g:
+            if DIRECT_PARAM_GRADS and gamma.is_leaf and gamma.dtype == torch.float32 and gamma.is_contiguous():
+                dgamma = _grad_buffer(gamma)
+            else:
+                dgamma = ret_g = torch.zeros(c, dtype=torch.float32, device=x.device)
+        if need_b:
+            if DIRECT_PARAM_GRADS and beta.is_leaf and beta.dtype == torch.float32 and beta.is_contiguous():
+                dbeta = _grad_buffer(beta)
+            else:
+                dbeta = ret_b = torch.zeros(c, dtype=torch.float32, device=x.device)
+        das = torch.empty(n, c, dtype=torch.float32, device=x.device) if ada_s is not None else None
+        dab = torch.empty(n, c, dtype=torch.float32, device=x.device) if ada_b is not None else None
+        P = _hip.ptr
+        _hip.check(lib.genie_groupnorm_bwd(P(x), P(dy), P(dx), n, t * h * w, c, pitch_of(x), ctx.groups, P(_f32(gamma)), P(_f32(beta)),
+                                           P(_f32(ada_s)), P(_f32(ada_b)), ctx.act, P(mean), P(rstd), P(dgamma), P(dbeta), P(das), P(dab),
+                                           P(ws), _hip.stream_ptr()), 'genie_groupnorm_bwd')
+        return dx, ret_g, ret_b, das, dab, None, None, None
+
+
+def group_norm(x: Tensor, groups: int, gamma: Optional[Tensor], beta: Optional[Tensor], eps: float = 1e-5,
+               ada_scale: Optional[Tensor] = None, ada_shift: Optional[Tensor] = None, act: bool = False) -> Tensor:
+    x = to_cl(x)
+    if x.shape[1] % groups != 0:
+        raise ValueError(f'num_channels {x.shape[1]} must be divisible by num_groups {groups}')
+    return _GroupNormFn.apply(x, gamma, beta, ada_scale, ada_shift, groups, eps, 1 if act else 0)
+
+
+class _SiluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x: Tensor):
+        y = empty_like_cl(x)
+        numel = x.shape[0] * x.shape[2] * x.shape[3] * x.shape[4] * pitch_of(x)
+        _hip.check(_hip.load_library().genie_silu_fwd(x.data_ptr(), y.data_ptr(), numel, _hip.stream_ptr()), 'genie_silu_fwd')
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        (x,) = ctx.saved_tensors
+        dy = to_cl(dy)
+        dx = empty_like_cl(x)
+        numel = x.shape[0] * x.shape[2] * x.shape[3] * x.shape[4] * pitch_of(x)
+        _hip.check(_hip.load_library().genie_silu_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), numel, _hip.stream_ptr()), 'genie_silu_bwd')
+        return dx
+
+
+def silu(x: Tensor) -> Tensor:
+    return _SiluFn.apply(to_cl(x))
+
+
+# ------------------------------------------------------------------------------------------------
+# MSE against an arbitrary-strided target
+# ------------------------------------------------------------------------------------------------
+class _MseFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rec: Tensor, target: Tensor):
+        lib = _hip.load_library()
+        loss = torch.empty((), dtype=torch.float32, device=rec.device)
+        ws = workspace(1024, rec.device, 'mse')
+        dt = _hip.GENIE_F32 if target.dtype == torch.float32 else _hip.GENIE_BF16
+        _hip.check(lib.genie_mse_fwd(rec.data_ptr(), pitch_of(rec), target.data_ptr(), dt, _hip.i64(rec.shape), _hip.i64(target.stride()),
+                                     ws.data_ptr(), loss.data_ptr(), _hip.stream_ptr()), 'genie_mse_fwd')
+        ctx.save_for_backward(rec, target)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss: Tensor):
+        rec, target = ctx.saved_tensors
+        lib = _hip.load_library()
+        drec = empty_like_cl(rec)
+        g = dloss.float().contiguous()
+        dt = _hip.GENIE_F32 if target.dtype == torch.float32 else _hip.GENIE_BF16
+        _hip.check(lib.genie_mse_bwd(rec.data_ptr(), pitch_of(rec), target.data_ptr(), dt, _hip.i64(rec.shape), _hip.i64(target.stride()),
+                                     g.data_ptr(), drec.data_ptr(), _hip.stream_ptr()), 'genie_mse_bwd')
+        return drec, None
+
+
+def mse_loss(rec: Tensor, target: Tensor) -> Tensor:
+    """mean((rec - target)^2) as an fp32 scalar; `target` is read in place (fp32/bf16, any strides)."""
+    if tuple(rec.shape) != tuple(target.shape):
+        raise ValueError(f'mse_loss: shape mismatch {tuple(rec.shape)} vs {tuple(target.shape)}')
+    if target.dtype not in (torch.float32, torch.bfloat16):
+        target = target.float()
+    _hip.require_gpu(target, 'mse_loss')
+    return _MseFn.apply(to_cl(rec), target.detach())
+
+
+# ------------------------------------------------------------------------------------------------
+# Lookup-free quantisation on (ntok, pitch) rows
+# ------------------------------------------------------------------------------------------------
+class _LfqFn(torch.autograd.Function):
+    """z2d: (ntok, pitch) bf16/fp32 rows (a view of the latent); returns (quant rows, idx, loss4)."""
+
+    @staticmethod
+    def forward(ctx, z2d: Tensor, width: int, ncb: int, d: int, training: bool, beta: float, commit_w: float, ent_w: float, div_w: float):
+        lib = _hip.load_library()
+        ntok, pitch = z2d.shape[0], z2d.stride(0)
+        dt = _hip.GENIE_F32 if z2d.dtype == torch.float32 else _hip.GENIE_BF16
+        quant = torch.zeros((ntok, pitch), dtype=z2d.dtype, device=z2d.device)[:, :z2d.shape[1]] if pitch != width else torch.empty_like(z2d)
+        idx = torch.empty((ntok, ncb), dtype=torch.int64, device=z2d.device)
+        _hip.check(lib.genie_lfq_quantize(z2d.data_ptr(), dt, ntok, ncb, d, pitch, quant.data_ptr(), idx.data_ptr(), _hip.stream_ptr()), 'genie_lfq_quantize')
+        loss4 = None
+        if training:
+            loss4 = torch.empty(4, dtype=torch.float32, device=z2d.device)
+            dzl = torch.empty((ntok, ncb * d), dtype=torch.float32, device=z2d.device)
+            ws = workspace(lib.genie_lfq_loss_ws_floats(ntok, ncb, d), z2d.device, 'lfq')
+            _hip.check(lib.genie_lfq_loss(z2d.data_ptr(), dt, ntok, ncb, d, pitch, beta, commit_w, ent_w, div_w, ws.data_ptr(), loss4.data_ptr(),
+                                          dzl.data_ptr(), _hip.stream_ptr()), 'genie_lfq_loss')
+            ctx.save_for_backward(dzl)
+        ctx.meta = (dt, ntok, width, pitch, z2d.dtype, z2d.shape[1])
+        ctx.mark_non_differentiable(idx)
+        return quant, idx, loss4
+
+    @staticmethod
+    def backward(ctx, dquant, _didx, dloss4):
+        dt, ntok, width, pitch, dtype, ncol = ctx.meta
+        lib = _hip.load_library()
+        dzl = ctx.saved_tensors[0] if ctx.saved_tensors else None
+        out = torch.empty((ntok, pitch), dtype=dtype, device=dquant.device if dquant is not None else dloss4.device)
+        dq = None
+        if dquant is not None:
+            dq = dquant
+            if dq.dtype != dtype or dq.stride(0) != pitch or dq.stride(1) != 1:
+                tmp = torch.zeros((ntok, pitch), dtype=dtype, device=dq.device)
+                tmp[:, :ncol] = dq
+                dq = tmp
+        gl = None
+        if dloss4 is not None and dzl is not None:
+            gl = dloss4[0:1].float().contiguous()      # only the total carries gradient
+        _hip.check(lib.genie_lfq_bwd(_hip.ptr(dq), _hip.ptr(dzl) if gl is not None else None, _hip.ptr(gl), out.data_ptr(), dt, ntok, width, pitch,
+                                     _hip.stream_ptr()), 'genie_lfq_bwd')
+        return out[:, :ncol], None, None, None, None, None, None, None, None
+
+
+def lfq_rows(z2d: Tensor, ncb: int, d: int, training: bool, beta: float, commit_w: float, ent_w: float, div_w: float):
+    return _LfqFn.apply(z2d, ncb * d, ncb, d, training, beta, commit_w, ent_w, div_w)

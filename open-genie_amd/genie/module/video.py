@@ -1,0 +1,342 @@
+"""3-D convolution building blocks on the HIP gather-GEMM (drop-in for reference genie/module/video.py).
+
+Same constructor signatures, attributes and ``state_dict`` layout as the reference classes, so reference
+checkpoints load; ``forward`` takes any (N, C, T, H, W) CUDA tensor and returns a CL tensor (logical NCTHW,
+bf16, channels-last strides).  There is no CPU path.
+"""
+from __future__ import annotations
+
+import math
+from abc import ABC
+from typing import Optional, Tuple
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from .. import functional as GF
+from ..cl import to_cl
+from ..conv import ConvSpec, causal_spec, same_spec
+from ..utils import default, exists
+
+
+def _triple(v) -> Tuple[int, int, int]:
+    return (v, v, v) if isinstance(v, int) else tuple(v)
+
+
+class Conv3d(nn.Module):
+    """Conv3d whose arithmetic is ``genie_conv_igemm``; parameters laid out like ``nn.Conv3d`` (keys
+    ``weight`` (Cout, Cin, kt, kh, kw) / ``bias``), stored channels_last_3d so that packing is a cast.
+
+    ``spec`` fixes the padding rule: symmetric (``nn.Conv3d(padding=(k-1)//2)``, reference video.py:580-586)
+    or causal (reference video.py:154-164)."""
+
+    def __init__(self, in_channels: int, out_channels: int, kernel_size, spec: ConvSpec, bias: bool = True) -> None:
+        super().__init__()
+        ks = _triple(kernel_size)
+        w = torch.empty(out_channels, in_channels, *ks)
+        nn.init.kaiming_uniform_(w, a=math.sqrt(5))                 # nn.Conv3d.reset_parameters
+        self.weight = nn.Parameter(w.contiguous(memory_format=torch.channels_last_3d))
+        if bias:
+            bound = 1 / math.sqrt(in_channels * ks[0] * ks[1] * ks[2])
+            self.bias = nn.Parameter(torch.empty(out_channels).uniform_(-bound, bound))
+        else:
+            self.register_parameter('bias', None)
+        self.in_channels, self.out_channels, self.kernel_size = in_channels, out_channels, ks
+        self.spec = spec
+        self.op = GF.ConvOp(spec)
+
+    def forward(self, inp: Tensor, resid: Optional[Tensor] = None) -> Tensor:
+        return GF.conv3d(inp, self.weight, self.bias, self.op, resid)
+
+    def extra_repr(self) -> str:
+        s = self.spec
+        return f'{s.cin}, {s.cout}, kernel_size={s.kernel}, stride={s.stride}, pad_front={s.pad_front}, pad_back={s.pad_back}, shuffle={s.shuffle}'
+
+
+def get_blur_kernel(kernel_size, device=None, dtype=None, norm: bool = True) -> Tensor:
+    """Pascal-triangle blur taps (reference video.py:22-56, including its use of kernel_size[0] for the
+    h taps and for the length of the w taps)."""
+    if isinstance(kernel_size, int):
+        kernel_size = (kernel_size, kernel_size)
+    k0, k1 = kernel_size[0], kernel_size[1]
+    t = torch.tensor([math.comb(k0 - 1, i) for i in range(k0)], device=device, dtype=dtype)
+    h = torch.tensor([math.comb(k0 - 1, i) for i in range(k0)], device=device, dtype=dtype)
+    w = torch.tensor([math.comb(k1 - 1, i) for i in range(k0)], device=device, dtype=dtype)
+    k = t[:, None, None] * h[None, :, None] * w[None, None, :]
+    return k / k.sum() if norm else k
+
+
+class Upsample(nn.Module, ABC):
+    def __init__(self, time_factor: int = 1, space_factor: int = 1) -> None:
+        super().__init__()
+        self.time_factor, self.space_factor = time_factor, space_factor
+        self.go_up = None
+
+    @property
+    def factor(self):
+        return self.time_factor * (self.space_factor ** 2)
+
+    def forward(self, inp: Tensor, **kwargs) -> Tensor:
+        return self.go_up(inp)
+
+
+class Downsample(nn.Module, ABC):
+    def __init__(self, time_factor: int = 1, space_factor: int = 1) -> None:
+        super().__init__()
+        self.time_factor, self.space_factor = time_factor, space_factor
+        self.go_down = None
+
+    @property
+    def factor(self):
+        return self.time_factor * (self.space_factor ** 2)
+
+    def forward(self, inp: Tensor, **kwargs) -> Tensor:
+        return self.go_down(inp)
+
+
+class CausalConv3d(nn.Module):
+    """reference video.py:106-200.  The causal front padding is a predicate in the gather, never a copy."""
+
+    def __init__(self, in_channels: int, out_channels: int, kernel_size, stride=(1, 1, 1), dilation=(1, 1, 1),
+                 padding=None, pad_mode: str = 'constant', _shuffle=None, **kwargs) -> None:
+        super().__init__()
+        stride, dilation, kernel_size = _triple(stride), _triple(dilation), _triple(kernel_size)
+        if isinstance(padding, int) or padding is None:
+            padding = (padding, padding)
+        if pad_mode != 'constant':
+            raise NotImplementedError(f"CausalConv3d: pad_mode '{pad_mode}' is not implemented on the HIP path (zero padding only)")
+        bias = kwargs.pop('bias', True)
+        if kwargs.pop('groups', 1) != 1:
+            raise NotImplementedError('CausalConv3d: grouped convolutions are not implemented on the HIP path')
+        if kwargs:
+            raise TypeError(f'CausalConv3d: unexpected arguments {sorted(kwargs)}')
+        spec = causal_spec(in_channels, out_channels, kernel_size, stride, dilation, padding, shuffle=_shuffle)
+        self.conv3d = Conv3d(in_channels, out_channels, kernel_size, spec, bias=bias)
+        self.in_channels, self.out_channels = in_channels, out_channels
+
+    def forward(self, inp: Tensor) -> Tensor:
+        return self.conv3d(inp)
+
+    @property
+    def inp_dim(self) -> int:
+        return self.in_channels
+
+    @property
+    def out_dim(self) -> int:
+        return self.out_channels
+
+
+class _Shuffled(nn.Module):
+    """Stand-in for the reference's einops ``Rearrange`` child (no parameters; keeps Sequential indices)."""
+
+    def forward(self, x):
+        return x
+
+
+class DepthToSpaceTimeUpsample(Upsample):
+    """reference video.py:379-430: CausalConv3d(C -> C' * tf * sf^2) then
+    'b (c p q r) t h w -> b c (t p) (h q) (w r)'.  The rearrange is the store pattern of the GEMM epilogue."""
+
+    def __init__(self, in_channels: int, out_channels: Optional[int] = None, time_factor: int = 2, space_factor: int = 2,
+                 kernel_size=1) -> None:
+        super().__init__(time_factor=time_factor, space_factor=space_factor)
+        out_channels = default(out_channels, in_channels)
+        self.go_up = nn.Sequential(
+            CausalConv3d(in_channels, out_channels * time_factor * space_factor ** 2, kernel_size=kernel_size,
+                         _shuffle=(time_factor, space_factor, space_factor)),
+            _Shuffled(),
+        )
+        self.in_channels, self.out_channels = in_channels, out_channels
+
+    def forward(self, inp: Tensor, **kwargs) -> Tensor:
+        return self.go_up(inp)
+
+    @property
+    def inp_dim(self) -> int:
+        return self.in_channels
+
+    @property
+    def out_dim(self) -> int:
+        return self.out_channels
+
+
+class SpaceTimeDownsample(Downsample):
+    """reference video.py:457-483: strided CausalConv3d."""
+
+    def __init__(self, in_channels: int, kernel_size, out_channels: Optional[int] = None, time_factor: int = 2,
+                 space_factor: int = 2, **kwargs) -> None:
+        super().__init__(time_factor=1 / time_factor, space_factor=1 / space_factor)
+        self.go_down = CausalConv3d(in_channels, default(out_channels, in_channels), kernel_size=_triple(kernel_size),
+                                    stride=(time_factor, space_factor, space_factor), **kwargs)
+
+
+class BlurPooling3d(nn.Module):
+    """reference video.py:487-537.  With num_groups=1 the reference's dense conv sums ALL input channels into
+    every output channel; reproduced by running the same dense kernel."""
+
+    def __init__(self, in_channels: int, kernel_size, out_channels: Optional[int] = None, time_factor: int = 2,
+                 space_factor=2, num_groups: int = 1, **kwargs) -> None:
+        super().__init__()
+        ks = _triple(kernel_size)
+        if isinstance(space_factor, int):
+            space_factor = (space_factor, space_factor)
+        if num_groups != 1:
+            raise NotImplementedError('BlurPooling3d: num_groups > 1 is not implemented on the HIP path')
+        self.register_buffer('blur', get_blur_kernel(ks))
+        self.stride = (time_factor, *space_factor)
+        self.kwargs, self.num_groups, self.out_channels = kwargs, num_groups, out_channels
+        self.padding = tuple((k - 1) // 2 for k in ks)
+        self._ops = {}
+
+    def forward(self, inp: Tensor) -> Tensor:
+        inp = to_cl(inp)
+        c = inp.shape[1]
+        o = default(self.out_channels, c)
+        key = (c, o)
+        if key not in self._ops:
+            ks = tuple(self.blur.shape)
+            spec = ConvSpec(c, o, ks, tuple(self.stride), (1, 1, 1), self.padding, self.padding, None)
+            self._ops[key] = GF.ConvOp(spec)
+        ker = self.blur[None, None].expand(o, c, *self.blur.shape).contiguous()   # every (out, in) tap = the blur
+        return GF.conv3d(inp, ker, None, self._ops[key])
+
+    def __repr__(self):
+        return f'BlurPooling3d({self.out_channels}, kernel_size={tuple(self.blur.shape)}, stride={self.stride}, padding={self.padding})'
+
+
+class VideoResidualBlock(nn.Module):
+    """reference video.py:539-656: main = [GN, act, conv k, (down), GN, act, conv k] + res = [(down), conv 1].
+
+    Fused here: GN + SiLU in one pass each; the final `main + res` add rides in the epilogue of the second
+    main conv (the reference allocates a separate sum)."""
+
+    def __init__(self, in_channels: int, out_channels: Optional[int] = None, kernel_size=3, num_groups: int = 1,
+                 pad_mode: str = 'constant', downsample=None, use_causal: bool = False, use_norm: bool = True,
+                 use_blur: bool = True, act_fn: str = 'swish') -> None:
+        super().__init__()
+        from .norm import GroupNorm, SiLU
+        if isinstance(downsample, int):
+            downsample = (downsample, downsample)
+        ks = _triple(kernel_size)
+        if act_fn not in ('swish', 'silu'):
+            raise NotImplementedError(f"VideoResidualBlock: act_fn '{act_fn}' is not implemented on the HIP path (swish/silu only)")
+        if exists(downsample) and not use_blur:
+            # the reference raises TypeError here too (SpaceTimeDownsample gets an unexpected num_groups)
+            raise TypeError("VideoResidualBlock: downsample with use_blur=False is unsupported (the reference raises as well)")
+        out_channels = default(out_channels, in_channels)
+        tf, sf = downsample if exists(downsample) else (None, None)
+
+        def conv(ci, co, k):
+            k = _triple(k)
+            if use_causal:   # CausalConv3d reads padding[0], padding[1] as the (h, w) pads (video.py:157-158)
+                pad = None if k == (1, 1, 1) else ((k[0] - 1) // 2, (k[1] - 1) // 2)
+                return CausalConv3d(ci, co, k, padding=pad, pad_mode=pad_mode)
+            return Conv3d(ci, co, k, same_spec(ci, co, k))
+
+        def down(ch):
+            return BlurPooling3d(ch, ks, time_factor=tf, space_factor=sf, num_groups=num_groups) if exists(downsample) else nn.Identity()
+
+        norm = (lambda ch: GroupNorm(num_groups, ch)) if use_norm else (lambda ch: nn.Identity())
+        self.res = nn.Sequential(down(in_channels), conv(in_channels, out_channels, 1))
+        self.main = nn.Sequential(norm(in_channels), SiLU(), conv(in_channels, out_channels, ks), down(out_channels),
+                                  norm(out_channels), SiLU(), conv(out_channels, out_channels, ks))
+        self.inp_channels, self.out_channels = in_channels, out_channels
+        self.use_norm, self.use_causal = use_norm, use_causal
+
+    def _norm_act(self, x: Tensor, norm: nn.Module) -> Tensor:
+        if self.use_norm:
+            return GF.group_norm(x, norm.num_groups, norm.weight, norm.bias, norm.eps, act=True)
+        return GF.silu(x)
+
+    def forward(self, inp: Tensor) -> Tensor:
+        inp = to_cl(inp)
+        res = self.res[1](self.res[0](inp))
+        h = self.main[2](self._norm_act(inp, self.main[0]))
+        h = self.main[3](h)
+        h = self._norm_act(h, self.main[4])
+        last = self.main[6]
+        if isinstance(last, CausalConv3d):
+            return last.conv3d(h, resid=res)
+        return last(h, resid=res)
+
+    @property
+    def inp_dim(self) -> int:
+        return self.inp_channels
+
+    @property
+    def out_dim(self) -> int:
+        return self.out_channels
+
+
+class DepthToSpaceUpsample(Upsample):
+    """reference video.py:279-327: per-frame Conv2d 1x1 then 'b (c p q) h w -> b c (h p) (w q)'."""
+
+    def __init__(self, in_channels: int, out_channels: Optional[int] = None, factor: int = 2) -> None:
+        super().__init__(space_factor=factor)
+        out_channels = default(out_channels, in_channels)
+        spec = ConvSpec(in_channels, out_channels * factor ** 2, (1, 1, 1), shuffle=(1, factor, factor))
+        conv = Conv3d(in_channels, out_channels * factor ** 2, 1, spec)
+        conv.weight = nn.Parameter(conv.weight.detach().reshape(out_channels * factor ** 2, in_channels, 1, 1).clone())   # Conv2d key shape
+        self.go_up = nn.Sequential(conv, _Shuffled())
+        self.in_channels, self.out_channels = in_channels, out_channels
+
+    def forward(self, inp: Tensor, **kwargs) -> Tensor:
+        conv = self.go_up[0]
+        return GF.conv3d(inp, conv.weight.unsqueeze(2), conv.bias, conv.op)
+
+    @property
+    def inp_dim(self) -> int:
+        return self.in_channels
+
+    @property
+    def out_dim(self) -> int:
+        return self.out_channels
+
+
+class DepthToTimeUpsample(Upsample):
+    """reference video.py:329-377: Conv1d 1 over time then 'b (c f) t -> b c (t f)'."""
+
+    def __init__(self, in_channels: int, out_channels: Optional[int] = None, factor: int = 2) -> None:
+        super().__init__(time_factor=factor)
+        out_channels = default(out_channels, in_channels)
+        spec = ConvSpec(in_channels, out_channels * factor, (1, 1, 1), shuffle=(factor, 1, 1))
+        conv = Conv3d(in_channels, out_channels * factor, 1, spec)
+        conv.weight = nn.Parameter(conv.weight.detach().reshape(out_channels * factor, in_channels, 1).clone())           # Conv1d key shape
+        self.go_up = nn.Sequential(conv, _Shuffled())
+        self.in_channels, self.out_channels = in_channels, out_channels
+
+    def forward(self, inp: Tensor, **kwargs) -> Tensor:
+        conv = self.go_up[0]
+        return GF.conv3d(inp, conv.weight[..., None, None], conv.bias, conv.op)
+
+    @property
+    def inp_dim(self) -> int:
+        return self.in_channels
+
+    @property
+    def out_dim(self) -> int:
+        return self.out_channels
+
+
+class CausalConvTranspose3d(nn.Module):
+    """reference video.py:202-277.  Not used by any shipped blueprint; kept constructible so the registry is
+    complete, but the transposed convolution is not implemented on the HIP path yet."""
+
+    def __init__(self, in_channels: int, out_channels: int, kernel_size, stride=(1, 1, 1), dilation=(1, 1, 1), space_pad=None, **kwargs) -> None:
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.args = (kernel_size, stride, dilation, space_pad, kwargs)
+
+    def forward(self, inp: Tensor) -> Tensor:
+        raise NotImplementedError('CausalConvTranspose3d is outside the implemented hot path (SURVEY.md section 2, row 1: unused by any shipped desc)')
+
+
+class SpaceTimeUpsample(Upsample):
+    """reference video.py:432-455 (nn.ConvTranspose3d); unused by any shipped blueprint."""
+
+    def __init__(self, in_dim: int, out_dim: int, time_factor: int = 2, space_factor: int = 2, **kwargs) -> None:
+        super().__init__(time_factor=time_factor, space_factor=space_factor)
+
+    def forward(self, inp: Tensor, **kwargs) -> Tensor:
+        raise NotImplementedError('SpaceTimeUpsample (ConvTranspose3d) is outside the implemented hot path')

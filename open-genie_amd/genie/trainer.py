@@ -1,0 +1,173 @@
+"""Training runtime for the hot path: one flat parameter arena, fused AdamW, clip-sharded data parallel.
+
+The reference trains through Lightning (``Trainer.fit`` -> DDP wrapper -> ``training_step`` -> AdamW,
+reference genie/tokenizer.py:391-442, config/tokenize.yaml:49-53,75-77).  Lightning is optional here; this
+module is the MI355X-first equivalent of that loop:
+
+* ``ParamArena`` re-homes every trainable parameter (and its ``.grad``) as a view into ONE fp32 buffer each.
+  The wgrad kernels accumulate straight into the gradient arena, the optimiser is a single fused kernel
+  over the arena (``genie_adamw_step``: update + "consume and clear" of the gradients), and data-parallel
+  reduction is a handful of large RCCL all-reduces over contiguous arena ranges.
+* ``DataParallel`` = one process per GPU, clips sharded by rank, gradient all-reduce (mean) over xGMI in
+  a few big buckets issued on a side stream as soon as backward has passed the bucket's first layer, so
+  the reduction of the decoder's gradients overlaps the encoder's backward.  The logged scalars of a step
+  are reduced in ONE small all-reduce (the reference's ``log_dict(sync_dist=True)`` sends six).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+from torch import Tensor
+
+from . import _hip
+
+_ALIGN = 64   # elements (256 B)
+
+
+def _is_dense(shape, stride) -> bool:
+    """True if (shape, stride) enumerates each of prod(shape) storage slots exactly once."""
+    dims = sorted(((st, sz) for sz, st in zip(shape, stride) if sz > 1), key=lambda t: t[0])
+    expect = 1
+    for st, sz in dims:
+        if st != expect:
+            return False
+        expect *= sz
+    return True
+
+
+class ParamArena:
+    def __init__(self, module: nn.Module, device=None) -> None:
+        named = [(n, p) for n, p in module.named_parameters() if p.requires_grad]
+        if not named:
+            raise ValueError('ParamArena: module has no trainable parameters')
+        device = device if device is not None else named[0][1].device
+        offs, total = [], 0
+        for _, p in named:
+            offs.append(total)
+            total += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.numel = total
+        self.params = torch.zeros(total, dtype=torch.float32, device=device)
+        self.grads = torch.zeros(total, dtype=torch.float32, device=device)
+        self.exp_avg = torch.zeros(total, dtype=torch.float32, device=device)
+        self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=device)
+        self.slots: Dict[str, Tuple[int, int]] = {}
+        self._plist: List[nn.Parameter] = []
+        with torch.no_grad():
+            for (name, p), off in zip(named, offs):
+                n = p.numel()
+                if p.dtype != torch.float32:
+                    raise TypeError(f'ParamArena: parameter {name} is {p.dtype}; master parameters are fp32')
+                shape, stride = tuple(p.shape), tuple(p.stride())
+                if not _is_dense(shape, stride):
+                    stride = tuple(torch.empty(shape).stride())
+                view = self.params[off:off + n].as_strided(shape, stride)
+                view.copy_(p.detach().to(device))
+                p.data = view
+                p.grad = self.grads[off:off + n].as_strided(shape, stride)
+                self.slots[name] = (off, n)
+                self._plist.append(p)
+        self.step_count = 0
+
+    def offset_of(self, module: nn.Module, root: nn.Module) -> Optional[int]:
+        """Arena offset of the first trainable parameter of `module` (a sub-module of `root`)."""
+        ids = {id(p) for p in module.parameters() if p.requires_grad}
+        for name, p in root.named_parameters():
+            if id(p) in ids:
+                return self.slots[name][0]
+        return None
+
+    def zero_grad(self) -> None:
+        self.grads.zero_()
+
+    def adamw_step(self, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2,
+                   grad_scale: float = 1.0, zero_grad: bool = True) -> None:
+        """torch.optim.AdamW semantics (the reference's optimiser, tokenizer.py:437-442) in ONE kernel over the arena."""
+        self.step_count += 1
+        lib = _hip.load_library()
+        _hip.check(lib.genie_adamw_step(self.params.data_ptr(), self.grads.data_ptr(), self.exp_avg.data_ptr(),
+                                        self.exp_avg_sq.data_ptr(), self.numel, lr, betas[0], betas[1], eps, weight_decay,
+                                        self.step_count, grad_scale, 1 if zero_grad else 0, _hip.stream_ptr()), 'genie_adamw_step')
+        # the kernel wrote through the arena, not through the Parameter objects: tell autograd, so that the
+        # cached bf16 weight packs (functional.ConvOp, keyed on the version counter) are rebuilt
+        torch.autograd.graph.increment_version(self._plist)
+
+
+class DataParallel:
+    """Clip-sharded data parallelism over the gradient arena.  One process per GPU; ``torch.distributed`` is
+    initialised by the caller (``nccl`` = RCCL on the GPUs, ``gloo`` in the CPU tests of the bookkeeping)."""
+
+    def __init__(self, grads: Tensor, boundaries: Sequence[int] = (), group=None) -> None:
+        self.grads = grads
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        cuts = sorted(set([0, grads.numel()] + [int(b) for b in boundaries if 0 < b < grads.numel()]))
+        self.buckets = list(zip(cuts[:-1], cuts[1:]))
+        self.comm_stream = torch.cuda.Stream(device=grads.device) if grads.is_cuda else None
+        self._done = [False] * len(self.buckets)
+        self.bytes_reduced = 0
+
+    def _reduce(self, lo: int, hi: int) -> None:
+        if self.world == 1 or hi <= lo:
+            return
+        chunk = self.grads[lo:hi]
+        self.bytes_reduced += chunk.numel() * 4
+        if self.comm_stream is not None:
+            self.comm_stream.wait_stream(torch.cuda.current_stream())       # behind every kernel enqueued so far
+            with torch.cuda.stream(self.comm_stream):
+                dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group)
+                chunk.mul_(1.0 / self.world)
+        else:
+            dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group)
+            chunk.mul_(1.0 / self.world)
+
+    def bucket_ready(self, index: int) -> None:
+        """Gradients of bucket `index` (and of every later bucket) are fully enqueued."""
+        for i in range(len(self.buckets) - 1, index - 1, -1):
+            if not self._done[i]:
+                self._reduce(*self.buckets[i])
+                self._done[i] = True
+
+    def finish(self) -> None:
+        """Reduce whatever is left and make the compute stream wait for the reductions (call before the optimiser)."""
+        self.bucket_ready(0)
+        if self.comm_stream is not None and self.world > 1:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        self._done = [False] * len(self.buckets)
+
+    def reduce_scalars(self, values: Sequence[Tensor]) -> Tensor:
+        """One all-reduce for all logged scalars of a step (mean over ranks)."""
+        v = torch.stack([torch.as_tensor(x, dtype=torch.float32, device=self.grads.device).detach().reshape(()) for x in values])
+        if self.world > 1:
+            dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.group)
+            v /= self.world
+        return v
+
+    def install_overlap_hooks(self, arena: ParamArena, root: nn.Module, modules: Sequence[nn.Module]) -> None:
+        """Cut the arena at the first parameter of each module in `modules` (given in forward order) and start a
+        bucket's reduction when backward delivers the gradient of that module's input."""
+        offs = [arena.offset_of(m, root) for m in modules]
+        pairs = [(o, m) for o, m in zip(offs, modules) if o is not None]
+        cuts = sorted(set([0, self.grads.numel()] + [o for o, _ in pairs if 0 < o < self.grads.numel()]))
+        self.buckets = list(zip(cuts[:-1], cuts[1:]))
+        self._done = [False] * len(self.buckets)
+        index_of = {lo: i for i, (lo, _) in enumerate(self.buckets)}
+        for off, mod in pairs:
+            if off not in index_of:
+                continue
+            idx = index_of[off]
+
+            def pre_hook(_m, args, idx=idx):
+                x = args[0] if args else None
+                if isinstance(x, Tensor) and x.requires_grad:
+                    x.register_hook(lambda g, idx=idx: self.bucket_ready(idx))
+
+            mod.register_forward_pre_hook(pre_hook)
+
+
+def shard_clips(num_clips: int, rank: int, world: int) -> range:
+    """Rank r takes clips r::world -- what Lightning's DistributedSampler does for the reference's DataLoader
+    (reference genie/module/data.py:97)."""
+    return range(rank, num_clips, world)

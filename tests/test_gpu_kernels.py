@@ -268,3 +268,30 @@ def test_conv_shuffle_wgrad(G, cin, cf, fac, size):
     G.conv.conv_wgrad(G.cl.to_cl(x.cuda()), G.cl.to_cl(dy.cuda()), spec, dw, db)
     torch.testing.assert_close(dw.cpu(), wt.grad, rtol=1e-3, atol=1e-3 * wt.grad.abs().max().item())
     torch.testing.assert_close(db.cpu(), b.grad, rtol=1e-3, atol=1e-3 * b.grad.abs().max().item())
+
+
+@pytest.mark.parametrize('d,ncb,ntok,scale', [(18, 1, 64, 0.05), (18, 1, 40, 0.002), (8, 1, 200, 0.3), (6, 3, 50, 0.01), (10, 1, 128, 0.02), (1, 1, 16, 0.01)])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_lfq_loss_and_grad(G, d, ncb, ntok, scale, dtype):
+    """Training loss of LFQ (entropy over all 2^d codes with the clamp inside the log + commitment) and its
+    gradient, against the reference formulation evaluated by the oracle (which materialises N x 2^d)."""
+    from oracle import genie_oracle as O
+    torch.manual_seed(8)
+    z = (torch.randn(ntok, ncb * d) * scale).to(dtype)
+    z[0] = 0.
+    zr = z.float().clone().requires_grad_(True)
+    (_, _), ref_loss = O.lfq_forward(zr.reshape(1, ntok, ncb * d), {}, '', d, ncb, training=True, beta=100.)
+    ref_loss.backward()
+    pitch = (ncb * d + 7) & ~7
+    zz = torch.zeros(ntok, pitch, dtype=dtype, device='cuda')
+    zz[:, :ncb * d] = z.cuda()
+    lib = G.hip.load_library()
+    ws = torch.empty(lib.genie_lfq_loss_ws_floats(ntok, ncb, d), device='cuda')
+    loss4 = torch.zeros(4, device='cuda')
+    dz = torch.zeros(ntok, ncb * d, device='cuda')
+    G.hip.check(lib.genie_lfq_loss(zz.data_ptr(), G.hip.GENIE_F32 if dtype == torch.float32 else G.hip.GENIE_BF16, ntok, ncb, d, pitch, 100., 0.25, 0.1, 1.,
+                                   ws.data_ptr(), loss4.data_ptr(), dz.data_ptr(), G.hip.stream_ptr()), 'lfq loss')
+    assert abs(loss4[0].item() - ref_loss.item()) < 1e-5 + 1e-5 * abs(ref_loss.item()), (loss4.tolist(), ref_loss.item())
+    g = zr.grad
+    err = (dz.cpu() - g).abs().max().item()
+    assert err <= 2e-3 * g.abs().max().item() + 1e-7, (err, g.abs().max().item())
