@@ -192,12 +192,14 @@ int genie_rotary_layernorm_fwd(const void* x, void* u, int64_t ntok, int C, int6
 int genie_rotary_layernorm_bwd(const void* x, const void* du, const void* dres, void* dx, int64_t ntok, int C, int64_t pitch,
                                const float* cos_sin, int64_t pos_div, int pos_mod, const float* gamma, const float* stats,
                                float* dgamma, float* dbeta, void* stream);
-/* out = softmax(scale * q k^T [causal]) v (+ resid); lse: fp32 [out tokens][nhead] (token = element offset / out_channels) */
-int genie_attention_fwd(const void* q, const void* k, const void* v, const void* resid, void* out, float* lse, int nseq, int nhead,
+/* out = softmax(scale * q k^T [causal]) v (+ resid); o_attn (optional) receives the same without the residual (what backward
+ * needs); lse: fp32 [out tokens][nhead] (token = element offset / out_channels) */
+int genie_attention_fwd(const void* q, const void* k, const void* v, const void* resid, void* out, void* o_attn, float* lse, int nseq, int nhead,
                         int d_head, int Sq, int Sk, const int64_t* q_map, const int64_t* kv_map, const int64_t* out_map, float scale,
                         int causal, int out_channels, void* stream);
-/* Self-attention (q == k == v): dq receives dQ + dK + dV.  Otherwise dq gets dQ and dk / dv (addressed by dkv_map, which must
- * not alias across sequences) get dK / dV.  D_ws: fp32 [out_tokens][nhead] scratch. */
+/* `out` must be the attention output WITHOUT the residual (o_attn of the forward) when resid is NULL; with resid given,
+ * out - resid is used (less accurate).  Self-attention (q == k == v): dq receives dQ + dK + dV.  Otherwise dq gets dQ and
+ * dk / dv (addressed by dkv_map, which must not alias across sequences) get dK / dV.  D_ws: fp32 [out_tokens][nhead] scratch. */
 int genie_attention_bwd(const void* q, const void* k, const void* v, const void* out, const void* resid, const void* dO,
                         const float* lse, float* D_ws, void* dq, void* dk, void* dv, int nseq, int nhead, int d_head, int Sq, int Sk,
                         const int64_t* q_map, const int64_t* kv_map, const int64_t* out_map, const int64_t* dkv_map, float scale,

@@ -200,7 +200,7 @@ __device__ __forceinline__ long long seq_base(const SeqMap& m, int seq) {
 }
 
 struct AttnArgs {
-    const bf16_t* q; const bf16_t* k; const bf16_t* v; const bf16_t* resid; bf16_t* out;
+    const bf16_t* q; const bf16_t* k; const bf16_t* v; const bf16_t* resid; bf16_t* out; bf16_t* oattn;
     float* lse;                 // [token][nhead], token = (element offset of the token row) / C  (may be null)
     int C;                      // channels per token row (= nhead * DH for the q/out tensor)
     SeqMap qm, km, om;          // q/out/resid share qm for addressing of q; om for out & resid
@@ -371,6 +371,12 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const AttnArgs a) {
                 float f[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) f[e] = oacc[d][4 * g + e] * inv;
+                if (a.oattn) {                      // un-residualed output, kept for backward (D = rowsum(dO * O) needs it exactly)
+                    u32x2_t av;
+                    av[0] = pack_bf16x2(f[0], f[1]);
+                    av[1] = pack_bf16x2(f[2], f[3]);
+                    *reinterpret_cast<u32x2_t*>(a.oattn + obase + dd) = av;
+                }
                 if (a.resid) {
                     const u32x2_t rv = *reinterpret_cast<const u32x2_t*>(a.resid + obase + dd);
                     f[0] += __uint_as_float(rv[0] << 16); f[1] += __uint_as_float(rv[0] & 0xffff0000u);
@@ -391,14 +397,14 @@ static SeqMap mk_map(const int64_t* m) {
     return s;
 }
 
-extern "C" int genie_attention_fwd(const void* q, const void* k, const void* v, const void* resid, void* out, float* lse, int nseq, int nhead,
+extern "C" int genie_attention_fwd(const void* q, const void* k, const void* v, const void* resid, void* out, void* o_attn, float* lse, int nseq, int nhead,
                                    int d_head, int Sq, int Sk, const int64_t* q_map, const int64_t* kv_map, const int64_t* out_map, float scale,
                                    int causal, int out_channels, void* stream) {
     GENIE_CHECK_ARG(q && k && v && out && q_map && kv_map && out_map, "genie_attention_fwd: null pointer");
     GENIE_CHECK_ARG(d_head == 32 || d_head == 64 || d_head == 128, "genie_attention_fwd: d_head %d not in {32, 64, 128}", d_head);
     GENIE_CHECK_ARG(nseq >= 1 && nhead >= 1 && Sq >= 1 && Sk >= 1, "genie_attention_fwd: empty problem");
     AttnArgs a;
-    a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.resid = (const bf16_t*)resid; a.out = (bf16_t*)out; a.lse = lse;
+    a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.resid = (const bf16_t*)resid; a.out = (bf16_t*)out; a.oattn = (bf16_t*)o_attn; a.lse = lse;
     a.qm = mk_map(q_map); a.km = mk_map(kv_map); a.om = mk_map(out_map);
     GENIE_CHECK_ARG(a.qm.n_inner >= 1 && a.km.n_inner >= 1 && a.om.n_inner >= 1, "genie_attention_fwd: bad sequence map");
     a.nseq = nseq; a.nhead = nhead; a.Sq = Sq; a.Sk = Sk; a.scale = scale; a.causal = causal; a.kv_same = (k == v) ? 1 : 0;

@@ -79,7 +79,7 @@ SIGNATURES = {
     'genie_adamw_step': (C.c_int, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _I, _P]),
     'genie_rotary_layernorm_fwd': (C.c_int, [_P, _P, _L, _I, _L, _P, _L, _I, _P, _P, _F, _P, _P]),
     'genie_rotary_layernorm_bwd': (C.c_int, [_P, _P, _P, _P, _L, _I, _L, _P, _L, _I, _P, _P, _P, _P, _P]),
-    'genie_attention_fwd': (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _PL, _PL, _PL, _F, _I, _I, _P]),
+    'genie_attention_fwd': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _PL, _PL, _PL, _F, _I, _I, _P]),
     'genie_attention_bwd': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _PL, _PL, _PL, _PL, _F, _I, _I, _L, _P]),
     'genie_probe_ds_read_tr16': (C.c_int, [_P, _P, _P, _P]),
 }

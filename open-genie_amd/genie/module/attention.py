@@ -122,12 +122,14 @@ class _AttnFn(torch.autograd.Function):
             inner = t if mode == 'space' else hw
             kvmap = (inner, Sk * c, 0, c)
         out = empty_like_cl(x)
+        keep = any(ctx.needs_input_grad)
+        oattn = empty_like_cl(x) if (keep and add_resid) else None
         lse = torch.empty(ntok * n_head, dtype=torch.float32, device=x.device)
-        _hip.check(lib.genie_attention_fwd(P(u), P(k), P(v), P(x) if add_resid else None, P(out), P(lse), nseq, n_head, d_head, S, Sk,
+        _hip.check(lib.genie_attention_fwd(P(u), P(k), P(v), P(x) if add_resid else None, P(out), P(oattn), P(lse), nseq, n_head, d_head, S, Sk,
                                            _hip.i64(qmap), _hip.i64(kvmap), _hip.i64(qmap), scale, 1 if causal else 0, c, _hip.stream_ptr()),
                    'genie_attention_fwd')
         ctx.cfg = (mode, n_head, d_head, scale, causal, add_resid, eps, qmap, kvmap, nseq, S, Sk, pos_div, pos_mod)
-        ctx.save_for_backward(x, gamma, beta, table, kext, vext, u, out, lse, stats)
+        ctx.save_for_backward(x, gamma, beta, table, kext, vext, u, oattn if oattn is not None else out, lse, stats)
         return out
 
     @staticmethod
@@ -149,7 +151,7 @@ class _AttnFn(torch.autograd.Function):
             dk = torch.empty((nseq, Sk, c), dtype=torch.bfloat16, device=x.device)
             dv = torch.empty_like(dk)
             dkvmap = _hip.i64((1, Sk * c, 0, c))
-        _hip.check(lib.genie_attention_bwd(P(u), P(k), P(v), P(out), P(x) if add_resid else None, P(dout), P(lse), P(D), P(du), P(dk), P(dv),
+        _hip.check(lib.genie_attention_bwd(P(u), P(k), P(v), P(out), None, P(dout), P(lse), P(D), P(du), P(dk), P(dv),
                                            nseq, n_head, d_head, S, Sk, _hip.i64(qmap), _hip.i64(kvmap), _hip.i64(qmap), dkvmap, scale,
                                            1 if causal else 0, c, ntok, _hip.stream_ptr()), 'genie_attention_bwd')
         dx = empty_like_cl(x)
