@@ -64,6 +64,18 @@ __device__ __forceinline__ bf16x4_t lds_tr16(const char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4_t*)(p));
 }
 
+// The same read as inline asm.  hipcc's waitcnt pass treats the builtin as "may alias the in-flight LDS-DMA" and puts
+// s_waitcnt vmcnt(0) in front of it, which serialises the next chunk's loads with this chunk's MFMAs; an asm statement
+// is outside its bookkeeping, so the loads stay in flight.  The caller waits (lgkmcnt) before consuming.
+__device__ __forceinline__ bf16x4_t lds_tr16_asm(uint32_t lds_addr) {
+    bf16x4_t v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(lds_addr));
+    return v;
+}
+__device__ __forceinline__ uint32_t lds_offset(const void* p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+
 template <int BM, int BN, int WM, int WN>
 __global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs a) {
     constexpr int BK = 64;                                  // pixels per chunk
@@ -80,9 +92,17 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
 
-    int b = blockIdx.x;
-    const int split = b % a.split_k; b /= a.split_k;
+    // Work order: the taps of one (tile, pixel range) are consecutive, and consecutive work ids stay on ONE XCD
+    // (blocks are dealt round-robin to the 8 XCDs), so the 27 taps that re-read the same dy tile and shifted x tiles
+    // hit that XCD's L2 instead of streaming both tensors from HBM once per tap.
+    int b;
+    {
+        const int nb = gridDim.x, bid = blockIdx.x;
+        const int q = nb >> 3, r = nb & 7, xcd = bid & 7;
+        b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
     const int tap_i = b % a.ntaps; b /= a.ntaps;
+    const int split = b % a.split_k; b /= a.split_k;
     const int tile_n = b % a.tiles_n, tile_m = b / a.tiles_n;
     const int co0 = tile_m * BM, ci0 = tile_n * BN;
     const GenieTap tp = a.taps[tap_i];
@@ -122,10 +142,45 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs a) {
         b_c[i] = ci < a.Cs && ci < ((a.Cin + 7) & ~7) ? ci : -1;
     }
 
+    const int tap_delta = ((tp.dt * a.Hs + tp.dh) * a.Ws + tp.dw) * a.Cs;
+
     auto stage = [&](int chunk, int buf) {
         char* abase = smem + buf * STAGE;
         char* bbase = abase + A_BYTES;
         const int mbase = chunk * BK;
+        if constexpr (BM == 128 && BN == 128) {
+            // The 4 A loads and 4 B loads of a lane touch the same 4 pixel rows, and 16 lanes share each row: decode the
+            // wave's 16 rows ONCE (lane r & 15 owns row r) and broadcast the results with ds_bpermute.
+            const int r = lane & 15;
+            const uint32_t m = mbase + ((r >> 2) * 4 + wave) * 4 + (r & 3);
+            uint32_t dyoff = 0, xoff = 0, thw = 0x80000000u;          // bit 31: row invalid
+            if (m < (uint32_t)a.M) {
+                uint32_t q1 = fd_div(m, a.dWo); const uint32_t wo = m - q1 * a.dWo.d;
+                uint32_t q2 = fd_div(q1, a.dHo); const uint32_t ho = q1 - q2 * a.dHo.d;
+                uint32_t n = fd_div(q2, a.dTo); const uint32_t to = q2 - n * a.dTo.d;
+                dyoff = (((n * a.Td + to * a.dmt) * a.Hd + ho * a.dmh) * a.Wd + wo * a.dmw) * a.Cd;
+                const uint32_t t0 = to * a.st, h0 = ho * a.sh, w0 = wo * a.sw;
+                xoff = (((n * a.Ts + t0) * a.Hs + h0) * a.Ws + w0) * a.Cs;
+                thw = (t0 << 20) | (h0 << 10) | w0;                   // 10 bits each (host checks the ranges)
+            }
+#pragma unroll
+            for (int i = 0; i < A_LOADS; ++i) {
+                const int srcl = (i * 4 + (lane >> 4)) << 2;          // byte index for ds_bpermute
+                const uint32_t v_dy = (uint32_t)__builtin_amdgcn_ds_bpermute(srcl, (int)dyoff);
+                const uint32_t v_x = (uint32_t)__builtin_amdgcn_ds_bpermute(srcl, (int)xoff);
+                const uint32_t v_p = (uint32_t)__builtin_amdgcn_ds_bpermute(srcl, (int)thw);
+                const bool rowok = (v_p >> 31) == 0;
+                const bf16_t* pa = a.dy + (v_dy + (uint32_t)a_coff[i]);
+                pa = (rowok & (a_coff[i] >= 0)) ? pa : zero;
+                __builtin_amdgcn_global_load_lds(GLB_PTR(pa), LDS_PTR(abase + (i * 4 + wave) * 1024), 16, 0, 0);
+                const int t = (int)((v_p >> 20) & 1023) + tp.dt, h = (int)((v_p >> 10) & 1023) + tp.dh, w = (int)(v_p & 1023) + tp.dw;
+                const bool ok = rowok & (b_c[i] >= 0) & ((unsigned)t < (unsigned)a.Ts) & ((unsigned)h < (unsigned)a.Hs) & ((unsigned)w < (unsigned)a.Ws);
+                const bf16_t* pb = a.src + (v_x + (uint32_t)(tap_delta + b_c[i]));
+                pb = ok ? pb : zero;
+                __builtin_amdgcn_global_load_lds(GLB_PTR(pb), LDS_PTR(bbase + (i * 4 + wave) * 1024), 16, 0, 0);
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i) {
             const uint32_t m = mbase + a_row[i];
@@ -186,30 +241,48 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs a) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) ones[e] = (short)0x3F80;
 
+    const uint32_t smem_base = lds_offset(smem);
     if (c_begin < c_end) {
         stage(c_begin, 0);
         __syncthreads();
         for (int c = c_begin; c < c_end; ++c) {
             const int cur = (c - c_begin) & 1;
             if (c + 1 < c_end) stage(c + 1, cur ^ 1);
-            const char* abase = smem + cur * STAGE;
-            const char* bbase = abase + A_BYTES;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
+            const uint32_t abase = smem_base + cur * STAGE;
+            const uint32_t bbase = abase + A_BYTES;
+            // fragments of k-step ks+1 are requested before the MFMAs of k-step ks (two register sets, fully unrolled)
+            bf16x4_t alo[2][TM], ahi[2][TM], blo[2][TN], bhi[2][TN];
+            auto issue = [&](int ks, int set) {
                 const int r0 = ks * 16 + krow;
-                bf16x8_t af[TM], bfr[TN];
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
-                    const bf16x4_t lo = lds_tr16(abase + frag_addr(A_PITCH, A_CPR, r0, a_col[i]));
-                    const bf16x4_t hi = lds_tr16(abase + frag_addr(A_PITCH, A_CPR, r0 + 4, a_col[i]));
-                    af[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    alo[set][i] = lds_tr16_asm(abase + frag_addr(A_PITCH, A_CPR, r0, a_col[i]));
+                    ahi[set][i] = lds_tr16_asm(abase + frag_addr(A_PITCH, A_CPR, r0 + 4, a_col[i]));
                 }
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    const bf16x4_t lo = lds_tr16(bbase + frag_addr(B_PITCH, B_CPR, r0, b_col[j]));
-                    const bf16x4_t hi = lds_tr16(bbase + frag_addr(B_PITCH, B_CPR, r0 + 4, b_col[j]));
-                    bfr[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    blo[set][j] = lds_tr16_asm(bbase + frag_addr(B_PITCH, B_CPR, r0, b_col[j]));
+                    bhi[set][j] = lds_tr16_asm(bbase + frag_addr(B_PITCH, B_CPR, r0 + 4, b_col[j]));
                 }
+            };
+            issue(0, 0);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int set = ks & 1;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                bf16x8_t af[TM], bfr[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    asm volatile("" : "+v"(alo[set][i]), "+v"(ahi[set][i]));
+                    af[i] = __builtin_shufflevector(alo[set][i], ahi[set][i], 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    asm volatile("" : "+v"(blo[set][j]), "+v"(bhi[set][j]));
+                    bfr[j] = __builtin_shufflevector(blo[set][j], bhi[set][j], 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+                if (ks < 3) issue(ks + 1, set ^ 1);
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -252,8 +325,14 @@ static int launch_wgrad(WgradArgs& a, hipStream_t s) {
     const long long base = (long long)a.tiles_m * a.tiles_n * a.ntaps;
     int sk = a.split_k;
     if (sk <= 0) {
-        sk = (int)((1536 + base - 1) / base);            // ~6 blocks per CU in flight
+        // 2 blocks fit per CU (64 KiB LDS, ~250 VGPRs) -> 512 resident blocks.  Pick the split so that the grid is a whole
+        // number of 512-block rounds (a 3.01-round grid wastes a quarter of the chip on its last round).
         const int max_sk = (a.nchunks + 7) / 8;          // keep >= 8 chunks (512 pixels) per block
+        sk = 1;
+        for (int rounds = 3; rounds >= 1; --rounds) {
+            const int cand = (int)((512ll * rounds) / base);
+            if (cand >= 1) { sk = cand < max_sk ? cand : max_sk; break; }
+        }
         if (sk > max_sk) sk = max_sk;
         if (sk < 1) sk = 1;
     }
@@ -301,6 +380,8 @@ extern "C" int genie_conv_wgrad(const GenieWgradDesc* d, void* stream) {
     a.nchunks = cdiv(M, 64);
     a.split_k = d->split_k;
     a.dWo = make_fastdiv(d->Wo); a.dHo = make_fastdiv(d->Ho); a.dTo = make_fastdiv(d->To);
+    GENIE_CHECK_ARG((long long)d->To * d->st < 1024 && (long long)d->Ho * d->sh < 1024 && (long long)d->Wo * d->sw < 1024,
+                    "genie_conv_wgrad: output extent * stride must stay below 1024 per axis");
     hipStream_t s = (hipStream_t)stream;
     if (d->Cin <= 32) return launch_wgrad<128, 32, 4, 1>(a, s);
     if (d->Cout <= 32) return launch_wgrad<32, 128, 1, 4>(a, s);
