@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GENIE_ABI_VERSION 1
+#define GENIE_ABI_VERSION 2
 
 #define GENIE_F32 0
 #define GENIE_BF16 1
@@ -66,6 +66,15 @@ typedef struct GenieTap {
     int32_t pad0, pad1;
 } GenieTap;
 
+/* One (dt, dh, channel block of 64) step of a kw-triple convolution (conv_igemm3.hip): the three taps dw = -1, 0, +1 share
+ * one staged activation tile.  a_delta = ((dt * Hs + dh) * Ws) * Cs + c0 + 64 * block (elements); wofs{0,1,2} = element offset
+ * of the K segment of tap dw = -1 / 0 / +1 (same channel block) inside a weight row. */
+typedef struct GenieTriStep {
+    int32_t a_delta, dt, dh;
+    int32_t wofs0, wofs1, wofs2;
+    int32_t pad0, pad1;
+} GenieTriStep;
+
 typedef struct GenieConvDesc {
     const void* src;      /* CL bf16 (N, Ts, Hs, Ws, Cs)                                       */
     const void* wgt;      /* bf16 rows, K-contiguous segments (see genie_pack_weight)          */
@@ -91,9 +100,32 @@ typedef struct GenieConvDesc {
     int32_t act;          /* epilogue activation: 0 none, 1 SiLU                               */
     void* splitk_ws;      /* optional fp32 scratch: enables split-K when the output has too few tiles to fill the chip */
     int64_t splitk_ws_bytes;
+    /* optional kw-triple schedule (stride-1, same-size convs whose taps come as dw = -1, 0, +1 triples over whole 64-channel
+     * blocks): DEVICE pointer to n_tri_steps entries covering the same K range as `taps`.  tri_bm: 0 = choose the row tile,
+     * 128 / 256 = force it, -1 = ignore the schedule; tri_flags (debug / A-B timing) bit 0: drain every barrier instead of
+     * counted waits, bit 1: one-tile-ahead schedule for the 256-row tile instead of the deep-prefetch one; bits 2-5: timing ablations
+     * (wrong results). */
+    const GenieTriStep* tri_steps;
+    int32_t n_tri_steps;
+    int32_t tri_bm;
+    int32_t tri_flags;
+    int32_t reserved0;
 } GenieConvDesc;
 
 int genie_conv_igemm(const GenieConvDesc* desc, void* stream);
+
+/* Which kernel the calling thread's last genie_conv_igemm / genie_conv_wgrad launched (profiling aid). */
+#define GENIE_VARIANT_IGEMM_128 0
+#define GENIE_VARIANT_IGEMM_128_SMALLC 1
+#define GENIE_VARIANT_IGEMM_32 2
+#define GENIE_VARIANT_IGEMM_32_SMALLC 3
+#define GENIE_VARIANT_IGEMM3_128 4
+#define GENIE_VARIANT_IGEMM3_256 5
+#define GENIE_VARIANT_WGRAD_128 8
+#define GENIE_VARIANT_WGRAD_128x32 9
+#define GENIE_VARIANT_WGRAD_32x128 10
+#define GENIE_VARIANT_WGRAD3 11
+int genie_last_conv_variant(void);
 
 /* Weight gradient: dW[row(n)][tap][c] += sum_m DY[dpix(m)][n'] * SRC[pix(m)*step + off_tap][c]
  * replaces: the weight/bias gradient of nn.Conv3d computed by autograd for every conv above.
@@ -112,6 +144,8 @@ typedef struct GenieWgradDesc {
     int32_t shuf_c, shuf_q, shuf_r;
     int64_t s_cout, s_tap, s_cin;
     int32_t split_k;      /* 0 = choose */
+    int32_t tri_mode;     /* 1: the taps are ordered as kw-triples (dw = -1, 0, +1 consecutive, same dt / dh) of a stride-1,
+                             same-size convolution -> conv_wgrad3.hip may take it (2: must, whatever the problem size); 0: generic kernel */
 } GenieWgradDesc;
 
 int genie_conv_wgrad(const GenieWgradDesc* desc, void* stream);

@@ -15,3 +15,8 @@ void genie_set_error(const char* fmt, ...) {
 
 extern "C" const char* genie_last_error(void) { return g_err; }
 extern "C" int genie_abi_version(void) { return GENIE_ABI_VERSION; }
+
+// which kernel the last genie_conv_igemm / genie_conv_wgrad call of this thread launched (profiling aid)
+static thread_local int g_last_variant = -1;
+void genie_note_variant(int v) { g_last_variant = v; }
+extern "C" int genie_last_conv_variant(void) { return g_last_variant; }

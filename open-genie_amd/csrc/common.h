@@ -19,6 +19,7 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
 #define GENIE_ERR_HIP (-2)
 
 void genie_set_error(const char* fmt, ...);
+void genie_note_variant(int v);   // GENIE_VARIANT_* of the kernel just launched
 
 #define GENIE_CHECK_ARG(cond, ...)                      \
     do {                                                \

@@ -13,39 +13,10 @@
 // are 128 B (64 bf16); 16-B sub-chunk c of row r is stored at physical slot c ^ ((r >> 1) & 7) so
 // that the ds_read_b128 fragment reads (32 rows x one k-slot) are bank-conflict free; because the
 // DMA writes lane-linear, the swizzle is applied to the per-lane *source* address.
-#include "common.h"
-#include "genie_hip.h"
+#include "igemm_common.h"
 
 static __device__ __attribute__((aligned(256))) uint32_t g_zero_page[64];
 
-struct IgemmArgs {
-    const bf16_t* src;
-    const bf16_t* wgt;
-    bf16_t* dst;
-    const bf16_t* resid;
-    const float* bias;
-    const GenieTap* taps;
-    int ntaps;
-    int N, Ts, Hs, Ws, Cs;
-    int To, Ho, Wo;
-    int st, sh, sw;
-    int M, Ncols, Nstore;
-    int w_row_stride;
-    int perm_c, perm_f;
-    int Td, Hd, Wd, Cd;
-    int dmt, dmh, dmw, dot, doh, dow;
-    int shuf_c, shuf_q, shuf_r;
-    int tiles_m, tiles_n;
-    int nk;           // total K chunks
-    int act;          // 0 none, 1 silu (epilogue)
-    int split_k;      // > 1: blockIdx.y = K split; partial tiles go to ws (fp32 [split][M][ws_ld]) and a second kernel finishes
-    int chunks_per_split;
-    float* ws;
-    int ws_ld;
-};
-
-#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
-#define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 
 template <int BN, int WM, int WN, bool SMALLC>
 __global__ void __launch_bounds__(256) igemm_kernel(const IgemmArgs a) {
@@ -256,108 +227,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmArgs a) {
         return;
     }
 
-    // ---- epilogue: dest offset = rowoff[m] + coloff[n]; rowoff staged through LDS ----
-    int* rowoff = reinterpret_cast<int*>(smem);
-    if (tid < BM) {
-        int m = m0 + tid;
-        int off = -1;
-        if (m < a.M) {
-            const int wo = m % a.Wo; m /= a.Wo;
-            const int ho = m % a.Ho; m /= a.Ho;
-            const int to = m % a.To; m /= a.To;
-            off = (int)((((unsigned)(m * a.Td + to * a.dmt + a.dot) * a.Hd + ho * a.dmh + a.doh) * a.Wd + wo * a.dmw + a.dow) * a.Cd);
-        }
-        rowoff[tid] = off;
-    }
-    __syncthreads();
-    const bool vec4 = (a.shuf_c & 3) == 0 && (a.Nstore & 3) == 0 && (a.Cd & 3) == 0;
-    if (vec4) {
-        // 4x4 transposes inside lane quads (DPP quad_perm): lane j of a quad ends up with ONE row and FOUR consecutive
-        // columns -> 8-byte stores instead of 2-byte ones (4x fewer store instructions)
-        const int jq = lane & 3;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int nq = n0 + wn * (TN * 32) + j * 32 + (lane & 28);         // first of this quad's 4 columns
-            const bool colok = nq < a.Nstore;
-            const int sub = nq / a.shuf_c, ch = nq - sub * a.shuf_c;
-            const int r_ = sub % a.shuf_r, q_ = (sub / a.shuf_r) % a.shuf_q, p_ = sub / (a.shuf_r * a.shuf_q);
-            const int coloff = ((p_ * a.Hd + q_) * a.Wd + r_) * a.Cd + ch;
-            float bias4[4] = {0.f, 0.f, 0.f, 0.f};
-            if (a.bias && colok) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int n = nq + e;
-                    if (n < a.Ncols) bias4[e] = a.bias[a.perm_f > 1 ? (n % a.perm_c) * a.perm_f + n / a.perm_c : n];
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    float v[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
-                    // round 1: partner lane ^ 1 swaps the off-diagonal of each 2x2
-#pragma unroll
-                    for (int k = 0; k < 4; k += 2) {
-                        const float send = (jq & 1) ? v[k] : v[k + 1];
-                        const float recv = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0xB1, 0xF, 0xF, true));
-                        if (jq & 1) v[k] = recv; else v[k + 1] = recv;
-                    }
-                    // round 2: partner lane ^ 2
-#pragma unroll
-                    for (int k = 0; k < 2; ++k) {
-                        const float send = (jq & 2) ? v[k] : v[k + 2];
-                        const float recv = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0x4E, 0xF, 0xF, true));
-                        if (jq & 2) v[k] = recv; else v[k + 2] = recv;
-                    }
-                    // now v[e] = value of row (8 g + 4 khalf + jq), column nq + e
-                    const int row = wm * (TM * 32) + i * 32 + 8 * g + 4 * khalf + jq;
-                    const int ro = rowoff[row];
-                    if (ro < 0 || !colok) continue;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += bias4[e];
-                    if (a.resid) {
-                        const u32x2_t rv = *reinterpret_cast<const u32x2_t*>(a.resid + (unsigned)ro + coloff);
-                        v[0] += __uint_as_float(rv[0] << 16); v[1] += __uint_as_float(rv[0] & 0xffff0000u);
-                        v[2] += __uint_as_float(rv[1] << 16); v[3] += __uint_as_float(rv[1] & 0xffff0000u);
-                    }
-                    if (a.act == 1) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
-                    }
-                    u32x2_t ov;
-                    ov[0] = pack_bf16x2(v[0], v[1]);
-                    ov[1] = pack_bf16x2(v[2], v[3]);
-                    *reinterpret_cast<u32x2_t*>(a.dst + (unsigned)ro + coloff) = ov;
-                }
-            }
-        }
-        return;
-    }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * (TN * 32) + j * 32 + (lane & 31);
-        if (n >= a.Nstore) continue;
-        const int sub = n / a.shuf_c, ch = n - sub * a.shuf_c;
-        const int r = sub % a.shuf_r, q = (sub / a.shuf_r) % a.shuf_q, p = sub / (a.shuf_r * a.shuf_q);
-        const int coloff = ((p * a.Hd + q) * a.Wd + r) * a.Cd + ch;
-        float bias = 0.f;
-        if (a.bias && n < a.Ncols) bias = a.bias[a.perm_f > 1 ? (n % a.perm_c) * a.perm_f + n / a.perm_c : n];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int r16 = 0; r16 < 16; ++r16) {
-                const int row = wm * (TM * 32) + i * 32 + (r16 & 3) + 8 * (r16 >> 2) + 4 * khalf;
-                const int ro = rowoff[row];
-                if (ro < 0) continue;
-                float v = acc[i][j][r16] + bias;
-                if (a.resid) v += bf16_to_f32(a.resid[(unsigned)ro + coloff]);
-                if (a.act == 1) v = silu_f(v);
-                a.dst[(unsigned)ro + coloff] = f32_to_bf16(v);
-            }
-        }
-    }
+    igemm_epilogue<BM, TM, TN>(a, acc, smem, m0, n0, wm, wn, tid, lane);
 }
 
 // split-K finish: sum the partial tiles, then the same epilogue (bias, resid, act, destination mapping)
@@ -408,6 +278,8 @@ static int launch_igemm(const IgemmArgs& a, hipStream_t s) {
     return GENIE_OK;
 }
 
+int genie_conv_igemm3_try(const GenieConvDesc* d, IgemmArgs a, hipStream_t s);   // conv_igemm3.hip
+
 extern "C" int genie_conv_igemm(const GenieConvDesc* d, void* stream) {
     GENIE_CHECK_ARG(d, "genie_conv_igemm: null descriptor");
     GENIE_CHECK_ARG(d->src && d->wgt && d->dst && d->taps, "genie_conv_igemm: null tensor pointer");
@@ -446,8 +318,14 @@ extern "C" int genie_conv_igemm(const GenieConvDesc* d, void* stream) {
     a.tiles_m = cdiv(M, 128);
     hipStream_t s = (hipStream_t)stream;
     a.split_k = 1; a.chunks_per_split = a.nk; a.ws = nullptr; a.ws_ld = 0;
+    a.tiles_n = cdiv(a.Nstore, 128);
+    {
+        const int rc = genie_conv_igemm3_try(d, a, s);
+        if (rc <= 0) return rc;
+    }
     if (a.Nstore <= 32) {
         a.tiles_n = cdiv(a.Nstore, 32);
+        genie_note_variant(smallc ? GENIE_VARIANT_IGEMM_32_SMALLC : GENIE_VARIANT_IGEMM_32);
         return smallc ? launch_igemm<32, 4, 1, true>(a, s) : launch_igemm<32, 4, 1, false>(a, s);
     }
     a.tiles_n = cdiv(a.Nstore, 128);
@@ -465,5 +343,6 @@ extern "C" int genie_conv_igemm(const GenieConvDesc* d, void* stream) {
             a.ws_ld = a.Nstore;
         }
     }
+    genie_note_variant(smallc ? GENIE_VARIANT_IGEMM_128_SMALLC : GENIE_VARIANT_IGEMM_128);
     return smallc ? launch_igemm<128, 2, 2, true>(a, s) : launch_igemm<128, 2, 2, false>(a, s);
 }

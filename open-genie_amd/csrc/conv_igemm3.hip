@@ -1,0 +1,496 @@
+// Gather-GEMM for stride-1 convolutions whose taps come in kw-triples (dw = -1, 0, +1): Conv3d k=(*,*,3) forward and its
+// backward-data pass (reference: nn.Conv3d(k=3, padding=1) in VideoResidualBlock video.py:580-620, CausalConv3d video.py:178-192,
+// the ST-block FFN conv attention.py:429-438, the DepthToSpaceTimeUpsample conv video.py:396-402).
+//
+// Why a second kernel: at a 128x128x64 tile the generic kernel moves 32 KB through the CU's vector-memory path per 16 MFMAs
+// per wave, i.e. 64 B/clk/CU at full MFMA rate -- exactly that path's peak, so it tops out near 35 % of the MFMA roofline.
+// The three taps of a kw-triple read the SAME activation rows shifted by one pixel, so this kernel stages each activation
+// tile ONCE per triple as an LDS image with explicit zero columns left and right of every image row
+//
+//     image row  (hl, wp) = hl * (W + 2) + wp,   wp = w + 1,   wp = 0 and wp = W + 1 are zero (the conv's w padding)
+//
+// and the three taps read it at row offsets +0 / +1 / +2: no masks in the MFMA loop, a third of the activation traffic.
+// With BM = 256 rows per block the weight tile is amortised over twice the rows: 27 KB per K-tile per 256x128 tile
+// (26 B/clk/CU at full rate) instead of 64.
+//
+//   M-tile  : BM consecutive output pixels = BM / W complete image rows (BM % W == 0, any (n, t, h) per row)
+//   K order : for (dt, dh, channel block of 64): one image; for s in 0..2: one 128 x 64 weight tile
+//   LDS     : 2 images (1.25 BM rows x 128 B) + 2 weight tiles (16 KB), all DMA'd (global_load_lds_dwordx4);
+//             16-B chunk c of row r sits at slot c ^ ((r >> 1) & 7) (source-side swizzle, conflict-free ds_read_b128)
+//   waves   : BM / 64 x 2, each 64 x 64 (2 x 2 v_mfma_f32_32x32x16_bf16 tiles), fp32 accumulate
+//   pipeline: the next weight tile and 1-2 glds rounds of the next image are issued before the MFMAs of the current K-tile;
+//             waits are counted (s_waitcnt vmcnt(N)) so that image rounds stay in flight across the workgroup barrier
+#include "igemm_common.h"
+
+static __device__ __attribute__((aligned(256))) uint32_t g_zero_page3[64];
+
+struct Igemm3Args {
+    IgemmArgs g;                   // tensors, row grid (To/Ho/Wo == Ts/Hs/Ws), destination mapping, weight permutation, tiles
+    int nsteps;                    // entries of the step table, one per (dt, dh, channel block)
+    int WP, img_rows;              // W + 2, (BM / W) * WP
+    int dbg;                       // timing ablations (results are WRONG when non-zero): 4 no glds in the loop, 8 no ds_read,
+                                   // 16 no MFMA, 32 no barrier
+};
+
+template <int BM, bool PIPE>
+__global__ void __launch_bounds__(BM * 2) igemm3_kernel(const Igemm3Args p, const GenieTriStep* __restrict__ steps) {
+    // `steps` is a separate __restrict__ argument so that the (wave-uniform) table reads become scalar loads
+    constexpr int BN = 128, NT = BM * 2, NWAVE = NT / 64;
+    constexpr int WN = 2;                               // wave grid (BM / 64) x 2, wave tile 64 x 64
+    constexpr int TM = 2, TN = 2;
+    constexpr int RPR = NT / 8;                         // LDS rows written by one glds round of the whole block
+    constexpr int A_ROUNDS = 5;                         // image rows <= 1.25 BM for W >= 8
+    constexpr int A_BYTES = A_ROUNDS * RPR * 128;
+    constexpr int B_BYTES = BN * 128;
+    constexpr int B_LOADS = BN / RPR;                   // 2 (512 threads) or 4 (256 threads)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const IgemmArgs& a = p.g;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int W = a.Wo, H = a.Ho, T = a.To, WP = p.WP;
+
+    int tile_m, tile_n;
+    {
+        const int id = xcd_tile_id(a.tiles_m * a.tiles_n, blockIdx.x);
+        tile_n = id % a.tiles_n;
+        tile_m = id / a.tiles_n;
+    }
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page3);
+
+    // ---- per-thread staging state: the image rows this lane fills (one per round) ----
+    // a_base: element offset of the row's home pixel (+ this lane's logical 16-B chunk); a_th: (t << 16) | h of the home pixel,
+    // or a value that fails every range check for rows that are padding / outside the tile / beyond M.
+    unsigned a_base[A_ROUNDS];
+    int a_th[A_ROUNDS];
+    const int row0_id = m0 / W;                         // (n, t, h) row index of the tile's first image row
+#pragma unroll
+    for (int i = 0; i < A_ROUNDS; ++i) {
+        const int r = i * RPR + (tid >> 3);
+        const int lc = (tid & 7) ^ ((r >> 1) & 7);
+        const int hl = r / WP, w = r - hl * WP - 1;
+        const int rowid = row0_id + hl;
+        const long long m = (long long)rowid * W + w;
+        const bool valid = r < p.img_rows && w >= 0 && w < W && m < a.M;
+        a_base[i] = valid ? (unsigned)m * (unsigned)a.Cs + lc * 8 : 0u;
+        a_th[i] = valid ? ((((rowid / H) % T) << 16) | (rowid % H)) : (int)0x80000000;
+    }
+    bool b_ok[B_LOADS];
+    const bf16_t* b_ptr[B_LOADS];
+#pragma unroll
+    for (int j = 0; j < B_LOADS; ++j) {
+        const int row = j * RPR + (tid >> 3);
+        const int lc = (tid & 7) ^ ((row >> 1) & 7);
+        const int n = n0 + row;
+        b_ok[j] = n < a.Ncols;
+        const int wr = b_ok[j] ? (a.perm_f > 1 ? (n % a.perm_c) * a.perm_f + n / a.perm_c : n) : 0;
+        b_ptr[j] = a.wgt + (size_t)wr * a.w_row_stride + lc * 8;
+    }
+
+    const int dbg = p.dbg;
+    auto stage_a = [&](const GenieTriStep& e, bool live, int i, char* abuf) {
+        if (dbg & 4) return;
+        const int t = (a_th[i] >> 16) + e.dt, h = (a_th[i] & 0xffff) + e.dh;
+        const bool ok = live & ((unsigned)t < (unsigned)T) & ((unsigned)h < (unsigned)H);
+        const bf16_t* q = a.src + (int)(a_base[i] + (unsigned)e.a_delta);
+        q = ok ? q : zero;
+        __builtin_amdgcn_global_load_lds(GLB_PTR(q), LDS_PTR(abuf + (i * NWAVE + wave) * 1024), 16, 0, 0);
+    };
+    auto stage_b = [&](int wofs, bool live, char* bbuf) {
+        if (dbg & 4) return;
+#pragma unroll
+        for (int j = 0; j < B_LOADS; ++j) {
+            const bf16_t* q = (live & b_ok[j]) ? b_ptr[j] + wofs : zero;
+            __builtin_amdgcn_global_load_lds(GLB_PTR(q), LDS_PTR(bbuf + (j * NWAVE + wave) * 1024), 16, 0, 0);
+        }
+    };
+
+    // ---- fragment read addresses ----
+    int a_row[TM], b_rd[TN], b_sw[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int pl = wm * 64 + i * 32 + (lane & 31);  // tile-local pixel
+        const int hl = pl / W;
+        a_row[i] = hl * WP + (pl - hl * W);             // image row of (pixel, dw = -1); + s for dw = s - 1
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int row = wn * 64 + j * 32 + (lane & 31);
+        b_rd[j] = row * 128;
+        b_sw[j] = (row >> 1) & 7;
+    }
+    const int khalf = lane >> 5;
+
+    f32x16_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto compute = [&](const char* abuf, int s, const char* bbuf) {
+        int a_rd[TM], a_sw[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int row = a_row[i] + s;
+            a_rd[i] = row * 128;
+            a_sw[i] = (row >> 1) & 7;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8_t af[TM], bfr[TN];
+            const int lc = ks * 2 + khalf;
+            if (dbg & 8) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) asm volatile("" : "=v"(af[i]));
+#pragma unroll
+                for (int j = 0; j < TN; ++j) asm volatile("" : "=v"(bfr[j]));
+            } else {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(abuf + a_rd[i] + ((lc ^ a_sw[i]) << 4));
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const bf16x8_t*>(bbuf + b_rd[j] + ((lc ^ b_sw[j]) << 4));
+            }
+            if (dbg & 16) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) asm volatile("" :: "v"(af[i]));
+#pragma unroll
+                for (int j = 0; j < TN; ++j) asm volatile("" :: "v"(bfr[j]));
+            } else {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    };
+
+    // end of a K-tile: everything issued before the last KEEP glds of this wave has landed, then the workgroup meets
+    auto sync_keep2 = [&]() {
+        if constexpr (PIPE) {
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            if (!(dbg & 32)) __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        } else {
+            __syncthreads();
+        }
+    };
+    auto sync_all = [&]() {
+        if constexpr (PIPE) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (!(dbg & 32)) __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        } else {
+            __syncthreads();
+        }
+    };
+
+    char* const A0 = smem;
+    char* const B0 = smem + 2 * A_BYTES;
+
+    // ---- prologue: image 0 and weight tile 0 ----
+    {
+        const GenieTriStep e = steps[0];
+#pragma unroll
+        for (int i = 0; i < A_ROUNDS; ++i) stage_a(e, true, i, A0);
+        stage_b(e.wofs0, true, B0);
+    }
+    sync_all();
+
+    int kpar = 0;                                       // parity of the current K-tile (selects the weight buffer)
+    for (int i = 0; i < p.nsteps; ++i) {
+        const GenieTriStep cur = steps[i];
+        const bool has_next = i + 1 < p.nsteps;
+        const GenieTriStep nxt = steps[has_next ? i + 1 : i];
+        char* const acur = A0 + (i & 1) * A_BYTES;
+        char* const anxt = A0 + ((i + 1) & 1) * A_BYTES;
+        char* const bcur = B0 + kpar * B_BYTES;
+        char* const boff = B0 + (kpar ^ 1) * B_BYTES;
+        // s = 0 : weight tile (i, 1) and image rounds 0, 1 of step i + 1 go out first
+        stage_b(cur.wofs1, true, boff);
+        __builtin_amdgcn_sched_barrier(0);               // the counted waits below rely on this issue order
+        stage_a(nxt, has_next, 0, anxt);
+        stage_a(nxt, has_next, 1, anxt);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(acur, 0, bcur);
+        sync_keep2();
+        // s = 1
+        stage_b(cur.wofs2, true, bcur);
+        __builtin_amdgcn_sched_barrier(0);
+        stage_a(nxt, has_next, 2, anxt);
+        stage_a(nxt, has_next, 3, anxt);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(acur, 1, boff);
+        sync_keep2();
+        // s = 2 : weight tile (i + 1, 0); the image of step i + 1 must be complete before the barrier
+        stage_b(nxt.wofs0, has_next, boff);
+        stage_a(nxt, has_next, 4, anxt);
+        compute(acur, 2, bcur);
+        sync_all();
+        kpar ^= 1;
+    }
+
+    igemm_epilogue<BM, TM, TN>(a, acc, smem, m0, n0, wm, wn, tid, lane);
+}
+
+
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Deep-prefetch variant for the 256-row tile (8 waves, 1 block per CU).  Measured on the lock-step kernel above (timing
+// ablations, 256->256 @16x32x32, B = 8): MFMAs alone 0.27 ms, the glds stream alone 0.26 ms, everything 0.43 ms -- with the
+// weight tile of K-tile k+1 issued at the start of K-tile k and waited for at its end, every K-tile (~0.5 us of MFMA work)
+// exposes a loaded L2/MALL round trip (~0.6 us).  Here weight tiles live in a ring of FOUR slots and are issued THREE K-tiles
+// ahead; image rounds go out in the first two K-tiles of a triple.  Per K-tile the wave issues one group
+//     s = 0: image rounds 0,1,2 then weight tile k+3        (5 glds)
+//     s = 1: image rounds 3,4   then weight tile k+3        (4 glds)
+//     s = 2:                         weight tile k+3        (2 glds)
+// and ends with a counted wait that retires everything up to weight tile k+1 (the tail of group k-2) -- i.e. leaves groups
+// k-1 and k in flight: vmcnt(2+5), vmcnt(5+4); at s = 2 the image rounds of group k-1 must have landed as well (the next
+// K-tile reads the new image), they precede that group's weight tile, so vmcnt(2+2).  The barrier after the wait publishes the
+// landed data to all waves (RAW) and fences the slot that the NEXT group overwrites (WAR: slot (k+4) & 3 = k & 3 was read in
+// K-tile k, the spare image was last read in K-tile 3i-1).
+// ------------------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(512) igemm3d_kernel(const Igemm3Args p, const GenieTriStep* __restrict__ steps) {
+    constexpr int BM = 256, BN = 128, NT = 512, NWAVE = 8, WN = 2, TM = 2, TN = 2;
+    constexpr int RPR = NT / 8, A_ROUNDS = 5;
+    constexpr int A_BYTES = A_ROUNDS * RPR * 128, B_BYTES = BN * 128;
+    constexpr int B_LOADS = BN / RPR;                   // 2
+    static_assert(B_LOADS == 2, "the counted waits below assume 2 weight glds per thread per K-tile");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const IgemmArgs& a = p.g;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int W = a.Wo, H = a.Ho, T = a.To, WP = p.WP;
+
+    int tile_m, tile_n;
+    {
+        const int id = xcd_tile_id(a.tiles_m * a.tiles_n, blockIdx.x);
+        tile_n = id % a.tiles_n;
+        tile_m = id / a.tiles_n;
+    }
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page3);
+
+    unsigned a_base[A_ROUNDS];
+    int a_th[A_ROUNDS];
+    const int row0_id = m0 / W;
+#pragma unroll
+    for (int i = 0; i < A_ROUNDS; ++i) {
+        const int r = i * RPR + (tid >> 3);
+        const int lc = (tid & 7) ^ ((r >> 1) & 7);
+        const int hl = r / WP, w = r - hl * WP - 1;
+        const int rowid = row0_id + hl;
+        const long long m = (long long)rowid * W + w;
+        const bool valid = r < p.img_rows && w >= 0 && w < W && m < a.M;
+        a_base[i] = valid ? (unsigned)m * (unsigned)a.Cs + lc * 8 : 0u;
+        a_th[i] = valid ? ((((rowid / H) % T) << 16) | (rowid % H)) : (int)0x80000000;
+    }
+    bool b_ok[B_LOADS];
+    const bf16_t* b_ptr[B_LOADS];
+#pragma unroll
+    for (int j = 0; j < B_LOADS; ++j) {
+        const int row = j * RPR + (tid >> 3);
+        const int lc = (tid & 7) ^ ((row >> 1) & 7);
+        const int n = n0 + row;
+        b_ok[j] = n < a.Ncols;
+        const int wr = b_ok[j] ? (a.perm_f > 1 ? (n % a.perm_c) * a.perm_f + n / a.perm_c : n) : 0;
+        b_ptr[j] = a.wgt + (size_t)wr * a.w_row_stride + lc * 8;
+    }
+    auto stage_a = [&](const GenieTriStep& e, bool live, int i, char* abuf) {
+        const int t = (a_th[i] >> 16) + e.dt, h = (a_th[i] & 0xffff) + e.dh;
+        const bool ok = live & ((unsigned)t < (unsigned)T) & ((unsigned)h < (unsigned)H);
+        const bf16_t* q = a.src + (int)(a_base[i] + (unsigned)e.a_delta);
+        q = ok ? q : zero;
+        __builtin_amdgcn_global_load_lds(GLB_PTR(q), LDS_PTR(abuf + (i * NWAVE + wave) * 1024), 16, 0, 0);
+    };
+    auto stage_b = [&](int wofs, bool live, char* bbuf) {
+#pragma unroll
+        for (int j = 0; j < B_LOADS; ++j) {
+            const bf16_t* q = (live & b_ok[j]) ? b_ptr[j] + wofs : zero;
+            __builtin_amdgcn_global_load_lds(GLB_PTR(q), LDS_PTR(bbuf + (j * NWAVE + wave) * 1024), 16, 0, 0);
+        }
+    };
+
+    int a_row[TM], b_rd[TN], b_sw[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int pl = wm * 64 + i * 32 + (lane & 31);
+        const int hl = pl / W;
+        a_row[i] = hl * WP + (pl - hl * W);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int row = wn * 64 + j * 32 + (lane & 31);
+        b_rd[j] = row * 128;
+        b_sw[j] = (row >> 1) & 7;
+    }
+    const int khalf = lane >> 5;
+
+    f32x16_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto compute = [&](const char* abuf, int s, const char* bbuf) {
+        int a_rd[TM], a_sw[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int row = a_row[i] + s;
+            a_rd[i] = row * 128;
+            a_sw[i] = (row >> 1) & 7;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8_t af[TM], bfr[TN];
+            const int lc = ks * 2 + khalf;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(abuf + a_rd[i] + ((lc ^ a_sw[i]) << 4));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const bf16x8_t*>(bbuf + b_rd[j] + ((lc ^ b_sw[j]) << 4));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    auto raw_barrier = [&]() {
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+
+    char* const A0 = smem;
+    char* const B0 = smem + 2 * A_BYTES;                // four weight slots
+
+    // ---- prologue: image 0, weight tiles 0, 1, 2 ----
+    {
+        const GenieTriStep e = steps[0];
+#pragma unroll
+        for (int i = 0; i < A_ROUNDS; ++i) stage_a(e, true, i, A0);
+        stage_b(e.wofs0, true, B0);
+        stage_b(e.wofs1, true, B0 + B_BYTES);
+        stage_b(e.wofs2, true, B0 + 2 * B_BYTES);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    raw_barrier();
+
+    int k = 0;                                          // K-tile index (3 i + s); weight tile k sits in slot k & 3
+    for (int i = 0; i < p.nsteps; ++i, k += 3) {
+        const GenieTriStep cur = steps[i];
+        const bool has_next = i + 1 < p.nsteps;
+        const GenieTriStep nxt = steps[has_next ? i + 1 : i];
+        char* const acur = A0 + (i & 1) * A_BYTES;
+        char* const anxt = A0 + ((i + 1) & 1) * A_BYTES;
+        // ---- s = 0: group = image rounds 0-2 of step i+1, then weight tile k+3 = (i+1, 0) ----
+        stage_a(nxt, has_next, 0, anxt);
+        stage_a(nxt, has_next, 1, anxt);
+        stage_a(nxt, has_next, 2, anxt);
+        __builtin_amdgcn_sched_barrier(0);              // the counted waits rely on this issue order
+        stage_b(nxt.wofs0, has_next, B0 + ((k + 3) & 3) * B_BYTES);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(acur, 0, B0 + (k & 3) * B_BYTES);
+        asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+        raw_barrier();
+        // ---- s = 1: image rounds 3, 4, then weight tile k+4 = (i+1, 1) ----
+        stage_a(nxt, has_next, 3, anxt);
+        stage_a(nxt, has_next, 4, anxt);
+        __builtin_amdgcn_sched_barrier(0);
+        stage_b(nxt.wofs1, has_next, B0 + ((k + 4) & 3) * B_BYTES);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(acur, 1, B0 + ((k + 1) & 3) * B_BYTES);
+        asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        raw_barrier();
+        // ---- s = 2: weight tile k+5 = (i+1, 2); the new image must have landed before the barrier ----
+        stage_b(nxt.wofs2, has_next, B0 + ((k + 5) & 3) * B_BYTES);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(acur, 2, B0 + ((k + 2) & 3) * B_BYTES);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        raw_barrier();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    raw_barrier();
+
+    igemm_epilogue<BM, TM, TN>(a, acc, smem, m0, n0, wm, wn, tid, lane);
+}
+
+static int launch_igemm3d(const Igemm3Args& p, const GenieTriStep* steps, hipStream_t s) {
+    constexpr int lds = 2 * (5 * 64 * 128) + 4 * 128 * 128;
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute((const void*)igemm3d_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) {
+            genie_set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return GENIE_ERR_HIP;
+        }
+        configured = true;
+    }
+    hipLaunchKernelGGL(igemm3d_kernel, dim3(p.g.tiles_m * p.g.tiles_n), dim3(512), lds, s, p, steps);
+    GENIE_CHECK_LAUNCH();
+    return GENIE_OK;
+}
+
+template <int BM, bool PIPE>
+static int launch_igemm3(const Igemm3Args& p, const GenieTriStep* steps, hipStream_t s) {
+    constexpr int NT = BM * 2;
+    constexpr int lds = 2 * (5 * (NT / 8) * 128) + 2 * 128 * 128;
+    auto k = igemm3_kernel<BM, PIPE>;
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) {
+            genie_set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return GENIE_ERR_HIP;
+        }
+        configured = true;
+    }
+    hipLaunchKernelGGL(k, dim3(p.g.tiles_m * p.g.tiles_n), dim3(NT), lds, s, p, steps);
+    GENIE_CHECK_LAUNCH();
+    return GENIE_OK;
+}
+
+// Called by genie_conv_igemm (conv_igemm.hip) with the generic arguments already filled in.  Returns 1 when the problem is not
+// eligible (caller falls back to the generic kernel), 0 on launch, < 0 on error.
+int genie_conv_igemm3_try(const GenieConvDesc* d, IgemmArgs a, hipStream_t s) {
+    if (!d->tri_steps || d->n_tri_steps <= 0 || d->tri_bm < 0) return 1;
+    if (d->small_c || d->st != 1 || d->sh != 1 || d->sw != 1) return 1;
+    if (d->To != d->Ts || d->Ho != d->Hs || d->Wo != d->Ws) return 1;
+    const int W = d->Wo;
+    if (W < 8 || a.Nstore <= 32) return 1;
+    if (d->Ts >= 32768 || d->Hs >= 65536) return 1;
+    int bm = d->tri_bm;
+    const int tiles_n = cdiv(a.Nstore, 128);
+    if (bm == 0) {
+        const long long t128 = (long long)cdiv(a.M, 128) * tiles_n, t256 = (long long)cdiv(a.M, 256) * tiles_n;
+        if (t128 < 256) return 1;                        // few tiles: the generic kernel's split-K fills the chip better
+        bm = (256 % W == 0 && t256 >= 512) ? 256 : 128;
+    }
+    if (bm != 128 && bm != 256) {
+        genie_set_error("genie_conv_igemm: tri_bm must be 0, 128 or 256 (got %d)", bm);
+        return GENIE_ERR_ARG;
+    }
+    if (bm % W != 0) {
+        if (d->tri_bm == 0 && 128 % W == 0) bm = 128;
+        else return 1;
+    }
+    Igemm3Args p;
+    p.g = a;
+    p.g.tiles_m = cdiv(a.M, bm);
+    p.g.tiles_n = tiles_n;
+    p.g.split_k = 1;
+    p.nsteps = d->n_tri_steps;
+    p.WP = W + 2;
+    p.img_rows = (bm / W) * (W + 2);
+    p.dbg = d->tri_flags & ~3;
+    const bool pipe = (d->tri_flags & 1) == 0;
+    genie_note_variant(bm == 256 ? GENIE_VARIANT_IGEMM3_256 : GENIE_VARIANT_IGEMM3_128);
+    if (bm == 256 && (d->tri_flags & 2) == 0) return launch_igemm3d(p, d->tri_steps, s);     // deep-prefetch schedule
+    if (bm == 256) return pipe ? launch_igemm3<256, true>(p, d->tri_steps, s) : launch_igemm3<256, false>(p, d->tri_steps, s);
+    return pipe ? launch_igemm3<128, true>(p, d->tri_steps, s) : launch_igemm3<128, false>(p, d->tri_steps, s);
+}

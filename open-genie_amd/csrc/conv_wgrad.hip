@@ -353,6 +353,8 @@ static int launch_wgrad(WgradArgs& a, hipStream_t s) {
     return GENIE_OK;
 }
 
+int genie_conv_wgrad3_try(const GenieWgradDesc* d, hipStream_t s);   // conv_wgrad3.hip
+
 extern "C" int genie_conv_wgrad(const GenieWgradDesc* d, void* stream) {
     GENIE_CHECK_ARG(d, "genie_conv_wgrad: null descriptor");
     GENIE_CHECK_ARG(d->src && d->dy && d->dw && d->taps, "genie_conv_wgrad: null tensor pointer");
@@ -360,6 +362,10 @@ extern "C" int genie_conv_wgrad(const GenieWgradDesc* d, void* stream) {
     GENIE_CHECK_ARG(d->shuf_c >= 1 && d->shuf_q >= 1 && d->shuf_r >= 1, "genie_conv_wgrad: bad shuffle spec");
     GENIE_CHECK_ARG((long long)d->N * d->Ts * d->Hs * d->Ws * d->Cs < (1ll << 31) && (long long)d->N * d->Td * d->Hd * d->Wd * d->Cd < (1ll << 31),
                     "genie_conv_wgrad: tensor exceeds 2^31 elements");
+    {
+        const int rc = genie_conv_wgrad3_try(d, (hipStream_t)stream);
+        if (rc <= 0) return rc;
+    }
     WgradArgs a;
     a.src = (const bf16_t*)d->src; a.dy = (const bf16_t*)d->dy; a.dw = d->dw; a.dbias = d->dbias; a.taps = d->taps; a.ntaps = d->ntaps;
     a.N = d->N; a.Ts = d->Ts; a.Hs = d->Hs; a.Ws = d->Ws; a.Cs = d->Cs; a.Cin = d->Cin;
@@ -383,7 +389,8 @@ extern "C" int genie_conv_wgrad(const GenieWgradDesc* d, void* stream) {
     GENIE_CHECK_ARG((long long)d->To * d->st < 1024 && (long long)d->Ho * d->sh < 1024 && (long long)d->Wo * d->sw < 1024,
                     "genie_conv_wgrad: output extent * stride must stay below 1024 per axis");
     hipStream_t s = (hipStream_t)stream;
-    if (d->Cin <= 32) return launch_wgrad<128, 32, 4, 1>(a, s);
-    if (d->Cout <= 32) return launch_wgrad<32, 128, 1, 4>(a, s);
+    if (d->Cin <= 32) { genie_note_variant(GENIE_VARIANT_WGRAD_128x32); return launch_wgrad<128, 32, 4, 1>(a, s); }
+    if (d->Cout <= 32) { genie_note_variant(GENIE_VARIANT_WGRAD_32x128); return launch_wgrad<32, 128, 1, 4>(a, s); }
+    genie_note_variant(GENIE_VARIANT_WGRAD_128);
     return launch_wgrad<128, 128, 2, 2>(a, s);
 }

@@ -1,0 +1,345 @@
+// Conv3d weight gradient for stride-1 convolutions whose taps come in kw-triples (dw = -1, 0, +1), on gfx950 MFMA.
+//
+//   dW[co][(dt, dh, dw)][ci] += sum_pixels DY[pix][co] * X[pix + (dt, dh, dw)][ci]        (+ dbias[co] += sum DY)
+//
+// The generic kernel (conv_wgrad.hip) gives every tap its own block, so both operand tiles (32 KB per 64 pixels) are DMA'd
+// and read from LDS once per tap.  The three taps of a kw-triple read the SAME dy tile and the SAME x rows shifted by one
+// pixel, so here one block owns a whole triple:
+//   - dy tile [64 pixels][128 co] and an x IMAGE [(64 / W) rows of W + 2 pixels][128 ci] with explicit zero columns left and
+//     right of every image row are staged once per 64-pixel chunk and serve 3 x 16 = 48 MFMAs per wave-quad: a third of the
+//     glds issues and LDS-DMA bytes per MFMA;
+//   - the dy fragments (2 transposing LDS reads each) are shared by the three taps in registers, the x fragments are read at
+//     row offsets +0 / +1 / +2: 5 fragment reads per 6 MFMAs instead of 6.
+// 8 waves (2 per SIMD) as 2 (co) x 4 (ci); a wave owns 64 co x 32 ci x 3 taps = 96 accumulator registers.  Stages live in
+// a ring of THREE LDS buffers, issued two chunks ahead; waits are counted (vmcnt) so a whole stage stays in flight across
+// the barrier.  Both operands are pixel-major in HBM and in LDS; MFMA fragments come from ds_read_b64_tr_b16 (lane semantics
+// pinned by tests/test_gpu_kernels.py::test_probe_ds_read_tr16).  Split-K over pixel ranges, fp32 atomics into the gradient.
+#include "common.h"
+#include "genie_hip.h"
+
+static __device__ __attribute__((aligned(256))) uint32_t g_zero_page_w3[64];
+
+struct FastDiv3 {
+    uint32_t magic, shift, d;
+};
+static FastDiv3 make_fastdiv3(uint32_t d) {
+    FastDiv3 f;
+    f.d = d;
+    uint32_t l = 0;
+    while ((1ull << l) < d) ++l;
+    f.shift = 31 + l;
+    f.magic = (uint32_t)(((1ull << f.shift) + d - 1) / d);
+    return f;
+}
+__device__ __forceinline__ uint32_t fd3(uint32_t n, const FastDiv3& f) { return (uint32_t)(((uint64_t)n * f.magic) >> f.shift); }   // n < 2^31
+
+struct Wgrad3Args {
+    const bf16_t* src;
+    const bf16_t* dy;
+    float* dw;
+    float* dbias;
+    const GenieTap* taps;       // dt / dh of triple tr are read from taps[3 tr]
+    int ntriples;
+    int T, H, W, Cs, Cin;       // x geometry == row grid (stride 1, same size)
+    int Td, Hd, Wd, Cd, Cout;   // dy geometry
+    int dmt, dmh, dmw;
+    int shuf_c, shuf_q, shuf_r, shuf_f;
+    long long s_cout, s_tap, s_cin;
+    int M, nchunks, split_k, chunks_per_split;
+    int tiles_m, tiles_n;
+    int img_rows, log2W;        // (64 / W) * (W + 2);  W is a power of two in [8, 64]
+    FastDiv3 dW_, dH_, dT_;
+};
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+__device__ __forceinline__ bf16x4_t w3_tr16(uint32_t lds_addr) {
+    bf16x4_t v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(lds_addr));      // outside hipcc's waitcnt bookkeeping: caller waits
+    return v;
+}
+__device__ __forceinline__ uint32_t w3_lds_offset(const void* p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+
+__global__ void __launch_bounds__(512) wgrad3_kernel(const Wgrad3Args a) {
+    constexpr int BK = 64;                               // pixels per chunk
+    constexpr int PITCH = 256;                           // bytes per LDS row (128 channels)
+    constexpr int A_BYTES = BK * PITCH;                  // dy tile, 16 KB
+    constexpr int X_ROUNDS = 3, X_BYTES = X_ROUNDS * 32 * PITCH;   // x image, up to 96 rows (80 used at W = 8), 24 KB
+    constexpr int STAGE = A_BYTES + X_BYTES;             // 40 KB
+    constexpr int NSTAGE = 3;
+    constexpr int TM = 2;                                // 32-row co tiles per wave; one 32-col ci tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;             // 2 (co) x 4 (ci)
+
+    // work id: triples of one (tile, pixel range) are consecutive and consecutive ids stay on ONE XCD, so the 9 triples that
+    // re-read the same dy tile and shifted x rows hit that XCD's L2
+    int b;
+    {
+        const int nb = gridDim.x, bid = blockIdx.x;
+        const int q = nb >> 3, r = nb & 7, xcd = bid & 7;
+        b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tr = b % a.ntriples; b /= a.ntriples;
+    const int split = b % a.split_k; b /= a.split_k;
+    const int tile_n = b % a.tiles_n, tile_m = b / a.tiles_n;
+    const int co0 = tile_m * 128, ci0 = tile_n * 128;
+    const GenieTap tp = a.taps[3 * tr];
+    const int t_dt = __builtin_amdgcn_readfirstlane(tp.dt), t_dh = __builtin_amdgcn_readfirstlane(tp.dh);
+    const bool do_bias = a.dbias != nullptr && tr == 0 && tile_n == 0 && wn == 0;
+    const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page_w3);
+    const int W = a.W, WP = W + 2;
+
+    int c_begin = split * a.chunks_per_split, c_end = c_begin + a.chunks_per_split;
+    if (c_end > a.nchunks) c_end = a.nchunks;
+
+    // ---- staging state ----
+    // dy tile: 2 rounds of 32 rows; this lane's logical 16-B chunk is the same in both rounds (row & 3 is)
+    const int d_row = tid >> 4;                          // + 32 * round
+    int d_coff;                                          // element offset of (sub-pixel, channel) inside a dy pixel, or -1
+    {
+        const int lc = (tid & 15) ^ ((d_row & 3) << 2);
+        const int co = co0 + lc * 8;
+        if (co < a.Cout) {
+            const int sub = co / a.shuf_c, ch = co - sub * a.shuf_c;
+            const int r = sub % a.shuf_r, q = (sub / a.shuf_r) % a.shuf_q, p = sub / (a.shuf_r * a.shuf_q);
+            d_coff = ((p * a.Hd + q) * a.Wd + r) * a.Cd + ch;
+        } else {
+            d_coff = -1;
+        }
+    }
+    // x image: 3 rounds of 32 image rows; (hl, wp) and the channel chunk are fixed per round
+    int x_pix[X_ROUNDS];                                 // chunk-local pixel of the row's home position, or -1 (padding / unused row)
+    int x_c;                                             // first channel of this lane's chunk, or -1
+    {
+        const int lc = (tid & 15) ^ ((d_row & 3) << 2);
+        const int ci = ci0 + lc * 8;
+        x_c = (ci < a.Cs && ci < ((a.Cin + 7) & ~7)) ? ci : -1;
+#pragma unroll
+        for (int i = 0; i < X_ROUNDS; ++i) {
+            const int r = i * 32 + d_row;
+            const int hl = r / WP, wp = r - hl * WP;
+            x_pix[i] = (r < a.img_rows && wp >= 1 && wp <= W) ? hl * W + wp - 1 : -1;
+        }
+    }
+    const int tap_delta = (t_dt * a.H + t_dh) * W * a.Cs;
+
+    auto stage = [&](int chunk, int buf, bool live) {
+        char* abase = smem + buf * STAGE;
+        char* xbase = abase + A_BYTES;
+        const uint32_t mbase = (uint32_t)chunk * BK;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const uint32_t m = mbase + i * 32 + d_row;
+            const bf16_t* q = zero;
+            if (live && m < (uint32_t)a.M && d_coff >= 0) {
+                const uint32_t q1 = m >> a.log2W, wo = m & (uint32_t)(W - 1);
+                const uint32_t q2 = fd3(q1, a.dH_), ho = q1 - q2 * a.dH_.d;
+                const uint32_t n = fd3(q2, a.dT_), to = q2 - n * a.dT_.d;
+                q = a.dy + ((((n * a.Td + to * a.dmt) * a.Hd + ho * a.dmh) * a.Wd + wo * a.dmw) * a.Cd + (uint32_t)d_coff);
+            }
+            __builtin_amdgcn_global_load_lds(GLB_PTR(q), LDS_PTR(abase + (i * 8 + wave) * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < X_ROUNDS; ++i) {
+            const bf16_t* q = zero;
+            const uint32_t m = mbase + (uint32_t)x_pix[i];
+            if (live && x_pix[i] >= 0 && m < (uint32_t)a.M && x_c >= 0) {
+                const uint32_t q1 = m >> a.log2W;
+                const uint32_t q2 = fd3(q1, a.dH_), ho = q1 - q2 * a.dH_.d;
+                const uint32_t n = fd3(q2, a.dT_), to = q2 - n * a.dT_.d;
+                const int t = (int)to + t_dt, h = (int)ho + t_dh;
+                if ((unsigned)t < (unsigned)a.T && (unsigned)h < (unsigned)a.H) q = a.src + (int)(m * (uint32_t)a.Cs + (uint32_t)(tap_delta + x_c));
+            }
+            __builtin_amdgcn_global_load_lds(GLB_PTR(q), LDS_PTR(xbase + (i * 8 + wave) * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x16_t acc[3][TM];
+    f32x16_t accb[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accb[i][r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[s][i][r] = 0.f;
+    }
+
+    // ---- transposing-read addresses: lane = 16 g + 4 r + q reads k-row 8 (g >> 1) + r (+ 16 kstep, + 4 second read),
+    //      channels 16 (g & 1) + 4 q .. + 3 of the 32-wide tile ----
+    const int g16 = lane >> 4, rr = (lane >> 2) & 3, qq = lane & 3;
+    const int krow = 8 * (g16 >> 1) + rr;
+    int a_col[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a_col[i] = wm * 64 + i * 32 + 16 * (g16 & 1) + 4 * qq;
+    const int b_col = wn * 32 + 16 * (g16 & 1) + 4 * qq;
+    // x image row of chunk pixel kk (shift 0): (kk / W) * (W + 2) + kk % W;   kk = 16 ks + krow (+ 4)
+    int x_row[4][2];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            const int kk = ks * 16 + krow + 4 * h2;
+            x_row[ks][h2] = (kk >> a.log2W) * WP + (kk & (W - 1));
+        }
+    auto frag_addr = [&](int row, int col) -> uint32_t {   // byte offset inside a [rows][128 ch] image with the (row & 3) chunk swizzle
+        const int chunk = (col >> 3) ^ ((row & 3) << 2);
+        return (uint32_t)(row * PITCH + chunk * 16 + (col & 7) * 2);
+    };
+
+    bf16x8_t ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (short)0x3F80;
+
+    const uint32_t smem_base = w3_lds_offset(smem);
+    const int nch = c_end - c_begin;
+    if (nch > 0) {
+        // prologue: two stages in flight, the first one landed
+        stage(c_begin, 0, true);
+        stage(c_begin + 1, 1, nch > 1);
+        asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        int buf = 0;
+        for (int c = 0; c < nch; ++c) {
+            const int nbuf = buf >= 1 ? buf - 1 : NSTAGE - 1;            // (buf + 2) % 3
+            stage(c_begin + c + 2, nbuf, c + 2 < nch);                    // slot of chunk c - 1: every wave is past the barrier behind it
+            const uint32_t abase = smem_base + buf * STAGE;
+            const uint32_t xbase = abase + A_BYTES;
+            bf16x4_t alo[2][TM], ahi[2][TM], blo[2][3], bhi[2][3];
+            auto issue = [&](int ks, int set) {
+                const int r0 = ks * 16 + krow;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    alo[set][i] = w3_tr16(abase + frag_addr(r0, a_col[i]));
+                    ahi[set][i] = w3_tr16(abase + frag_addr(r0 + 4, a_col[i]));
+                }
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+                    blo[set][s] = w3_tr16(xbase + frag_addr(x_row[ks][0] + s, b_col));
+                    bhi[set][s] = w3_tr16(xbase + frag_addr(x_row[ks][1] + s, b_col));
+                }
+            };
+            issue(0, 0);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int set = ks & 1;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                bf16x8_t af[TM], bfr[3];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    asm volatile("" : "+v"(alo[set][i]), "+v"(ahi[set][i]));
+                    af[i] = __builtin_shufflevector(alo[set][i], ahi[set][i], 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+                    asm volatile("" : "+v"(blo[set][s]), "+v"(bhi[set][s]));
+                    bfr[s] = __builtin_shufflevector(blo[set][s], bhi[set][s], 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+                if (ks < 3) issue(ks + 1, set ^ 1);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                    for (int s = 0; s < 3; ++s) acc[s][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[s], acc[s][i], 0, 0, 0);
+                    if (do_bias) accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], ones, accb[i], 0, 0, 0);
+                }
+            }
+            // chunk c + 1 (issued one iteration ago) must have landed; the stage just issued (5 glds) stays in flight
+            asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            buf = buf == NSTAGE - 1 ? 0 : buf + 1;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+
+    // ---- epilogue: fp32 atomics; D row = cout (registers), col = cin (lane & 31) ----
+    const int khalf = lane >> 5;
+    const int ci = ci0 + wn * 32 + (lane & 31);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r16 = 0; r16 < 16; ++r16) {
+            const int co = co0 + wm * 64 + i * 32 + (r16 & 3) + 8 * (r16 >> 2) + 4 * khalf;
+            if (co >= a.Cout) continue;
+            const int sub = co / a.shuf_c, ch = co - sub * a.shuf_c;
+            const int co_nat = a.shuf_f > 1 ? ch * a.shuf_f + sub : co;
+            float* row = a.dw + co_nat * a.s_cout + (long long)(3 * tr) * a.s_tap;
+            if (ci < a.Cin) {
+#pragma unroll
+                for (int s = 0; s < 3; ++s) atomicAdd(row + s * a.s_tap + ci * a.s_cin, acc[s][i][r16]);
+            }
+            if (do_bias && (lane & 31) == 0) atomicAdd(a.dbias + co_nat, accb[i][r16]);
+        }
+    }
+}
+
+// Returns 1 when the problem is not eligible (caller falls back to the generic kernel), 0 on launch, < 0 on error.
+int genie_conv_wgrad3_try(const GenieWgradDesc* d, hipStream_t s) {
+    if (d->tri_mode <= 0) return 1;
+    if (d->st != 1 || d->sh != 1 || d->sw != 1 || d->To != d->Ts || d->Ho != d->Hs || d->Wo != d->Ws) return 1;
+    if (d->ntaps % 3 != 0 || d->ntaps < 3) return 1;
+    const int W = d->Wo;
+    if (!(W == 8 || W == 16 || W == 32 || W == 64)) return 1;
+    if (d->Cin < 64 || d->Cout < 64) return 1;
+    Wgrad3Args a;
+    a.src = (const bf16_t*)d->src; a.dy = (const bf16_t*)d->dy; a.dw = d->dw; a.dbias = d->dbias; a.taps = d->taps;
+    a.ntriples = d->ntaps / 3;
+    a.T = d->Ts; a.H = d->Hs; a.W = W; a.Cs = d->Cs; a.Cin = d->Cin;
+    a.Td = d->Td; a.Hd = d->Hd; a.Wd = d->Wd; a.Cd = d->Cd; a.Cout = d->Cout;
+    a.dmt = d->dmt; a.dmh = d->dmh; a.dmw = d->dmw;
+    const bool shuffled = d->shuf_c < d->Cout;
+    if (shuffled) {
+        if (d->shuf_c % 8 != 0 || d->Cout % d->shuf_c != 0) return 1;
+        a.shuf_c = d->shuf_c; a.shuf_q = d->shuf_q; a.shuf_r = d->shuf_r; a.shuf_f = d->Cout / d->shuf_c;
+    } else {
+        a.shuf_c = d->Cd > d->Cout ? d->Cd : d->Cout; a.shuf_q = 1; a.shuf_r = 1; a.shuf_f = 1;
+    }
+    a.s_cout = d->s_cout; a.s_tap = d->s_tap; a.s_cin = d->s_cin;
+    const long long M = (long long)d->N * d->To * d->Ho * d->Wo;
+    if (M <= 0 || M >= (1ll << 31)) return 1;
+    a.M = (int)M;
+    a.nchunks = cdiv(M, 64);
+    a.tiles_m = cdiv(d->Cout, 128);
+    a.tiles_n = cdiv((d->Cin + 7) & ~7, 128);
+    a.img_rows = (64 / W) * (W + 2);
+    a.log2W = W == 8 ? 3 : (W == 16 ? 4 : (W == 32 ? 5 : 6));
+    a.dW_ = make_fastdiv3(d->Wo); a.dH_ = make_fastdiv3(d->Ho); a.dT_ = make_fastdiv3(d->To);
+    const long long base = (long long)a.tiles_m * a.tiles_n * a.ntriples;
+    int sk = d->split_k;
+    if (sk <= 0) {
+        // one block per CU (8 waves, 120 KB LDS): a whole number of 256-block rounds, as many rounds (up to 3) as leave >= 32
+        // chunks per block -- the 196 KB of atomics per block and the pipeline fill need a long K loop to amortise
+        sk = 0;
+        for (int rounds = 3; rounds >= 1 && sk == 0; --rounds) {
+            const int cand = (int)((256ll * rounds) / base);
+            if (cand >= 1 && a.nchunks / cand >= 32) sk = cand;
+        }
+        if (sk == 0) sk = 1;
+        if (d->tri_mode == 1 && (base * sk < 200 || a.nchunks / sk < 16)) return 1;      // too little work: generic kernel (tri_mode 2 forces)
+    }
+    a.chunks_per_split = cdiv(a.nchunks, sk);
+    a.split_k = cdiv(a.nchunks, a.chunks_per_split);
+    constexpr int lds = 3 * (64 * 256 + 3 * 32 * 256);
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute((const void*)wgrad3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) {
+            genie_set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return GENIE_ERR_HIP;
+        }
+        configured = true;
+    }
+    genie_note_variant(GENIE_VARIANT_WGRAD3);
+    hipLaunchKernelGGL(wgrad3_kernel, dim3((unsigned)(base * a.split_k)), dim3(512), lds, s, a);
+    GENIE_CHECK_LAUNCH();
+    return GENIE_OK;
+}

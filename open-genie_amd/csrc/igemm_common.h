@@ -1,0 +1,150 @@
+// Shared pieces of the gather-GEMM kernels (conv_igemm.hip: generic 128-row tiles; conv_igemm3.hip: kw-triple tiles).
+#pragma once
+#include "common.h"
+#include "genie_hip.h"
+
+struct IgemmArgs {
+    const bf16_t* src;
+    const bf16_t* wgt;
+    bf16_t* dst;
+    const bf16_t* resid;
+    const float* bias;
+    const GenieTap* taps;
+    int ntaps;
+    int N, Ts, Hs, Ws, Cs;
+    int To, Ho, Wo;
+    int st, sh, sw;
+    int M, Ncols, Nstore;
+    int w_row_stride;
+    int perm_c, perm_f;
+    int Td, Hd, Wd, Cd;
+    int dmt, dmh, dmw, dot, doh, dow;
+    int shuf_c, shuf_q, shuf_r;
+    int tiles_m, tiles_n;
+    int nk;           // total K chunks
+    int act;          // 0 none, 1 silu (epilogue)
+    int split_k;      // > 1: blockIdx.y = K split; partial tiles go to ws (fp32 [split][M][ws_ld]) and a second kernel finishes
+    int chunks_per_split;
+    float* ws;
+    int ws_ld;
+};
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+// XCD-aware, bijective block -> tile id: consecutive ids land on ONE XCD (blocks are dealt round-robin to the 8 XCDs)
+__device__ __forceinline__ int xcd_tile_id(int nb, int b) {
+    const int q = nb >> 3, r = nb & 7, xcd = b & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+}
+
+// Epilogue shared by the gather-GEMM kernels.  acc[i][j] is the wave's (wm, wn) sub-tile as TM x TN 32x32 MFMA tiles
+// (row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5), col = lane & 31); BMROWS = rows of the block tile (<= blockDim.x);
+// smem: >= BMROWS ints of LDS that nobody reads any more (the caller has passed its last barrier).
+template <int BMROWS, int TM, int TN>
+__device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16_t (&acc)[TM][TN], char* smem, int m0, int n0, int wm, int wn,
+                                               int tid, int lane) {
+    const int khalf = lane >> 5;
+    // ---- epilogue: dest offset = rowoff[m] + coloff[n]; rowoff staged through LDS ----
+    int* rowoff = reinterpret_cast<int*>(smem);
+    if (tid < BMROWS) {
+        int m = m0 + tid;
+        int off = -1;
+        if (m < a.M) {
+            const int wo = m % a.Wo; m /= a.Wo;
+            const int ho = m % a.Ho; m /= a.Ho;
+            const int to = m % a.To; m /= a.To;
+            off = (int)((((unsigned)(m * a.Td + to * a.dmt + a.dot) * a.Hd + ho * a.dmh + a.doh) * a.Wd + wo * a.dmw + a.dow) * a.Cd);
+        }
+        rowoff[tid] = off;
+    }
+    __syncthreads();
+    const bool vec4 = (a.shuf_c & 3) == 0 && (a.Nstore & 3) == 0 && (a.Cd & 3) == 0;
+    if (vec4) {
+        // 4x4 transposes inside lane quads (DPP quad_perm): lane j of a quad ends up with ONE row and FOUR consecutive
+        // columns -> 8-byte stores instead of 2-byte ones (4x fewer store instructions)
+        const int jq = lane & 3;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int nq = n0 + wn * (TN * 32) + j * 32 + (lane & 28);         // first of this quad's 4 columns
+            const bool colok = nq < a.Nstore;
+            const int sub = nq / a.shuf_c, ch = nq - sub * a.shuf_c;
+            const int r_ = sub % a.shuf_r, q_ = (sub / a.shuf_r) % a.shuf_q, p_ = sub / (a.shuf_r * a.shuf_q);
+            const int coloff = ((p_ * a.Hd + q_) * a.Wd + r_) * a.Cd + ch;
+            float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+            if (a.bias && colok) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int n = nq + e;
+                    if (n < a.Ncols) bias4[e] = a.bias[a.perm_f > 1 ? (n % a.perm_c) * a.perm_f + n / a.perm_c : n];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
+                    // round 1: partner lane ^ 1 swaps the off-diagonal of each 2x2
+#pragma unroll
+                    for (int k = 0; k < 4; k += 2) {
+                        const float send = (jq & 1) ? v[k] : v[k + 1];
+                        const float recv = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0xB1, 0xF, 0xF, true));
+                        if (jq & 1) v[k] = recv; else v[k + 1] = recv;
+                    }
+                    // round 2: partner lane ^ 2
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const float send = (jq & 2) ? v[k] : v[k + 2];
+                        const float recv = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0x4E, 0xF, 0xF, true));
+                        if (jq & 2) v[k] = recv; else v[k + 2] = recv;
+                    }
+                    // now v[e] = value of row (8 g + 4 khalf + jq), column nq + e
+                    const int row = wm * (TM * 32) + i * 32 + 8 * g + 4 * khalf + jq;
+                    const int ro = rowoff[row];
+                    if (ro < 0 || !colok) continue;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += bias4[e];
+                    if (a.resid) {
+                        const u32x2_t rv = *reinterpret_cast<const u32x2_t*>(a.resid + (unsigned)ro + coloff);
+                        v[0] += __uint_as_float(rv[0] << 16); v[1] += __uint_as_float(rv[0] & 0xffff0000u);
+                        v[2] += __uint_as_float(rv[1] << 16); v[3] += __uint_as_float(rv[1] & 0xffff0000u);
+                    }
+                    if (a.act == 1) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+                    }
+                    u32x2_t ov;
+                    ov[0] = pack_bf16x2(v[0], v[1]);
+                    ov[1] = pack_bf16x2(v[2], v[3]);
+                    *reinterpret_cast<u32x2_t*>(a.dst + (unsigned)ro + coloff) = ov;
+                }
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * (TN * 32) + j * 32 + (lane & 31);
+        if (n >= a.Nstore) continue;
+        const int sub = n / a.shuf_c, ch = n - sub * a.shuf_c;
+        const int r = sub % a.shuf_r, q = (sub / a.shuf_r) % a.shuf_q, p = sub / (a.shuf_r * a.shuf_q);
+        const int coloff = ((p * a.Hd + q) * a.Wd + r) * a.Cd + ch;
+        float bias = 0.f;
+        if (a.bias && n < a.Ncols) bias = a.bias[a.perm_f > 1 ? (n % a.perm_c) * a.perm_f + n / a.perm_c : n];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r16 = 0; r16 < 16; ++r16) {
+                const int row = wm * (TM * 32) + i * 32 + (r16 & 3) + 8 * (r16 >> 2) + 4 * khalf;
+                const int ro = rowoff[row];
+                if (ro < 0) continue;
+                float v = acc[i][j][r16] + bias;
+                if (a.resid) v += bf16_to_f32(a.resid[(unsigned)ro + coloff]);
+                if (a.act == 1) v = silu_f(v);
+                a.dst[(unsigned)ro + coloff] = f32_to_bf16(v);
+            }
+        }
+    }
+}

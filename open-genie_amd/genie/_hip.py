@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('GENIE_HIP_LIB', os.path.join(os.path.dirname(_HERE), 'lib', 'libgenie_hip.so'))
 
 GENIE_F32, GENIE_BF16 = 0, 1
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class GenieTap(C.Structure):
@@ -35,7 +35,9 @@ class GenieConvDesc(C.Structure):
                 ('dmt', C.c_int32), ('dmh', C.c_int32), ('dmw', C.c_int32),
                 ('dot', C.c_int32), ('doh', C.c_int32), ('dow', C.c_int32),
                 ('shuf_c', C.c_int32), ('shuf_q', C.c_int32), ('shuf_r', C.c_int32), ('act', C.c_int32),
-                ('splitk_ws', C.c_void_p), ('splitk_ws_bytes', C.c_int64)]
+                ('splitk_ws', C.c_void_p), ('splitk_ws_bytes', C.c_int64),
+                ('tri_steps', C.c_void_p), ('n_tri_steps', C.c_int32), ('tri_bm', C.c_int32), ('tri_flags', C.c_int32),
+                ('reserved0', C.c_int32)]
 
 
 class GenieWgradDesc(C.Structure):
@@ -47,7 +49,7 @@ class GenieWgradDesc(C.Structure):
                 ('dmt', C.c_int32), ('dmh', C.c_int32), ('dmw', C.c_int32),
                 ('dot', C.c_int32), ('doh', C.c_int32), ('dow', C.c_int32),
                 ('shuf_c', C.c_int32), ('shuf_q', C.c_int32), ('shuf_r', C.c_int32),
-                ('s_cout', C.c_int64), ('s_tap', C.c_int64), ('s_cin', C.c_int64), ('split_k', C.c_int32)]
+                ('s_cout', C.c_int64), ('s_tap', C.c_int64), ('s_cin', C.c_int64), ('split_k', C.c_int32), ('tri_mode', C.c_int32)]
 
 
 _lib: Optional[C.CDLL] = None
@@ -62,6 +64,7 @@ SIGNATURES = {
     'genie_from_channels_last': (C.c_int, [_P, _I, _PL, _P, _I, _PL, _P]),
     'genie_conv_igemm': (C.c_int, [C.POINTER(GenieConvDesc), _P]),
     'genie_conv_wgrad': (C.c_int, [C.POINTER(GenieWgradDesc), _P]),
+    'genie_last_conv_variant': (C.c_int, []),
     'genie_pack_weight': (C.c_int, [_P, _P, _I, _I, _I, _L, _L, _L, _I, _I, _P]),
     'genie_cast_f32_to_bf16': (C.c_int, [_P, _P, _L, _P]),
     'genie_groupnorm_ws_floats': (C.c_int64, [_I, _I, _I]),

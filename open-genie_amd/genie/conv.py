@@ -12,6 +12,7 @@ Reference semantics:
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 from functools import lru_cache
 from typing import Optional, Tuple
@@ -57,11 +58,14 @@ class LaunchProfiler:
 PROFILER: Optional[LaunchProfiler] = None
 
 
+VARIANT_NAMES = {0: 'igemm_kernel<128,generic>', 1: 'igemm_kernel<128,smallc>', 2: 'igemm_kernel<32,generic>', 3: 'igemm_kernel<32,smallc>',
+                 4: 'igemm3_kernel<128>', 5: 'igemm3_kernel<256>', 8: 'wgrad_kernel<128,128>', 9: 'wgrad_kernel<128,32>',
+                 10: 'wgrad_kernel<32,128>', 11: 'wgrad3_kernel'}
+
+
 def _variant(kind: str, spec: 'ConvSpec', ncols: int, small_c: bool) -> str:
-    if kind == 'wgrad':
-        return 'wgrad_kernel<128,32>' if spec.cin <= 32 else ('wgrad_kernel<32,128>' if spec.cout <= 32 else 'wgrad_kernel<128,128>')
-    tile = '32' if cpitch(ncols) <= 32 else '128'
-    return f'igemm_kernel<{tile},{"smallc" if small_c else "generic"}>'
+    """Name of the kernel the last launch of this thread used (reported by the library)."""
+    return VARIANT_NAMES.get(_hip.load_library().genie_last_conv_variant(), 'unknown')
 
 
 @dataclass(frozen=True)
@@ -135,6 +139,51 @@ def _upload_taps(key, taps):
     return _tap_cache[(dev, key)]
 
 
+# kw-triple schedule (conv_igemm3.hip): GENIE_TRI = 0 choose the row tile (default), 128 / 256 force it, -1 never use it;
+# GENIE_TRI_FLAGS bit 0 = drain every barrier (debug / A-B timing)
+TRI_BM = int(os.environ.get('GENIE_TRI', '0'))
+TRI_FLAGS = int(os.environ.get('GENIE_TRI_FLAGS', '0'))
+TRI_WGRAD = int(os.environ.get('GENIE_TRI_WGRAD', '1'))          # conv_wgrad3.hip: 0 never, 1 when it pays, 2 whenever eligible
+_tri_cache = {}
+
+
+def tri_schedule(key, taps, hs: int, ws: int, cs: int):
+    """Group a tap list into (dt, dh, channel-block) steps whose three taps dw = -1, 0, +1 share one staged activation tile.
+    Returns (device int32 [n, 8], n) or None when the taps do not come as complete triples over whole 64-channel blocks."""
+    dev = torch.cuda.current_device()
+    ck = (dev, key, hs, ws, cs)
+    if ck in _tri_cache:
+        return _tri_cache[ck]
+    groups = {}
+    for (dt, dh, dw, wofs, c0, nch) in taps:
+        groups.setdefault((dt, dh, c0, nch), {})[dw] = wofs
+    rows, ok = [], True
+    for (dt, dh, c0, nch), by_dw in groups.items():
+        if sorted(by_dw) != [-1, 0, 1] or nch % 64 != 0 or c0 % 8 != 0:
+            ok = False
+            break
+        for cb in range(nch // 64):
+            rows.append([((dt * hs + dh) * ws) * cs + c0 + cb * 64, dt, dh, by_dw[-1] + cb * 64, by_dw[0] + cb * 64, by_dw[1] + cb * 64, 0, 0])
+    out = None
+    if ok and rows and len(taps) == 3 * len(groups):
+        out = (torch.tensor(rows, dtype=torch.int32).cuda(), len(rows))
+    _tri_cache[ck] = out
+    return out
+
+
+def _fwd_tap_list(spec: ConvSpec):
+    taps = []
+    kt, kh, kw = spec.kernel
+    j = 0
+    for a in range(kt):
+        for b in range(kh):
+            for c in range(kw):
+                taps.append((a * spec.dilation[0] - spec.pad_front[0], b * spec.dilation[1] - spec.pad_front[1],
+                             c * spec.dilation[2] - spec.pad_front[2], j * spec.cinp, 0, spec.cinp))
+                j += 1
+    return taps
+
+
 def fwd_taps(spec: ConvSpec):
     taps = []
     kt, kh, kw = spec.kernel
@@ -148,7 +197,7 @@ def fwd_taps(spec: ConvSpec):
     return _upload_taps(('fwd', spec), taps)
 
 
-def dgrad_taps(spec: ConvSpec, parity: Triple, hi_pitch: int):
+def dgrad_taps(spec: ConvSpec, parity: Triple, hi_pitch: int, want_list: bool = False):
     """Taps of the backward-data gather for the input positions i = a * stride + parity.
 
     Plain conv: source (dy) coordinate = a + (parity + pad - k*dil) / stride for the k that divide.
@@ -174,6 +223,8 @@ def dgrad_taps(spec: ConvSpec, parity: Triple, hi_pitch: int):
                                     sub = (p * Q + q) * R + r
                                     taps.append((d[0] * P + p, d[1] * Q + q, d[2] * R + r, j * spec.coutp + sub * cf, 0, cf))
                 j += 1
+    if want_list:
+        return taps
     return _upload_taps(('dgrad', spec, parity, hi_pitch), taps) if taps else (None, 0, 0)
 
 
@@ -273,6 +324,11 @@ def conv_forward(x: Tensor, wpack: Tensor, bias: Optional[Tensor], spec: ConvSpe
     d.act = act
     ws = _splitk_ws(x.device)
     d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), ws.numel() * 4
+    d.tri_bm, d.tri_flags = TRI_BM, TRI_FLAGS
+    if TRI_BM >= 0 and spec.stride == (1, 1, 1) and (to, ho, wo) == (t, h, w) and not d.small_c and pitch_of(x) % 64 == 0:
+        sched = tri_schedule(('fwd', spec), _fwd_tap_list(spec), h, w, pitch_of(x))
+        if sched is not None:
+            d.tri_steps, d.n_tri_steps = sched[0].data_ptr(), sched[1]
     t0 = PROFILER.begin() if PROFILER is not None else None
     _hip.check(_hip.load_library().genie_conv_igemm(C.byref(d), _hip.stream_ptr()), 'genie_conv_igemm(fwd)')
     if t0 is not None:
@@ -322,6 +378,12 @@ def conv_dgrad(dy: Tensor, wpack_bwd: Tensor, spec: ConvSpec, in_size: Triple, r
                 d.act = 0
                 ws = _splitk_ws(dy.device)
                 d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), ws.numel() * 4
+                d.tri_bm, d.tri_flags = TRI_BM, TRI_FLAGS
+                if (TRI_BM >= 0 and st == (1, 1, 1) and spec.shuffle is None and tuple(dy.shape[2:]) == (t, h, w)
+                        and pitch_of(dy) % 64 == 0):
+                    sched = tri_schedule(('dgrad', spec), dgrad_taps(spec, (0, 0, 0), pitch_of(dy), want_list=True), h, w, pitch_of(dy))
+                    if sched is not None:
+                        d.tri_steps, d.n_tri_steps = sched[0].data_ptr(), sched[1]
                 _hip.check(lib.genie_conv_igemm(C.byref(d), _hip.stream_ptr()), 'genie_conv_igemm(dgrad)')
                 first = False
     if t0 is not None:
@@ -359,6 +421,8 @@ def conv_wgrad(x: Tensor, dy: Tensor, spec: ConvSpec, dweight: Tensor, dbias: Op
         d.shuf_c, d.shuf_q, d.shuf_r = spec.cout, 1, 1
     d.s_cout, d.s_tap, d.s_cin = s[0], s[4], s[1]
     d.split_k = 0
+    d.tri_mode = TRI_WGRAD if (TRI_WGRAD and spec.stride == (1, 1, 1) and spec.kernel[2] == 3 and spec.dilation[2] == 1
+                       and spec.pad_front[2] == 1 and spec.pad_back[2] == 1 and (to, ho, wo) == (t, h, w)) else 0
     t0 = PROFILER.begin() if PROFILER is not None else None
     _hip.check(_hip.load_library().genie_conv_wgrad(C.byref(d), _hip.stream_ptr()), 'genie_conv_wgrad')
     if t0 is not None:

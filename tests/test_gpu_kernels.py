@@ -206,6 +206,75 @@ def test_conv_shuffle_forward_dgrad(G, cin, cf, fac, size):
         assert_close_bf16(dx, xr.grad, 'shuffle dgrad')
 
 
+TRI_CASES = [
+    # cin, cout, kernel, causal, size (n, t, h, w)
+    (64, 128, (3, 3, 3), False, (2, 4, 8, 8)),
+    (128, 64, (3, 3, 3), True, (1, 3, 16, 16)),
+    (64, 160, (3, 3, 3), False, (1, 2, 32, 32)),        # two column tiles, the second partial
+    (128, 128, (3, 3, 3), True, (1, 2, 2, 64)),         # one image row per 64 pixels
+    (64, 96, (3, 3, 3), False, (3, 1, 5, 8)),           # M = 120: partial row tile, odd H
+    (64, 128, (1, 3, 3), False, (1, 2, 3, 128)),        # W = 128
+    (192, 72, (3, 1, 3), True, (2, 3, 4, 16)),          # three channel blocks, kh = 1
+]
+
+
+@pytest.mark.parametrize('bm', [128, 256])
+@pytest.mark.parametrize('flags', [0, 1, 2])
+@pytest.mark.parametrize('cin,cout,kernel,causal,size', TRI_CASES)
+def test_conv_triple_kernel(G, cin, cout, kernel, causal, size, bm, flags, monkeypatch):
+    """conv_igemm3.hip (kw-triples share one staged activation tile): forward and backward-data against the oracle, both row
+    tiles, counted-wait and drain-every-barrier variants; the library must report that the triple kernel really ran."""
+    monkeypatch.setattr(G.conv, 'TRI_BM', bm)
+    monkeypatch.setattr(G.conv, 'TRI_FLAGS', flags)
+    torch.manual_seed(11)
+    n, t, h, w = size
+    x = bf16_round(torch.randn(n, cin, t, h, w))
+    wt = bf16_round(torch.randn(cout, cin, *kernel) / (cin * kernel[0] * kernel[1] * kernel[2]) ** 0.5)
+    b = torch.randn(cout)
+    xr = x.clone().requires_grad_(True)
+    if causal:
+        from oracle import genie_oracle as O
+        ref = O.causal_conv3d(xr, wt, b, stride=(1, 1, 1))
+        spec = G.conv.causal_spec(cin, cout, kernel)
+    else:
+        ref = F.conv3d(xr, wt, b, padding=tuple((k - 1) // 2 for k in kernel))
+        spec = G.conv.same_spec(cin, cout, kernel)
+    dy = bf16_round(torch.randn_like(ref))
+    ref.backward(dy)
+    wd = wt.cuda()
+    lib = G.hip.load_library()
+    want = 5 if bm == 256 and 256 % w == 0 else 4
+    out = G.conv.conv_forward(G.cl.to_cl(x.cuda()), G.conv.pack_weight_fwd(wd, spec), b.cuda(), spec)
+    assert lib.genie_last_conv_variant() == want, lib.genie_last_conv_variant()
+    assert_close_bf16(out, ref, 'triple fwd')
+    dx = G.conv.conv_dgrad(G.cl.to_cl(dy.cuda()), G.conv.pack_weight_bwd(wd, spec), spec, (t, h, w))
+    if cout % 64 == 0:
+        assert lib.genie_last_conv_variant() == want, lib.genie_last_conv_variant()
+    assert_close_bf16(dx, xr.grad, 'triple dgrad')
+
+
+def test_conv_triple_shuffle_and_residual(G, monkeypatch):
+    """The triple kernel under the depth-to-space-time store pattern (upsample conv) and with the residual add in the epilogue."""
+    from oracle import genie_oracle as O
+    monkeypatch.setattr(G.conv, 'TRI_BM', 128)
+    torch.manual_seed(12)
+    x = bf16_round(torch.randn(1, 64, 2, 4, 8))
+    wt = bf16_round(torch.randn(32 * 8, 64, 3, 3, 3) / (64 * 27) ** 0.5)
+    b = torch.randn(32 * 8)
+    ref = O.depth_to_spacetime(O.causal_conv3d(x, wt, b), 2, 2)
+    spec = G.conv.causal_spec(64, 256, (3, 3, 3), shuffle=(2, 2, 2))
+    out = G.conv.conv_forward(G.cl.to_cl(x.cuda()), G.conv.pack_weight_fwd(wt.cuda(), spec), b.cuda(), spec)
+    assert G.hip.load_library().genie_last_conv_variant() == 4
+    assert_close_bf16(out, ref, 'triple shuffle fwd')
+    r = bf16_round(torch.randn(2, 128, 3, 8, 8))
+    x2 = bf16_round(torch.randn(2, 64, 3, 8, 8))
+    w2 = bf16_round(torch.randn(128, 64, 3, 3, 3) / 42.)
+    spec2 = G.conv.same_spec(64, 128, (3, 3, 3))
+    out2 = G.conv.conv_forward(G.cl.to_cl(x2.cuda()), G.conv.pack_weight_fwd(w2.cuda(), spec2), None, spec2, resid=G.cl.to_cl(r.cuda()))
+    assert G.hip.load_library().genie_last_conv_variant() == 4
+    assert_close_bf16(out2, O.conv3d_same(x2, w2, None) + r, 'triple conv + resid')
+
+
 def test_conv_residual_epilogue(G):
     torch.manual_seed(5)
     x = bf16_round(torch.randn(2, 64, 3, 6, 6))
@@ -247,6 +316,49 @@ def test_conv_wgrad(G, cin, cout, kernel, stride, causal, size, wfmt):
     # accumulation semantics
     G.conv.conv_wgrad(G.cl.to_cl(x.cuda()), G.cl.to_cl(dy.cuda()), spec, dw, None)
     torch.testing.assert_close(dw.cpu(), 2 * wt.grad, rtol=1e-3, atol=2e-3 * scale)
+
+
+TRI_WGRAD_CASES = [
+    # cin, cout, kernel, causal, size (n, t, h, w), shuffle
+    (64, 128, (3, 3, 3), False, (2, 4, 8, 8), None),
+    (128, 128, (3, 3, 3), True, (1, 3, 16, 16), None),
+    (192, 160, (3, 3, 3), False, (1, 2, 4, 32), None),       # partial co / ci tiles
+    (64, 64, (3, 3, 3), True, (1, 2, 3, 64), None),          # one image row per chunk
+    (64, 96, (1, 3, 3), False, (1, 1, 3, 8), None),          # M = 24: a single partial chunk
+    (128, 64, (3, 1, 3), True, (3, 5, 2, 16), None),         # M = 480: last chunk partial, kh = 1
+    (64, 32 * 8, (3, 3, 3), True, (1, 2, 4, 8), (2, 2, 2)),  # upsample conv: dy is the shuffled high-resolution gradient
+    (128, 64 * 4, (3, 3, 3), True, (2, 2, 4, 16), (1, 2, 2)),
+]
+
+
+@pytest.mark.parametrize('cin,cout,kernel,causal,size,shuffle', TRI_WGRAD_CASES)
+def test_conv_wgrad_triple_kernel(G, cin, cout, kernel, causal, size, shuffle, monkeypatch):
+    """conv_wgrad3.hip (one block per kw-triple: shared dy tile and x image) against autograd of the oracle."""
+    from oracle import genie_oracle as O
+    torch.manual_seed(13)
+    n, t, h, w = size
+    x = bf16_round(torch.randn(n, cin, t, h, w))
+    wt = torch.randn(cout, cin, *kernel, requires_grad=True)
+    b = torch.randn(cout, requires_grad=True)
+    if causal:
+        ref = O.causal_conv3d(x, wt, b)
+        spec = G.conv.causal_spec(cin, cout, kernel, shuffle=shuffle)
+    else:
+        ref = F.conv3d(x, wt, b, padding=tuple((k - 1) // 2 for k in kernel))
+        spec = G.conv.same_spec(cin, cout, kernel)
+    if shuffle is not None:
+        ref = O.depth_to_spacetime(ref, shuffle[0], shuffle[1])
+    dy = bf16_round(torch.randn_like(ref))
+    ref.backward(dy)
+    dw = torch.zeros(cout, cin, *kernel, device='cuda').contiguous(memory_format=torch.channels_last_3d)
+    db = torch.zeros(cout, device='cuda')
+    monkeypatch.setattr(G.conv, 'TRI_WGRAD', 2)          # force the triple kernel whatever the problem size
+    G.conv.conv_wgrad(G.cl.to_cl(x.cuda()), G.cl.to_cl(dy.cuda()), spec, dw, db)
+    assert G.hip.load_library().genie_last_conv_variant() == 11
+    torch.testing.assert_close(dw.cpu(), wt.grad, rtol=1e-3, atol=1e-3 * wt.grad.abs().max().item())
+    torch.testing.assert_close(db.cpu(), b.grad, rtol=1e-3, atol=1e-3 * b.grad.abs().max().item())
+    G.conv.conv_wgrad(G.cl.to_cl(x.cuda()), G.cl.to_cl(dy.cuda()), spec, dw, None)      # accumulates
+    torch.testing.assert_close(dw.cpu(), 2 * wt.grad, rtol=1e-3, atol=2e-3 * wt.grad.abs().max().item())
 
 
 @pytest.mark.parametrize('cin,cf,fac,size', [(64, 32, (2, 2, 2), (1, 2, 4, 4)), (128, 64, (1, 2, 2), (2, 2, 3, 5)), (64, 256, (2, 2, 2), (1, 2, 4, 4))])
