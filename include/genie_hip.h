@@ -157,6 +157,21 @@ int genie_pack_weight(const float* src, void* dst, int R, int J, int K, int64_t 
                       int perm_c, int perm_f, void* stream);
 int genie_cast_f32_to_bf16(const float* src, void* dst, int64_t numel, void* stream);
 
+/* All transposed (backward-data) weight packs of a model in ONE launch, from the bf16 mirror of the parameter arena
+ * (genie_adamw_step_mirror): job i turns bf16 [R = cout][J = tap][K = cin] at src + src_off (the channels_last_3d layout of an
+ * nn.Conv3d weight; K % 8 == 0) into bf16 [cin][tap][roundup8(cout)] at dst + dst_off, optionally in depth-to-space column
+ * order (perm_c, perm_f as in genie_pack_weight).  tiles_r = ceil(R / 64), tiles_k = ceil(K / 64); first_block = sum over the
+ * earlier jobs of tiles_r * J * tiles_k (the table lives in device memory, ascending); total_blocks = the grand total. */
+typedef struct GeniePackJob {
+    int64_t src_off, dst_off;
+    int32_t R, J, K;
+    int32_t perm_c, perm_f;
+    int32_t tiles_r, tiles_k;
+    int32_t first_block;
+} GeniePackJob;
+int genie_pack_transpose_batched(const GeniePackJob* jobs_dev, int njobs, int total_blocks, const void* src_bf16, void* dst_bf16,
+                                 void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * GroupNorm (+ optional adaptive scale/shift, + optional SiLU), forward and backward (norm.hip).
  * replaces: nn.GroupNorm + nn.SiLU (video.py:578-579, 612-613; tokenizer.py descs 'group_norm','silu'),
@@ -208,6 +223,10 @@ int genie_mse_bwd(const void* rec_cl, int cpitch, const void* target, int target
                   void* stream);
 int genie_adamw_step(float* p, float* g, float* m, float* v, int64_t numel, float lr, float beta1, float beta2, float eps,
                      float weight_decay, int step, float grad_scale, int zero_grad, void* stream);
+/* the same, additionally writing a bf16 image of the updated parameters (p_bf16[numel]): for channels_last_3d Conv3d weights
+ * with in_channels % 8 == 0 that image IS the forward weight pack, so no per-step repacking is needed */
+int genie_adamw_step_mirror(float* p, float* g, float* m, float* v, void* p_bf16, int64_t numel, float lr, float beta1, float beta2,
+                            float eps, float weight_decay, int step, float grad_scale, int zero_grad, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Space-time transformer attention (attention.hip).

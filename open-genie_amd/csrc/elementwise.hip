@@ -314,7 +314,7 @@ extern "C" int genie_mse_bwd(const void* rec, int cpitch, const void* target, in
 __global__ void __launch_bounds__(256) adamw_kernel(float4* __restrict__ p, float4* __restrict__ g, float4* __restrict__ m,
                                                     float4* __restrict__ v, long long n4, float lr, float beta1, float beta2,
                                                     float eps, float wd, float bc1, float rsqrt_bc2, float gscale,
-                                                    int zero_grad) {
+                                                    int zero_grad, u32x2_t* __restrict__ mirror) {
     const float step = lr / bc1;
     const float decay = 1.f - lr * wd;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
@@ -331,20 +331,38 @@ __global__ void __launch_bounds__(256) adamw_kernel(float4* __restrict__ p, floa
         }
         p[i] = pp; m[i] = mm; v[i] = vv;
         if (zero_grad) g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (mirror) {                                   // bf16 image of the updated parameters (the conv kernels' weight packs)
+            u32x2_t o;
+            o[0] = pack_bf16x2(pp.x, pp.y);
+            o[1] = pack_bf16x2(pp.z, pp.w);
+            mirror[i] = o;
+        }
     }
 }
 
-extern "C" int genie_adamw_step(float* p, float* g, float* m, float* v, int64_t numel, float lr, float beta1, float beta2,
-                                float eps, float weight_decay, int step, float grad_scale, int zero_grad, void* stream) {
+static int adamw_launch(float* p, float* g, float* m, float* v, int64_t numel, float lr, float beta1, float beta2, float eps,
+                        float weight_decay, int step, float grad_scale, int zero_grad, void* mirror, void* stream) {
     GENIE_CHECK_ARG(p && g && m && v, "genie_adamw_step: null pointer");
     GENIE_CHECK_ARG(numel % 4 == 0, "genie_adamw_step: arena numel %lld must be a multiple of 4", (long long)numel);
     GENIE_CHECK_ARG(step >= 1, "genie_adamw_step: step must be >= 1");
     if (numel == 0) return GENIE_OK;
     const double bc1 = 1.0 - pow((double)beta1, (double)step);
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
-    adamw_kernel<<<ew_grid(numel / 4), 256, 0, (hipStream_t)stream>>>((float4*)p, (float4*)g, (float4*)m, (float4*)v, numel / 4, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)(1.0 / sqrt(bc2)), grad_scale, zero_grad);
+    adamw_kernel<<<ew_grid(numel / 4), 256, 0, (hipStream_t)stream>>>((float4*)p, (float4*)g, (float4*)m, (float4*)v, numel / 4, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)(1.0 / sqrt(bc2)), grad_scale, zero_grad, (u32x2_t*)mirror);
     GENIE_CHECK_LAUNCH();
     return GENIE_OK;
+}
+
+extern "C" int genie_adamw_step(float* p, float* g, float* m, float* v, int64_t numel, float lr, float beta1, float beta2,
+                                float eps, float weight_decay, int step, float grad_scale, int zero_grad, void* stream) {
+    return adamw_launch(p, g, m, v, numel, lr, beta1, beta2, eps, weight_decay, step, grad_scale, zero_grad, nullptr, stream);
+}
+
+extern "C" int genie_adamw_step_mirror(float* p, float* g, float* m, float* v, void* p_bf16, int64_t numel, float lr, float beta1,
+                                       float beta2, float eps, float weight_decay, int step, float grad_scale, int zero_grad,
+                                       void* stream) {
+    GENIE_CHECK_ARG(p_bf16, "genie_adamw_step_mirror: null mirror");
+    return adamw_launch(p, g, m, v, numel, lr, beta1, beta2, eps, weight_decay, step, grad_scale, zero_grad, p_bf16, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -404,6 +422,69 @@ extern "C" int genie_cast_f32_to_bf16(const float* src, void* dst, int64_t numel
     GENIE_CHECK_ARG(numel % 4 == 0, "genie_cast_f32_to_bf16: numel %lld must be a multiple of 4", (long long)numel);
     if (numel == 0) return GENIE_OK;
     cast_bf16_kernel<<<ew_grid(numel / 4), 256, 0, (hipStream_t)stream>>>((const float4*)src, (u32x2_t*)dst, numel / 4);
+    GENIE_CHECK_LAUNCH();
+    return GENIE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Batched transposed weight pack: for every job, bf16 [R = cout][J = tap][K = cin] (dense, the layout of a channels_last_3d
+// nn.Conv3d weight inside the bf16 parameter mirror) -> bf16 [cin][tap][Rp], Rp = roundup8(cout), zero padded, with the optional
+// depth-to-space column order (column r' holds natural row (r' % permC) * permF + r' / permC).  One launch for ALL convolutions
+// of a model: blocks are dealt to jobs through the `first_block` prefix (binary search), each block transposes a 64 x 64 tile
+// of one tap through LDS so that both the reads (64 cin = 128 B) and the writes (64 cout = 128 B) are row-contiguous.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) pack_transpose_batched_kernel(const GeniePackJob* __restrict__ jobs, int njobs,
+                                                                     const bf16_t* __restrict__ src, bf16_t* __restrict__ dst) {
+    __shared__ bf16_t tile[64][66];
+    int lo = 0, hi = njobs - 1;
+    const int bid = blockIdx.x;
+    while (lo < hi) {                                   // last job whose first_block <= bid
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].first_block <= bid) lo = mid; else hi = mid - 1;
+    }
+    const GeniePackJob jb = jobs[lo];
+    int t = bid - jb.first_block;
+    const int tk = t % jb.tiles_k; t /= jb.tiles_k;
+    const int j = t % jb.J;
+    const int tr = t / jb.J;
+    const int r0 = tr * 64, k0 = tk * 64;
+    const int Rp = (jb.R + 7) & ~7;
+    const bf16_t* s = src + jb.src_off;
+    bf16_t* d = dst + jb.dst_off;
+    const int tid = threadIdx.x;
+    // load: rows r' = r0 + 32 * pass + tid / 8 (destination column order), 8 consecutive k per thread
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int rl = pass * 32 + (tid >> 3), kc = (tid & 7) * 8;
+        const int rp = r0 + rl;
+        u32x4_t v = {0u, 0u, 0u, 0u};
+        if (rp < jb.R && k0 + kc < jb.K) {
+            const int rn = jb.perm_f > 1 ? (rp % jb.perm_c) * jb.perm_f + rp / jb.perm_c : rp;
+            v = *reinterpret_cast<const u32x4_t*>(s + ((long long)rn * jb.J + j) * jb.K + k0 + kc);
+        }
+        uint32_t* row = reinterpret_cast<uint32_t*>(&tile[rl][kc]);    // rows are 132 B: 4-byte aligned, kc even
+        row[0] = v[0]; row[1] = v[1]; row[2] = v[2]; row[3] = v[3];
+    }
+    __syncthreads();
+    // store: rows k = k0 + 32 * pass + tid / 8, 8 consecutive r' per thread
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int kl = pass * 32 + (tid >> 3), rc = (tid & 7) * 8;
+        const int k = k0 + kl;
+        if (k < jb.K && r0 + rc < Rp) {
+            u32x4_t o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (uint32_t)tile[rc + 2 * e][kl] | ((uint32_t)tile[rc + 2 * e + 1][kl] << 16);
+            *reinterpret_cast<u32x4_t*>(d + ((long long)k * jb.J + j) * Rp + r0 + rc) = o;
+        }
+    }
+}
+
+extern "C" int genie_pack_transpose_batched(const GeniePackJob* jobs_dev, int njobs, int total_blocks, const void* src_bf16,
+                                            void* dst_bf16, void* stream) {
+    GENIE_CHECK_ARG(jobs_dev && src_bf16 && dst_bf16, "genie_pack_transpose_batched: null pointer");
+    GENIE_CHECK_ARG(njobs >= 1 && total_blocks >= 1, "genie_pack_transpose_batched: empty job list");
+    pack_transpose_batched_kernel<<<total_blocks, 256, 0, (hipStream_t)stream>>>(jobs_dev, njobs, (const bf16_t*)src_bf16, (bf16_t*)dst_bf16);
     GENIE_CHECK_LAUNCH();
     return GENIE_OK;
 }

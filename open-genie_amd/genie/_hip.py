@@ -52,6 +52,11 @@ class GenieWgradDesc(C.Structure):
                 ('s_cout', C.c_int64), ('s_tap', C.c_int64), ('s_cin', C.c_int64), ('split_k', C.c_int32), ('tri_mode', C.c_int32)]
 
 
+class GeniePackJob(C.Structure):
+    _fields_ = [('src_off', C.c_int64), ('dst_off', C.c_int64), ('R', C.c_int32), ('J', C.c_int32), ('K', C.c_int32),
+                ('perm_c', C.c_int32), ('perm_f', C.c_int32), ('tiles_r', C.c_int32), ('tiles_k', C.c_int32), ('first_block', C.c_int32)]
+
+
 _lib: Optional[C.CDLL] = None
 
 # name -> (restype, argtypes); the single source for the symbol-export test as well
@@ -80,6 +85,8 @@ SIGNATURES = {
     'genie_mse_fwd': (C.c_int, [_P, _I, _P, _I, _PL, _PL, _P, _P, _P]),
     'genie_mse_bwd': (C.c_int, [_P, _I, _P, _I, _PL, _PL, _P, _P, _P]),
     'genie_adamw_step': (C.c_int, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _I, _P]),
+    'genie_adamw_step_mirror': (C.c_int, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _I, _P]),
+    'genie_pack_transpose_batched': (C.c_int, [_P, _I, _I, _P, _P, _P]),
     'genie_rotary_layernorm_fwd': (C.c_int, [_P, _P, _L, _I, _L, _P, _L, _I, _P, _P, _F, _P, _P]),
     'genie_rotary_layernorm_bwd': (C.c_int, [_P, _P, _P, _P, _L, _I, _L, _P, _L, _I, _P, _P, _P, _P, _P]),
     'genie_attention_fwd': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _PL, _PL, _PL, _F, _I, _I, _P]),

@@ -145,6 +145,7 @@ TRI_BM = int(os.environ.get('GENIE_TRI', '0'))
 TRI_FLAGS = int(os.environ.get('GENIE_TRI_FLAGS', '0'))
 TRI_WGRAD = int(os.environ.get('GENIE_TRI_WGRAD', '1'))          # conv_wgrad3.hip: 0 never, 1 when it pays, 2 whenever eligible
 _tri_cache = {}
+FORCE_SPLIT_K = 0                   # experiments only: split-K factor handed to genie_conv_wgrad (0 = library chooses)
 
 
 def tri_schedule(key, taps, hs: int, ws: int, cs: int):
@@ -420,7 +421,7 @@ def conv_wgrad(x: Tensor, dy: Tensor, spec: ConvSpec, dweight: Tensor, dbias: Op
     else:
         d.shuf_c, d.shuf_q, d.shuf_r = spec.cout, 1, 1
     d.s_cout, d.s_tap, d.s_cin = s[0], s[4], s[1]
-    d.split_k = 0
+    d.split_k = FORCE_SPLIT_K
     d.tri_mode = TRI_WGRAD if (TRI_WGRAD and spec.stride == (1, 1, 1) and spec.kernel[2] == 3 and spec.dilation[2] == 1
                        and spec.pad_front[2] == 1 and spec.pad_back[2] == 1 and (to, ho, wo) == (t, h, w)) else 0
     t0 = PROFILER.begin() if PROFILER is not None else None

@@ -70,6 +70,68 @@ class ParamArena:
                 self.slots[name] = (off, n)
                 self._plist.append(p)
         self.step_count = 0
+        self.mirror: Optional[Tensor] = None          # bf16 image of `params`, kept current by the optimiser kernel
+        self._packs = None
+
+    # ------------------------------------------------------------------------------------------------------------------
+    # bf16 weight packs without per-step repacking
+    # ------------------------------------------------------------------------------------------------------------------
+    def attach_weight_packs(self, root: nn.Module) -> int:
+        """Keep the conv kernels' bf16 weight packs current as a side effect of the optimiser step instead of re-packing
+        ~260 tensors per step: the optimiser kernel also writes a bf16 mirror of the arena -- for a channels_last_3d Conv3d
+        weight with in_channels % 8 == 0 that mirror IS the forward pack ([cout][tap][cin]) -- and ONE batched transpose
+        kernel rebuilds every backward-data pack ([cin][tap][coutp]).  Returns the number of convolutions managed; the
+        rest (stem, 18-channel latent convs, non-arena weights) keep packing themselves on demand."""
+        import ctypes as C
+
+        from .module.video import Conv3d
+        lib = _hip.load_library()
+        if self.mirror is None:
+            self.mirror = torch.empty(self.numel, dtype=torch.bfloat16, device=self.params.device)
+            _hip.check(lib.genie_cast_f32_to_bf16(self.params.data_ptr(), self.mirror.data_ptr(), self.numel, _hip.stream_ptr()),
+                       'genie_cast_f32_to_bf16')
+        by_id = {id(p): name for name, p in root.named_parameters()}
+        managed, jobs, dst_total, blocks = [], [], 0, 0
+        for m in root.modules():
+            if not isinstance(m, Conv3d):
+                continue
+            w = m.weight
+            name = by_id.get(id(w))
+            if name is None or name not in self.slots:
+                continue
+            cout, cin, kt, kh, kw = w.shape
+            nt = kt * kh * kw
+            if cin % 8 != 0 or tuple(w.stride()) != (nt * cin, 1, kh * kw * cin, kw * cin, cin):
+                continue
+            off, n = self.slots[name]
+            spec = m.spec
+            coutp = (cout + 7) & ~7
+            perm_c, perm_f = (spec.cfinal, spec.shuffle[0] * spec.shuffle[1] * spec.shuffle[2]) if spec.shuffle is not None else (0, 1)
+            tiles_r, tiles_k = (cout + 63) // 64, (cin + 63) // 64
+            jobs.append((off, dst_total, cout, nt, cin, perm_c, perm_f, tiles_r, tiles_k, blocks))
+            fwd = self.mirror[off:off + n].view(cout, nt, cin)
+            managed.append((m.op, w, fwd, dst_total, (cin, nt, coutp)))
+            dst_total += (cin * nt * coutp + 63) // 64 * 64
+            blocks += tiles_r * nt * tiles_k
+        if not managed:
+            return 0
+        arr = (_hip.GeniePackJob * len(jobs))(*[_hip.GeniePackJob(*j) for j in jobs])
+        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone()
+        bwd = torch.empty(dst_total, dtype=torch.bfloat16, device=self.params.device)
+        self._packs = {'jobs': host.to(self.params.device), 'njobs': len(jobs), 'blocks': blocks, 'bwd': bwd,
+                       'managed': [(op, w, fwd, bwd[o:o + shp[0] * shp[1] * shp[2]].view(*shp)) for op, w, fwd, o, shp in managed]}
+        self._refresh_packs()
+        return len(managed)
+
+    def _refresh_packs(self) -> None:
+        pk = self._packs
+        lib = _hip.load_library()
+        _hip.check(lib.genie_pack_transpose_batched(pk['jobs'].data_ptr(), pk['njobs'], pk['blocks'], self.mirror.data_ptr(),
+                                                    pk['bwd'].data_ptr(), _hip.stream_ptr()), 'genie_pack_transpose_batched')
+        for op, w, fwd, bwdv in pk['managed']:
+            key = (w._version, w.data_ptr())
+            op._fwd = (key, fwd)
+            op._bwd = (key, bwdv)
 
     def offset_of(self, module: nn.Module, root: nn.Module) -> Optional[int]:
         """Arena offset of the first trainable parameter of `module` (a sub-module of `root`)."""
@@ -87,12 +149,21 @@ class ParamArena:
         """torch.optim.AdamW semantics (the reference's optimiser, tokenizer.py:437-442) in ONE kernel over the arena."""
         self.step_count += 1
         lib = _hip.load_library()
-        _hip.check(lib.genie_adamw_step(self.params.data_ptr(), self.grads.data_ptr(), self.exp_avg.data_ptr(),
-                                        self.exp_avg_sq.data_ptr(), self.numel, lr, betas[0], betas[1], eps, weight_decay,
-                                        self.step_count, grad_scale, 1 if zero_grad else 0, _hip.stream_ptr()), 'genie_adamw_step')
+        if self.mirror is not None:
+            _hip.check(lib.genie_adamw_step_mirror(self.params.data_ptr(), self.grads.data_ptr(), self.exp_avg.data_ptr(),
+                                                   self.exp_avg_sq.data_ptr(), self.mirror.data_ptr(), self.numel, lr, betas[0], betas[1],
+                                                   eps, weight_decay, self.step_count, grad_scale, 1 if zero_grad else 0,
+                                                   _hip.stream_ptr()), 'genie_adamw_step_mirror')
+        else:
+            _hip.check(lib.genie_adamw_step(self.params.data_ptr(), self.grads.data_ptr(), self.exp_avg.data_ptr(),
+                                            self.exp_avg_sq.data_ptr(), self.numel, lr, betas[0], betas[1], eps, weight_decay,
+                                            self.step_count, grad_scale, 1 if zero_grad else 0, _hip.stream_ptr()), 'genie_adamw_step')
         # the kernel wrote through the arena, not through the Parameter objects: tell autograd, so that the
-        # cached bf16 weight packs (functional.ConvOp, keyed on the version counter) are rebuilt
+        # cached bf16 weight packs (functional.ConvOp, keyed on the version counter) are rebuilt ...
         torch.autograd.graph.increment_version(self._plist)
+        # ... except the ones this arena keeps current itself (attach_weight_packs)
+        if self._packs is not None:
+            self._refresh_packs()
 
 
 class DataParallel:

@@ -1,0 +1,85 @@
+"""Training runtime on the MI355X: fused AdamW over the parameter arena against torch.optim.AdamW, and the bf16 weight packs
+that ride on the optimiser kernel (mirror + one batched transpose) against per-conv packing."""
+import pytest
+import torch
+
+from util import ROOT  # noqa: F401  (puts the package on sys.path)
+
+pytestmark = pytest.mark.gpu
+
+ENC = (('causal-conv3d', {'in_channels': 3, 'out_channels': 64, 'kernel_size': 3}),
+       ('video-residual', {'in_channels': 64}),
+       ('spacetime_downsample', {'in_channels': 64, 'out_channels': 64, 'kernel_size': 3, 'time_factor': 2, 'space_factor': 2}),
+       ('video-residual', {'in_channels': 64, 'out_channels': 128}),
+       ('group_norm', {'num_groups': 8, 'num_channels': 128}), ('silu', {}),
+       ('causal-conv3d', {'in_channels': 128, 'out_channels': 10, 'kernel_size': 1}))
+DEC = (('causal-conv3d', {'in_channels': 10, 'out_channels': 128, 'kernel_size': 3}),
+       ('video-residual', {'in_channels': 128}),
+       ('adaptive_group_norm', {'dim_cond': 10, 'num_groups': 8, 'num_channels': 128, 'has_ext': True}),
+       ('depth2spacetime_upsample', {'in_channels': 128, 'kernel_size': 3, 'time_factor': 2, 'space_factor': 2}),
+       ('video-residual', {'in_channels': 128, 'out_channels': 72}),
+       ('group_norm', {'num_groups': 8, 'num_channels': 72}), ('silu', {}),
+       ('causal-conv3d', {'in_channels': 72, 'out_channels': 3, 'kernel_size': 3}))
+
+
+def _model():
+    from genie import VideoTokenizer
+    torch.manual_seed(0)
+    return VideoTokenizer(ENC, DEC, d_codebook=10, gan_loss_weight=0., perc_loss_weight=0.).cuda().train()
+
+
+def test_arena_adamw_matches_torch():
+    """genie_adamw_step over the flat arena == torch.optim.AdamW (reference tokenizer.py:437-442, config lr / weight decay) on
+    the same gradients, two steps, including the consume-and-clear of the gradient arena."""
+    from genie.trainer import ParamArena
+    m = _model()
+    arena = ParamArena(m)
+    ref_params = [torch.nn.Parameter(p.detach().clone()) for p in m.parameters()]
+    opt = torch.optim.AdamW(ref_params, lr=1e-3, weight_decay=0.01)
+    x = torch.randn(2, 3, 4, 16, 16, device='cuda')
+    for _ in range(2):
+        loss, _ = m(x)
+        loss.backward()
+        for rp, p in zip(ref_params, m.parameters()):
+            rp.grad = p.grad.detach().clone()
+        arena.adamw_step(lr=1e-3, weight_decay=0.01)
+        opt.step()
+        assert arena.grads.abs().max().item() == 0.
+        for (name, p), rp in zip(m.named_parameters(), ref_params):
+            torch.testing.assert_close(p.detach(), rp.detach(), rtol=2e-6, atol=2e-7, msg=name)
+
+
+def test_weight_packs_follow_the_optimiser():
+    """attach_weight_packs: after every optimiser step the managed forward / backward-data packs are bit-identical to what
+    per-convolution packing of the fp32 weights gives, the loss trajectory is unchanged (up to atomic-add order), and unmanaged convs still repack."""
+    from genie import conv as gconv
+    from genie.module.video import Conv3d
+    from genie.trainer import ParamArena
+    x = torch.randn(2, 3, 4, 16, 16, device='cuda')
+    losses = []
+    for attach in (False, True):
+        m = _model()
+        arena = ParamArena(m)
+        n = arena.attach_weight_packs(m) if attach else 0
+        convs = [c for c in m.modules() if isinstance(c, Conv3d)]
+        if attach:
+            assert 0 < n < len(convs)                       # stem (3 ch) and the 10-channel latent convs stay unmanaged
+        traj = []
+        for _ in range(3):
+            loss, _ = m(x)
+            loss.backward()
+            arena.adamw_step(lr=1e-3, weight_decay=0.01)
+            traj.append(loss.item())
+            if attach:
+                managed = {id(op) for op, *_ in arena._packs['managed']}
+                for c in convs:
+                    if id(c.op) not in managed:
+                        continue
+                    key = (c.weight._version, c.weight.data_ptr())
+                    assert c.op._fwd[0] == key and c.op._bwd[0] == key
+                    assert torch.equal(c.op._fwd[1].reshape(-1), gconv.pack_weight_fwd(c.weight, c.spec).reshape(-1)), c
+                    assert torch.equal(c.op._bwd[1].reshape(-1), gconv.pack_weight_bwd(c.weight, c.spec).reshape(-1)), c
+        losses.append(traj)
+    # identical packs -> identical arithmetic up to the order of the wgrad kernels' fp32 atomics
+    for a, b in zip(*losses):
+        assert abs(a - b) <= 1e-5 * abs(a), losses
