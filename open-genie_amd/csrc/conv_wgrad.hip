@@ -329,6 +329,12 @@ static int launch_wgrad(WgradArgs& a, hipStream_t s) {
         // number of 512-block rounds (a 3.01-round grid wastes a quarter of the chip on its last round).
         const int max_sk = (a.nchunks + 7) / 8;          // keep >= 8 chunks (512 pixels) per block
         sk = 1;
+        if (a.ntaps == 1) {
+            // 1x1x1 convs stream x and dy exactly once (HBM-bound): measured best at ~256 blocks in total -- every extra split
+            // adds a BM x BN fp32 tile of atomics (128->128 @16x64x64, B = 8: 0.094 ms at 1024 splits, 0.065 ms at 256)
+            const int cand = (int)(256 / base);
+            sk = cand >= 1 ? (cand < max_sk ? cand : max_sk) : 1;
+        } else
         for (int rounds = 3; rounds >= 1; --rounds) {
             const int cand = (int)((512ll * rounds) / base);
             if (cand >= 1) { sk = cand < max_sk ? cand : max_sk; break; }

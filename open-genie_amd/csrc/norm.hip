@@ -83,38 +83,37 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const bf16_t* __restrict_
     }
 }
 
-// ---- finalize, stage A: one thread per (n, channel) sums the per-block partials (coalesced over channels) ----
-__global__ void __launch_bounds__(256) gn_chan_reduce_kernel(const float* __restrict__ part, GnGeom g, double* __restrict__ chan) {
-    const int n = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= g.Cp) return;
-    double s = 0.0, q = 0.0;
-    const float* o = part + ((long long)n * g.nblk * g.Cp + c) * 2;
-    for (int blk = 0; blk < g.nblk; ++blk) {
-        s += (double)o[0];
-        q += (double)o[1];
-        o += (long long)g.Cp * 2;
-    }
-    chan[((long long)n * g.Cp + c) * 2] = s;
-    chan[((long long)n * g.Cp + c) * 2 + 1] = q;
+// ---- finalize: one 256-thread block per (n, group) sums the per-block partials of the group's channels (fixed order, fp64)
+//      and writes mean / rstd ----
+__device__ __forceinline__ double block_sum_256(double v, double* red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();                                    // red may still be read from a previous call
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
 }
 
-// ---- finalize, stage B: one 64-lane block per (n, g) ----
-__global__ void __launch_bounds__(64) gn_finalize_kernel(const double* __restrict__ chan, GnGeom g, float eps,
-                                                         float* __restrict__ mean, float* __restrict__ rstd) {
-    const int n = blockIdx.y, grp = blockIdx.x, lane = threadIdx.x;
+__global__ void __launch_bounds__(256) gn_finalize_kernel(const float* __restrict__ part, GnGeom g, float eps,
+                                                          float* __restrict__ mean, float* __restrict__ rstd) {
+    __shared__ double red[4];
+    const int n = blockIdx.y, grp = blockIdx.x, tid = threadIdx.x;
     const int cg = g.C / g.G;
+    // the group's partials: nblk rows of cg (sum, sumsq) pairs = nblk * cg pairs; thread t takes pairs t, t + 256, ... of the
+    // flattened list (independent loads, fixed order per thread)
     double s = 0.0, q = 0.0;
-    for (int i = lane; i < cg; i += 64) {
-        const int c = grp * cg + i;
-        s += chan[((long long)n * g.Cp + c) * 2];
-        q += chan[((long long)n * g.Cp + c) * 2 + 1];
+    const float* base = part + ((long long)n * g.nblk * g.Cp + (long long)grp * cg) * 2;
+    const int total = g.nblk * cg;
+#pragma unroll 4
+    for (int f = tid; f < total; f += 256) {
+        const int blk = f / cg, ci = f - blk * cg;
+        const float2 v = *reinterpret_cast<const float2*>(base + ((long long)blk * g.Cp + ci) * 2);
+        s += (double)v.x;
+        q += (double)v.y;
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        s += __shfl_xor(s, o, 64);
-        q += __shfl_xor(q, o, 64);
-    }
-    if (lane == 0) {
+    s = block_sum_256(s, red);
+    q = block_sum_256(q, red);
+    if (tid == 0) {
         const double cnt = (double)cg * (double)g.npix;
         const double m = s / cnt;
         double var = q / cnt - m * m;
@@ -184,10 +183,7 @@ extern "C" int genie_groupnorm_fwd(const void* x, void* y, int N, int64_t npix, 
     hipStream_t s = (hipStream_t)stream;
     gn_stats_kernel<<<dim3(g.nblk, N), 256, 0, s>>>((const bf16_t*)x, g, ws);
     GENIE_CHECK_LAUNCH();
-    double* chan = reinterpret_cast<double*>(ws + (long long)N * GN_MAX_BLK * cpitch * 2);
-    gn_chan_reduce_kernel<<<dim3(cdiv(cpitch, 256), N), 256, 0, s>>>(ws, g, chan);
-    GENIE_CHECK_LAUNCH();
-    gn_finalize_kernel<<<dim3(G, N), 64, 0, s>>>(chan, g, eps, mean, rstd);
+    gn_finalize_kernel<<<dim3(G, N), 256, 0, s>>>(ws, g, eps, mean, rstd);
     GENIE_CHECK_LAUNCH();
     gn_apply_kernel<<<dim3(g.nblk, N), 256, 0, s>>>((const bf16_t*)x, (bf16_t*)y, g, gamma, beta, ada_scale, ada_shift, mean, rstd, act);
     GENIE_CHECK_LAUNCH();
@@ -254,50 +250,56 @@ __global__ void __launch_bounds__(256) gn_bwd_reduce_kernel(const bf16_t* __rest
     }
 }
 
-// backward finalize, stage A: one thread per (n, channel): totals over blocks -> parameter grads, weighted totals for stage B
-__global__ void __launch_bounds__(256) gn_bwd_chan_kernel(const float* __restrict__ part, GnGeom g, const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, const float* __restrict__ ada_s,
-                                                          float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                          float* __restrict__ dada_s, float* __restrict__ dada_b, float* __restrict__ chan) {
-    const int n = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= g.C) return;
-    double s1 = 0.0, s2 = 0.0;
-    const float* o = part + ((long long)n * g.nblk * g.Cp + c) * 2;
-    for (int blk = 0; blk < g.nblk; ++blk) {
-        s1 += (double)o[0];
-        s2 += (double)o[1];
-        o += (long long)g.Cp * 2;
-    }
-    const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
-    const float as = ada_s ? ada_s[(long long)n * g.C + c] : 1.f;
-    if (dgamma) atomicAdd(dgamma + c, (float)(s2 * as));
-    if (dbeta) atomicAdd(dbeta + c, (float)(s1 * as));
-    if (dada_s) dada_s[(long long)n * g.C + c] = (float)(ga * s2 + be * s1);
-    if (dada_b) dada_b[(long long)n * g.C + c] = (float)s1;
-    chan[((long long)n * g.Cp + c) * 2] = (float)((double)(ga * as) * s1);
-    chan[((long long)n * g.Cp + c) * 2 + 1] = (float)((double)(ga * as) * s2);
-}
-
-// stage B: one 64-lane block per (n, g): group totals -> k2, k3
-__global__ void __launch_bounds__(64) gn_bwd_finalize_kernel(const float* __restrict__ chan, GnGeom g, const float* __restrict__ mean,
-                                                             const float* __restrict__ rstd, float* __restrict__ kcoef) {
-    const int n = blockIdx.y, grp = blockIdx.x, lane = threadIdx.x;
+// backward finalize: one 256-thread block per (n, group).  Thread t owns channels t, t + 256, ... of the group: totals over the
+// blocks (fixed order, fp64) -> parameter gradients, then the group totals -> k2, k3 of  dx = k1 * dz + k2 * x + k3.
+__global__ void __launch_bounds__(256) gn_bwd_finalize_kernel(const float* __restrict__ part, GnGeom g, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, const float* __restrict__ ada_s,
+                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                              float* __restrict__ dada_s, float* __restrict__ dada_b,
+                                                              float* __restrict__ kcoef) {
+    __shared__ double red[4];
+    const int n = blockIdx.y, grp = blockIdx.x, tid = threadIdx.x;
     const int cg = g.C / g.G;
+    // tpc threads share a channel (each sums a slice of the blocks), combined in a fixed order through LDS
+    __shared__ double part_s[256][2];
+    const int tpc = cg >= 256 ? 1 : (cg > 128 ? 1 : (cg > 64 ? 2 : (cg > 32 ? 4 : 8)));
+    const int cpp = 256 / tpc;                           // channels per pass
     double P1 = 0.0, P2 = 0.0;
-    for (int ci = lane; ci < cg; ci += 64) {
-        const int c = grp * cg + ci;
-        P1 += (double)chan[((long long)n * g.Cp + c) * 2];
-        P2 += (double)chan[((long long)n * g.Cp + c) * 2 + 1];
+    for (int c0 = 0; c0 < cg; c0 += cpp) {
+        const int ci = c0 + tid / tpc, sub = tid % tpc;
+        double s1 = 0.0, s2 = 0.0;
+        if (ci < cg) {
+            const float* o = part + ((long long)n * g.nblk * g.Cp + (grp * cg + ci)) * 2;
+#pragma unroll 4
+            for (int blk = sub; blk < g.nblk; blk += tpc) {
+                const float2 v = *reinterpret_cast<const float2*>(o + (long long)blk * g.Cp * 2);
+                s1 += (double)v.x;
+                s2 += (double)v.y;
+            }
+        }
+        __syncthreads();
+        part_s[tid][0] = s1; part_s[tid][1] = s2;
+        __syncthreads();
+        if (sub == 0 && ci < cg) {
+            for (int u = 1; u < tpc; ++u) { s1 += part_s[tid + u][0]; s2 += part_s[tid + u][1]; }
+            const int c = grp * cg + ci;
+            const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+            const float as = ada_s ? ada_s[(long long)n * g.C + c] : 1.f;
+            if (dgamma) atomicAdd(dgamma + c, (float)(s2 * as));
+            if (dbeta) atomicAdd(dbeta + c, (float)(s1 * as));
+            if (dada_s) dada_s[(long long)n * g.C + c] = (float)(ga * s2 + be * s1);
+            if (dada_b) dada_b[(long long)n * g.C + c] = (float)s1;
+            // same roundings as the two-kernel version: per-channel weighted totals go through fp32
+            P1 += (double)(float)((double)(ga * as) * s1);
+            P2 += (double)(float)((double)(ga * as) * s2);
+        }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        P1 += __shfl_xor(P1, o, 64);
-        P2 += __shfl_xor(P2, o, 64);
-    }
-    if (lane == 0) {
+    P1 = block_sum_256(P1, red);
+    P2 = block_sum_256(P2, red);
+    if (tid == 0) {
         const double M = (double)cg * (double)g.npix;
         const double rs = (double)rstd[n * g.G + grp], mu = (double)mean[n * g.G + grp];
-        // dx = k1 * dz + k2 * x + k3,  k1 = rstd * gam_eff (per channel)
         kcoef[(n * g.G + grp) * 2 + 0] = (float)(-rs * rs * P2 / M);
         kcoef[(n * g.G + grp) * 2 + 1] = (float)(-rs * P1 / M + rs * rs * mu * P2 / M);
     }
@@ -364,9 +366,7 @@ extern "C" int genie_groupnorm_bwd(const void* x, const void* dy, void* dx, int 
     float* kcoef = chan + (long long)N * cpitch * 4;
     gn_bwd_reduce_kernel<<<dim3(g.nblk, N), 256, 0, s>>>((const bf16_t*)x, (const bf16_t*)dy, g, gamma, beta, ada_scale, ada_shift, mean, rstd, act, ws);
     GENIE_CHECK_LAUNCH();
-    gn_bwd_chan_kernel<<<dim3(cdiv(C, 256), N), 256, 0, s>>>(ws, g, gamma, beta, ada_scale, dgamma, dbeta, dada_scale, dada_shift, chan);
-    GENIE_CHECK_LAUNCH();
-    gn_bwd_finalize_kernel<<<dim3(G, N), 64, 0, s>>>(chan, g, mean, rstd, kcoef);
+    gn_bwd_finalize_kernel<<<dim3(G, N), 256, 0, s>>>(ws, g, gamma, beta, ada_scale, mean, rstd, dgamma, dbeta, dada_scale, dada_shift, kcoef);
     GENIE_CHECK_LAUNCH();
     gn_bwd_apply_kernel<<<dim3(g.nblk, N), 256, 0, s>>>((const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, g, gamma, beta, ada_scale, ada_shift, mean, rstd, kcoef, act);
     GENIE_CHECK_LAUNCH();
