@@ -49,8 +49,12 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
     return (bf16_t)(u >> 16);
 }
 
+// two fp32 -> packed bf16x2, round-to-nearest-even: ONE v_cvt_pk_bf16_f32 on gfx950 (the bit-twiddling form above costs ~10 VALU)
+typedef __attribute__((ext_vector_type(2))) float genie_f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 genie_bf16x2_t;
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+    const genie_f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, genie_bf16x2_t));
 }
 
 __device__ __forceinline__ void unpack8(const u32x4_t v, float* f) {
