@@ -84,4 +84,4 @@ def test_weight_packs_follow_the_optimiser():
     # ulp-level noise has gone through the LFQ entropy term (slope ~4 beta = 400 at the decision boundary), hence 1e-3
     for a, b in zip(*losses):
         assert abs(a - b) <= 1e-3 * abs(a), losses
-    assert losses[0][:2] == losses[1][:2], losses
+    assert losses[0][0] == losses[1][0] and abs(losses[0][1] - losses[1][1]) <= 1e-5 * abs(losses[0][1]), losses
