@@ -22,6 +22,17 @@ static __device__ __attribute__((aligned(256))) uint32_t g_zero_page_a[64];
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 
+// ds_read_b64_tr_b16 as inline asm: hipcc treats the builtin as possibly aliasing an in-flight LDS-DMA and puts
+// s_waitcnt vmcnt(0) in front of it, which would drain the K/V prefetch every tile.  The caller waits (lgkmcnt) before use.
+__device__ __forceinline__ bf16x4_t attn_tr16(uint32_t lds_addr) {
+    bf16x4_t v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(lds_addr));
+    return v;
+}
+__device__ __forceinline__ uint32_t attn_lds_offset(const void* p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+
 // ------------------------------------------------------------------------------------------------
 // rotary + LayerNorm prologue: one wave per token, C <= 2048
 // x, u: [ntok][C] bf16 rows (row pitch = pitch elements); pos(token) = (token / pos_div) % pos_mod
@@ -210,29 +221,36 @@ struct AttnArgs {
     int kv_same;                // k == v tile (one LDS image)
 };
 
-template <int DH>
-__global__ void __launch_bounds__(256) attn_fwd_kernel(const AttnArgs a) {
+// Forward.  NW waves of 32 queries share 64-key K/V tiles that live in a ring of THREE LDS stages, DMA'd two tiles ahead
+// (counted vmcnt + raw barrier: a whole tile stays in flight across the barrier).  Softmax runs in the exp2 domain with the
+// scale folded into one FMA per score; masks are only evaluated on tiles that touch the end of the key range or the causal
+// diagonal; the running-max rescale of O is skipped (wave-uniform branch) while no lane's maximum moves; P is rounded to bf16 by
+// v_cvt_pk_bf16_f32.
+template <int DH, int NW, bool KVSAME>
+__global__ void __launch_bounds__(64 * NW) attn_fwd_kernel(const AttnArgs a) {
     constexpr int KT = 64;                       // keys per tile
     constexpr int ROWB = DH * 2;                 // bytes per LDS row
     constexpr int CPR = DH / 8;                  // 16-B chunks per row
     constexpr int TILE = KT * ROWB;
     constexpr int KS = DH / 16;                  // MFMA k-steps of the QK^T product
     constexpr int DT = DH / 32;                  // 32-row tiles of O^T
+    constexpr int SLABS = TILE / 1024;           // 1-KiB DMA pieces per tile
+    constexpr int LPW = SLABS / NW;              // pieces per wave per tile
+    constexpr int LPT = KVSAME ? LPW : 2 * LPW;  // glds per wave per stage
+    constexpr int STAGE = KVSAME ? TILE : 2 * TILE;
+    constexpr int NSTAGE = 3;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* ktile = smem;
-    char* vtile = a.kv_same ? smem : smem + TILE;
 
-    const int tid = threadIdx.x, lane = tid & 63, nw = blockDim.x >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int qtiles = (a.Sq + 32 * nw - 1) / (32 * nw);
+    const int qtiles = (a.Sq + 32 * NW - 1) / (32 * NW);
     const int seq = blockIdx.x / qtiles, qtile = blockIdx.x % qtiles, head = blockIdx.y;
-    const int q0 = qtile * (32 * nw) + wave * 32;
+    const int q0 = qtile * (32 * NW) + wave * 32;
     const int qi = q0 + (lane & 31);             // this lane's query
     const int h = lane >> 5;
     const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page_a);
 
-    // swizzle of a 16-B chunk inside an LDS row (bank-conflict-free ds_read_b128 over 32 rows)
-    auto swz = [&](int row, int chunk) -> int {
+    auto swz = [&](int row, int chunk) -> int {   // 16-B chunk inside an LDS row (bank-conflict-free ds_read_b128 over 32 rows)
         if (CPR >= 8) return chunk ^ ((row >> 1) & 7);
         if (CPR == 4) return chunk ^ ((row >> 2) & 3);
         return chunk;
@@ -257,32 +275,57 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const AttnArgs a) {
     for (int d = 0; d < DT; ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
-    float m_run = -1e30f, l_run = 0.f;
+    float m_run = -1e30f, l_run = 0.f;           // running max of the RAW scores, running sum of exp2(c * (s - m))
+    const float c2 = a.scale * 1.4426950408889634f;
 
     const long long kbase = seq_base(a.km, seq) + head * DH;
-    const int blk_q_max = qtile * (32 * nw) + 32 * nw - 1;   // causal: no key beyond the block's last query contributes
+    const int blk_q_max = qtile * (32 * NW) + 32 * NW - 1;   // causal: no key beyond the block's last query contributes
     int k_end = a.Sk;
     if (a.causal && blk_q_max + 1 < k_end) k_end = blk_q_max + 1;
+    const int ntile = (k_end + KT - 1) / KT;
 
-    for (int k0 = 0; k0 < k_end; k0 += KT) {
-        // ---- stage K (and V) tile: 64 rows x DH, DMA 16 B per lane, source-side swizzle ----
-        __syncthreads();
-        for (int slab = wave; slab < TILE / 1024; slab += nw) {
-            const int idx = slab * 64 + lane;                // 16-B unit index inside the tile
-            const int row = idx / CPR, pc = idx % CPR;
-            const int lc = swz(row, pc);
-            const int key = k0 + row;
+    // per-lane constants of the staging: this wave's pieces of a tile
+    int st_row[LPW], st_lc[LPW];
+#pragma unroll
+    for (int i = 0; i < LPW; ++i) {
+        const int idx = (wave + i * NW) * 64 + lane;         // 16-B unit index inside the tile
+        st_row[i] = idx / CPR;
+        st_lc[i] = swz(st_row[i], idx % CPR);
+    }
+    auto stage = [&](int t, int buf) {
+        char* kt_ = smem + buf * STAGE;
+        const int k0 = t * KT;
+#pragma unroll
+        for (int i = 0; i < LPW; ++i) {
+            const int slab = wave + i * NW;
+            const int key = k0 + st_row[i];
             const bf16_t* pk = zero;
             const bf16_t* pv = zero;
-            if (key < a.Sk) {
-                const long long off = kbase + (long long)key * a.km.pos_stride + lc * 8;
+            if (t < ntile && key < a.Sk) {                     // past the last tile: zero page, so every iteration issues LPT glds
+                const long long off = kbase + (long long)key * a.km.pos_stride + st_lc[i] * 8;
                 pk = a.k + off;
                 pv = a.v + off;
             }
-            __builtin_amdgcn_global_load_lds(GLB_PTR(pk), LDS_PTR(ktile + slab * 1024), 16, 0, 0);
-            if (!a.kv_same) __builtin_amdgcn_global_load_lds(GLB_PTR(pv), LDS_PTR(vtile + slab * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(pk), LDS_PTR(kt_ + slab * 1024), 16, 0, 0);
+            if (!KVSAME) __builtin_amdgcn_global_load_lds(GLB_PTR(pv), LDS_PTR(kt_ + TILE + slab * 1024), 16, 0, 0);
         }
-        __syncthreads();
+    };
+    static_assert(SLABS % NW == 0, "every wave stages the same number of pieces (counted vmcnt)");
+
+    const int g16 = lane >> 4, rr = (lane >> 2) & 3, qq = lane & 3;
+    if (ntile > 0) {
+        stage(0, 0);
+        stage(1, 1);
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LPT) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+    int buf = 0;
+    for (int t = 0; t < ntile; ++t) {
+        const int k0 = t * KT;
+        stage(t + 2, buf == 0 ? 2 : buf - 1);                // slot of tile t - 1 (every wave is past the barrier behind it)
+        const char* ktile = smem + buf * STAGE;
+        const char* vtile = KVSAME ? ktile : ktile + TILE;
 
         // ---- S^T = K Q^T for two 32-key tiles ----
         f32x16_t sacc[2];
@@ -297,67 +340,91 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const AttnArgs a) {
                 sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[kt], 0, 0, 0);
             }
         }
-        // ---- mask, online softmax (lane-local + one cross-half exchange) ----
-        float tmax = -1e30f;
+        // ---- V^T fragments: requested now (lane = 16 g + 4 r + q reads keys base + r, d columns 16 (g & 1) + 4 q .. + 3), they
+        //      land under the softmax arithmetic ----
+        bf16x4_t vlo[2][2][DT], vhi[2][2][DT];
+        {
+            const uint32_t vbase = attn_lds_offset(vtile);
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const int r0 = kt * 32 + 16 * s2 + 4 * (g16 >> 1) + rr, r1 = r0 + 8;
+#pragma unroll
+                    for (int d = 0; d < DT; ++d) {
+                        const int col = d * 32 + 16 * (g16 & 1) + 4 * qq;
+                        vlo[kt][s2][d] = attn_tr16(vbase + r0 * ROWB + (swz(r0, col >> 3) << 4) + (col & 7) * 2);
+                        vhi[kt][s2][d] = attn_tr16(vbase + r1 * ROWB + (swz(r1, col >> 3) << 4) + (col & 7) * 2);
+                    }
+                }
+        }
+        // ---- masks: only where the tile crosses the end of the keys or (causal) the diagonal of this wave's queries ----
+        const bool edge = (k0 + KT > a.Sk) || (a.causal && k0 + KT - 1 > q0);
+        if (edge) {
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = k0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (key >= a.Sk || (a.causal && key > qi)) sacc[kt][r] = -INFINITY;
+                }
+        }
+        // ---- online softmax in the exp2 domain (lane-local + one cross-half exchange) ----
+        float tmax = sacc[0][0];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = k0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                float s = sacc[kt][r] * a.scale;
-                if (key >= a.Sk || (a.causal && key > qi)) s = -INFINITY;
-                sacc[kt][r] = s;
-                tmax = fmaxf(tmax, s);
-            }
+            for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sacc[kt][r]);
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
         const float m_new = fmaxf(m_run, tmax);
-        const float alpha = __expf(m_run - m_new);
+        if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0) {          // some lane's maximum moved: rescale (exact, alpha = 1 elsewhere)
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
+            l_run *= alpha;
+#pragma unroll
+            for (int d = 0; d < DT; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+            m_run = m_new;
+        }
+        const float mc = m_run * c2;
         float psum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = __expf(sacc[kt][r] - m_new);
+                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[kt][r], c2, -mc));
                 sacc[kt][r] = p;
                 psum += p;
             }
         psum += __shfl_xor(psum, 32, 64);
-        l_run = l_run * alpha + psum;
-        m_run = m_new;
-#pragma unroll
-        for (int d = 0; d < DT; ++d)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+        l_run += psum;
 
         // ---- O^T += V^T P^T ----
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                bf16x8_t pf;
+            for (int s2 = 0; s2 < 2; ++s2) {
+                u32x4_t pw;
 #pragma unroll
-                for (int e = 0; e < 8; e += 2) {
-                    const uint32_t pk2 = pack_bf16x2(sacc[kt][8 * s + e], sacc[kt][8 * s + e + 1]);
-                    pf[e] = (short)(pk2 & 0xffff);
-                    pf[e + 1] = (short)(pk2 >> 16);
-                }
-                // V^T fragment: lane = 16 g + 4 r + q reads keys (base + r), d columns 16 (g & 1) + 4 q .. + 3
-                const int g16 = lane >> 4, rr = (lane >> 2) & 3, qq = lane & 3;
-                const int keyrow0 = kt * 32 + 16 * s + 4 * (g16 >> 1) + rr;
+                for (int e = 0; e < 4; ++e) pw[e] = pack_bf16x2(sacc[kt][8 * s2 + 2 * e], sacc[kt][8 * s2 + 2 * e + 1]);
+                const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pw);
 #pragma unroll
                 for (int d = 0; d < DT; ++d) {
-                    const int col = d * 32 + 16 * (g16 & 1) + 4 * qq;
-                    const int r0 = keyrow0, r1 = keyrow0 + 8;
-                    const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) bf16x4_t*)(vtile + r0 * ROWB + (swz(r0, col >> 3) << 4) + (col & 7) * 2));
-                    const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) bf16x4_t*)(vtile + r1 * ROWB + (swz(r1, col >> 3) << 4) + (col & 7) * 2));
-                    const bf16x8_t vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    asm volatile("" : "+v"(vlo[kt][s2][d]), "+v"(vhi[kt][s2][d]));
+                    const bf16x8_t vf = __builtin_shufflevector(vlo[kt][s2][d], vhi[kt][s2][d], 0, 1, 2, 3, 4, 5, 6, 7);
                     oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[d], 0, 0, 0);
                 }
             }
         }
+        // tile t + 1 (issued one iteration ago) must have landed; the stage issued above stays in flight
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LPT) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        buf = buf == NSTAGE - 1 ? 0 : buf + 1;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     // ---- epilogue: O / l (+ resid); lane holds, for its query, d = 32 dt + (r & 3) + 8 (r >> 2) + 4 h ----
     if (qi < a.Sq) {
@@ -387,7 +454,8 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const AttnArgs a) {
                 ov[1] = pack_bf16x2(f[2], f[3]);
                 *reinterpret_cast<u32x2_t*>(a.out + obase + dd) = ov;
             }
-        if (a.lse && h == 0) a.lse[((obase - head * DH) / a.C) * a.nhead + head] = m_run + __logf(l_run);
+        // natural-log LSE of scale * s:  m * scale + ln(l)
+        if (a.lse && h == 0) a.lse[((obase - head * DH) / a.C) * a.nhead + head] = m_run * a.scale + __logf(l_run);
     }
 }
 
@@ -410,17 +478,29 @@ extern "C" int genie_attention_fwd(const void* q, const void* k, const void* v, 
     a.nseq = nseq; a.nhead = nhead; a.Sq = Sq; a.Sk = Sk; a.scale = scale; a.causal = causal; a.kv_same = (k == v) ? 1 : 0;
     a.C = out_channels;
     GENIE_CHECK_ARG(out_channels >= nhead * d_head, "genie_attention_fwd: out_channels %d < nhead * d_head", out_channels);
+    GENIE_CHECK_ARG(scale > 0.f, "genie_attention_fwd: scale must be positive (got %g)", (double)scale);
     int nw = (Sq + 31) / 32;
-    if (nw > 4) nw = 4;
+    nw = nw >= 3 ? 4 : nw;                                        // 1, 2 or 4 waves (every wave stages the same number of pieces)
     const int qtiles = (Sq + 32 * nw - 1) / (32 * nw);
     GENIE_CHECK_ARG((long long)nseq * qtiles < (1ll << 31) && nhead <= 65535, "genie_attention_fwd: grid too large");
     const int tile = 64 * d_head * 2;
-    const int lds = a.kv_same ? tile : 2 * tile;
+    const int lds = 3 * (a.kv_same ? tile : 2 * tile);
     dim3 grid((unsigned)(nseq * qtiles), nhead, 1);
     hipStream_t s = (hipStream_t)stream;
-    if (d_head == 32) attn_fwd_kernel<32><<<grid, 64 * nw, lds, s>>>(a);
-    else if (d_head == 64) attn_fwd_kernel<64><<<grid, 64 * nw, lds, s>>>(a);
-    else attn_fwd_kernel<128><<<grid, 64 * nw, lds, s>>>(a);
+#define GENIE_ATTN_FWD(DHv, NWv)                                                                         \
+    do {                                                                                                 \
+        if (a.kv_same) attn_fwd_kernel<DHv, NWv, true><<<grid, 64 * NWv, lds, s>>>(a);                   \
+        else attn_fwd_kernel<DHv, NWv, false><<<grid, 64 * NWv, lds, s>>>(a);                            \
+    } while (0)
+#define GENIE_ATTN_FWD_NW(DHv)                                                                           \
+    do {                                                                                                 \
+        if (nw == 1) GENIE_ATTN_FWD(DHv, 1); else if (nw == 2) GENIE_ATTN_FWD(DHv, 2); else GENIE_ATTN_FWD(DHv, 4); \
+    } while (0)
+    if (d_head == 32) GENIE_ATTN_FWD_NW(32);
+    else if (d_head == 64) GENIE_ATTN_FWD_NW(64);
+    else GENIE_ATTN_FWD_NW(128);
+#undef GENIE_ATTN_FWD_NW
+#undef GENIE_ATTN_FWD
     GENIE_CHECK_LAUNCH();
     return GENIE_OK;
 }
