@@ -87,6 +87,29 @@ def cpu_baseline(budget_s: float = 150.0):
     return {'value': None, 'unit': 'video-frames/sec', 'cores': threads, 'kind': 'port', 'sample': f'did not finish within {budget_s:.0f} s'}
 
 
+def side_kernels():
+    """The other two quantities BASELINE.json's metric names, measured at kernel level with HIP events on resident synthetic inputs
+    (a few ms in total): MFMA utilisation of the space-time attention kernels on the two long-sequence shapes of SURVEY.md 8a
+    (a10), and HBM GB/s (algorithmic bytes) of the bandwidth-bound CausalConv3d / GroupNorm family."""
+    import scripts.microbench as mb
+    mb.RESULTS.clear()
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        mb.bench_attn(10, only=('lam spatial S=4096', 'yaml_tok spatial S=1024'))
+        mb.bench_hbm(10, quick=True)
+    att, hbm = {}, {}
+    for r in mb.RESULTS:
+        if r['section'] == 'attn' and 'attention' in r['name']:
+            att[r['name']] = {'ms': r['ms'], 'tflops': r['tflops'], 'mfma_frac': r['mfma_frac']}
+        elif r['section'] == 'hbm' and 'gbps' in r:
+            hbm[r['name']] = {'ms': r['ms'], 'gbps': r['gbps'], 'hbm_frac': r['hbm_frac']}
+    best = max((v['mfma_frac'] for k, v in att.items() if 'fwd' in k), default=None)
+    return {'st_attention': {'peak_tflops': BF16_MFMA_PEAK_TFLOPS, 'flop_count': 'dense 4 S^2 C per sequence forward, 2.5x that backward',
+                             'best_fwd_mfma_frac': best, 'kernels': att},
+            'hbm_kernels': {'peak_gbps': 8000.0, 'bytes': 'algorithmic (stated per entry)', 'kernels': hbm}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -191,6 +214,18 @@ def main():
             os.makedirs(os.path.dirname(args.dump) or '.', exist_ok=True)
             with open(args.dump, 'w') as f:
                 json.dump(summ, f, indent=1)
+    if world == 1 and not args.no_kernel_events:
+        out.update(side_kernels())
+    prof_summary = os.path.join(ROOT, 'profiles', 'r01_summary.json')
+    if 'roofline' in out and os.path.exists(prof_summary):
+        try:                                  # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes of this command
+            ps = json.load(open(prof_summary))
+            tr = ps.get('traffic', {}).get(out['roofline']['kernel'])
+            if tr:
+                out['roofline']['traffic'] = tr['bytes_per_launch']
+                out['roofline']['traffic_source'] = tr['source']
+        except Exception:
+            pass
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline()
     print(json.dumps(out))

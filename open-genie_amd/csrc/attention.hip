@@ -489,8 +489,9 @@ extern "C" int genie_attention_fwd(const void* q, const void* k, const void* v, 
     hipStream_t s = (hipStream_t)stream;
 #define GENIE_ATTN_FWD(DHv, NWv)                                                                         \
     do {                                                                                                 \
-        if (a.kv_same) attn_fwd_kernel<DHv, NWv, true><<<grid, 64 * NWv, lds, s>>>(a);                   \
-        else attn_fwd_kernel<DHv, NWv, false><<<grid, 64 * NWv, lds, s>>>(a);                            \
+        auto kf_ = a.kv_same ? attn_fwd_kernel<DHv, NWv, true> : attn_fwd_kernel<DHv, NWv, false>;        \
+        if (lds > 65536) GENIE_CHECK_ARG(hipFuncSetAttribute((const void*)kf_, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess, "hipFuncSetAttribute failed"); \
+        kf_<<<grid, 64 * NWv, lds, s>>>(a);                                                              \
     } while (0)
 #define GENIE_ATTN_FWD_NW(DHv)                                                                           \
     do {                                                                                                 \
@@ -553,17 +554,21 @@ struct AttnBwdArgs {
     int causal, kv_same, fuse_self;
 };
 
-template <int DH>
-__global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const AttnBwdArgs a) {
+// Both backward kernels share the forward's structure: 64-row tiles in a ring of three LDS stages DMA'd two tiles ahead with
+// counted waits, exp2-domain probabilities p = exp2(c s - lse log2 e), masks only on edge tiles, transposing LDS reads (asm)
+// requested before the element-wise phase.  The softmax scale of dS is applied ONCE to the dQ / dK accumulators at the end.
+template <int DH, int NW, bool KVSAME>
+__global__ void __launch_bounds__(64 * NW) attn_bwd_dq_kernel(const AttnBwdArgs a) {
     constexpr int KT = 64, ROWB = DH * 2, CPR = DH / 8, TILE = KT * ROWB, KS = DH / 16, DT = DH / 32;
+    constexpr int SLABS = TILE / 1024, LPW = SLABS / NW, LPT = KVSAME ? LPW : 2 * LPW;
+    constexpr int STAGE = KVSAME ? TILE : 2 * TILE;
+    static_assert(SLABS % NW == 0, "every wave stages the same number of pieces (counted vmcnt)");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* ktile = smem;
-    char* vtile = a.kv_same ? smem : smem + TILE;
-    const int tid = threadIdx.x, lane = tid & 63, nw = blockDim.x >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int qtiles = (a.Sq + 32 * nw - 1) / (32 * nw);
+    const int qtiles = (a.Sq + 32 * NW - 1) / (32 * NW);
     const int seq = blockIdx.x / qtiles, qtile = blockIdx.x % qtiles, head = blockIdx.y;
-    const int q0 = qtile * (32 * nw) + wave * 32;
+    const int q0 = qtile * (32 * NW) + wave * 32;
     const int qi = q0 + (lane & 31), h = lane >> 5;
     const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page_a);
     auto swz = [&](int row, int chunk) -> int {
@@ -572,7 +577,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const AttnBwdArgs a) {
         return chunk;
     };
     bf16x8_t qf[KS], dof[KS];
-    float lse_q = 0.f, D_q = 0.f;
+    float lse2 = 0.f, D_q = 0.f;                  // lse * log2(e)
     {
         const bool ok = qi < a.Sq;
         const long long qoff = seq_base(a.qm, seq) + (long long)(ok ? qi : 0) * a.qm.pos_stride;
@@ -589,7 +594,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const AttnBwdArgs a) {
         }
         if (ok) {
             const long long tok = ooff / a.C;
-            lse_q = a.lse[tok * a.nhead + head];
+            lse2 = a.lse[tok * a.nhead + head] * 1.4426950408889634f;
             D_q = a.D[tok * a.nhead + head];
         }
     }
@@ -598,74 +603,124 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const AttnBwdArgs a) {
     for (int d = 0; d < DT; ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dq[d][r] = 0.f;
+    const float c2 = a.scale * 1.4426950408889634f;
     const long long kbase = seq_base(a.km, seq) + head * DH;
-    const int blk_q_max = qtile * (32 * nw) + 32 * nw - 1;
+    const int blk_q_max = qtile * (32 * NW) + 32 * NW - 1;
     int k_end = a.Sk;
     if (a.causal && blk_q_max + 1 < k_end) k_end = blk_q_max + 1;
+    const int ntile = (k_end + KT - 1) / KT;
     const int g16 = lane >> 4, rr = (lane >> 2) & 3, qq = lane & 3;
 
-    for (int k0 = 0; k0 < k_end; k0 += KT) {
-        __syncthreads();
-        for (int slab = wave; slab < TILE / 1024; slab += nw) {
-            const int idx = slab * 64 + lane;
-            const int row = idx / CPR, pc = idx % CPR;
-            const int lc = swz(row, pc);
-            const int key = k0 + row;
+    int st_row[LPW], st_lc[LPW];
+#pragma unroll
+    for (int i = 0; i < LPW; ++i) {
+        const int idx = (wave + i * NW) * 64 + lane;
+        st_row[i] = idx / CPR;
+        st_lc[i] = swz(st_row[i], idx % CPR);
+    }
+    auto stage = [&](int t, int buf) {
+        char* kt_ = smem + buf * STAGE;
+        const int k0 = t * KT;
+#pragma unroll
+        for (int i = 0; i < LPW; ++i) {
+            const int slab = wave + i * NW;
+            const int key = k0 + st_row[i];
             const bf16_t* pk = zero;
             const bf16_t* pv = zero;
-            if (key < a.Sk) {
-                const long long off = kbase + (long long)key * a.km.pos_stride + lc * 8;
+            if (t < ntile && key < a.Sk) {
+                const long long off = kbase + (long long)key * a.km.pos_stride + st_lc[i] * 8;
                 pk = a.k + off;
                 pv = a.v + off;
             }
-            __builtin_amdgcn_global_load_lds(GLB_PTR(pk), LDS_PTR(ktile + slab * 1024), 16, 0, 0);
-            if (!a.kv_same) __builtin_amdgcn_global_load_lds(GLB_PTR(pv), LDS_PTR(vtile + slab * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(pk), LDS_PTR(kt_ + slab * 1024), 16, 0, 0);
+            if (!KVSAME) __builtin_amdgcn_global_load_lds(GLB_PTR(pv), LDS_PTR(kt_ + TILE + slab * 1024), 16, 0, 0);
         }
-        __syncthreads();
+    };
+
+    if (ntile > 0) {
+        stage(0, 0);
+        stage(1, 1);
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LPT) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+    int buf = 0;
+    for (int t = 0; t < ntile; ++t) {
+        const int k0 = t * KT;
+        stage(t + 2, buf == 0 ? 2 : buf - 1);
+        const char* ktile = smem + buf * STAGE;
+        const char* vtile = KVSAME ? ktile : ktile + TILE;
+        f32x16_t sacc[2], pacc[2];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
-            f32x16_t sacc, pacc;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; pacc[r] = 0.f; }
+            for (int r = 0; r < 16; ++r) { sacc[kt][r] = 0.f; pacc[kt][r] = 0.f; }
             const int row = kt * 32 + (lane & 31);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const int off = row * ROWB + (swz(row, ks * 2 + h) << 4);
                 const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(ktile + off);
-                const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(vtile + off);
-                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc, 0, 0, 0);      // S^T
-                pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks], pacc, 0, 0, 0);     // dP^T
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = k0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const bool dead = key >= a.Sk || (a.causal && key > qi) || qi >= a.Sq;
-                const float p = dead ? 0.f : __expf(sacc[r] * a.scale - lse_q);
-                sacc[r] = p * (pacc[r] - D_q) * a.scale;                                         // dS^T
-            }
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                bf16x8_t df;
-#pragma unroll
-                for (int e = 0; e < 8; e += 2) {
-                    const uint32_t pk2 = pack_bf16x2(sacc[8 * s + e], sacc[8 * s + e + 1]);
-                    df[e] = (short)(pk2 & 0xffff);
-                    df[e + 1] = (short)(pk2 >> 16);
-                }
-                const int r0 = kt * 32 + 16 * s + 4 * (g16 >> 1) + rr, r1 = r0 + 8;
-#pragma unroll
-                for (int d = 0; d < DT; ++d) {
-                    const int col = d * 32 + 16 * (g16 & 1) + 4 * qq;
-                    const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) bf16x4_t*)(ktile + r0 * ROWB + (swz(r0, col >> 3) << 4) + (col & 7) * 2));
-                    const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) bf16x4_t*)(ktile + r1 * ROWB + (swz(r1, col >> 3) << 4) + (col & 7) * 2));
-                    const bf16x8_t kT = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                    dq[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kT, df, dq[d], 0, 0, 0);       // dQ^T += K^T dS^T
+                sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[kt], 0, 0, 0);      // S^T
+                if (KVSAME) {
+                    pacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, dof[ks], pacc[kt], 0, 0, 0); // dP^T (V == K)
+                } else {
+                    const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(vtile + off);
+                    pacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks], pacc[kt], 0, 0, 0);
                 }
             }
         }
+        // K^T fragments for dQ^T += K^T dS^T, requested before the element-wise phase
+        bf16x4_t klo[2][2][DT], khi[2][2][DT];
+        {
+            const uint32_t kb = attn_lds_offset(ktile);
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const int r0 = kt * 32 + 16 * s2 + 4 * (g16 >> 1) + rr, r1 = r0 + 8;
+#pragma unroll
+                    for (int d = 0; d < DT; ++d) {
+                        const int col = d * 32 + 16 * (g16 & 1) + 4 * qq;
+                        klo[kt][s2][d] = attn_tr16(kb + r0 * ROWB + (swz(r0, col >> 3) << 4) + (col & 7) * 2);
+                        khi[kt][s2][d] = attn_tr16(kb + r1 * ROWB + (swz(r1, col >> 3) << 4) + (col & 7) * 2);
+                    }
+                }
+        }
+        const bool edge = (k0 + KT > a.Sk) || (a.causal && k0 + KT - 1 > q0) || (q0 + 32 > a.Sq);
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[kt][r], c2, -lse2));
+                if (edge) {
+                    const int key = k0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (key >= a.Sk || (a.causal && key > qi) || qi >= a.Sq) p = 0.f;
+                }
+                sacc[kt][r] = p * (pacc[kt][r] - D_q);                                                  // dS^T / scale
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                u32x4_t dw;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dw[e] = pack_bf16x2(sacc[kt][8 * s2 + 2 * e], sacc[kt][8 * s2 + 2 * e + 1]);
+                const bf16x8_t df = __builtin_bit_cast(bf16x8_t, dw);
+#pragma unroll
+                for (int d = 0; d < DT; ++d) {
+                    asm volatile("" : "+v"(klo[kt][s2][d]), "+v"(khi[kt][s2][d]));
+                    const bf16x8_t kT = __builtin_shufflevector(klo[kt][s2][d], khi[kt][s2][d], 0, 1, 2, 3, 4, 5, 6, 7);
+                    dq[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kT, df, dq[d], 0, 0, 0);           // dQ^T += K^T dS^T
+                }
+            }
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LPT) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        buf = buf == 2 ? 0 : buf + 1;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (qi < a.Sq) {
         const long long obase = seq_base(a.qm, seq) + (long long)qi * a.qm.pos_stride + head * DH;
 #pragma unroll
@@ -673,26 +728,25 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const AttnBwdArgs a) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 u32x2_t ov;
-                ov[0] = pack_bf16x2(dq[d][4 * g], dq[d][4 * g + 1]);
-                ov[1] = pack_bf16x2(dq[d][4 * g + 2], dq[d][4 * g + 3]);
+                ov[0] = pack_bf16x2(dq[d][4 * g] * a.scale, dq[d][4 * g + 1] * a.scale);
+                ov[1] = pack_bf16x2(dq[d][4 * g + 2] * a.scale, dq[d][4 * g + 3] * a.scale);
                 *reinterpret_cast<u32x2_t*>(a.dq + obase + d * 32 + 8 * g + 4 * h) = ov;
             }
     }
 }
 
-template <int DH>
-__global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const AttnBwdArgs a) {
+template <int DH, int NW>
+__global__ void __launch_bounds__(64 * NW) attn_bwd_dkv_kernel(const AttnBwdArgs a) {
     constexpr int QT = 64, ROWB = DH * 2, CPR = DH / 8, TILE = QT * ROWB, KS = DH / 16, DT = DH / 32;
+    constexpr int SLABS = TILE / 1024, LPW = SLABS / NW, LPT = 2 * LPW + 2;
+    constexpr int STAGE = 2 * TILE + 512;            // Q tile | dO tile | lse log2e [64] | D [64]
+    static_assert(SLABS % NW == 0, "every wave stages the same number of pieces (counted vmcnt)");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* qtile_l = smem;
-    char* dotile = smem + TILE;
-    float* lse_l = reinterpret_cast<float*>(smem + 2 * TILE);
-    float* D_l = lse_l + QT;
-    const int tid = threadIdx.x, lane = tid & 63, nw = blockDim.x >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ktiles = (a.Sk + 32 * nw - 1) / (32 * nw);
+    const int ktiles = (a.Sk + 32 * NW - 1) / (32 * NW);
     const int seq = blockIdx.x / ktiles, ktile_i = blockIdx.x % ktiles, head = blockIdx.y;
-    const int key0 = ktile_i * (32 * nw) + wave * 32;
+    const int key0 = ktile_i * (32 * NW) + wave * 32;
     const int ki = key0 + (lane & 31), h = lane >> 5;
     const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page_a);
     auto swz = [&](int row, int chunk) -> int {
@@ -720,42 +774,88 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const AttnBwdArgs a) 
     for (int d = 0; d < DT; ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dk[d][r] = 0.f; dv[d][r] = 0.f; }
+    const float c2 = a.scale * 1.4426950408889634f;
     const long long qbase = seq_base(a.qm, seq) + head * DH;
     const long long obase_s = seq_base(a.om, seq) + head * DH;
-    const int blk_key_min = ktile_i * (32 * nw);
+    const long long otok_s = seq_base(a.om, seq);
+    const int blk_key_min = ktile_i * (32 * NW);
     const int q_begin = a.causal ? (blk_key_min / QT) * QT : 0;      // queries before the first key of the block see none of its keys
+    const int ntile = a.Sq > q_begin ? (a.Sq - q_begin + QT - 1) / QT : 0;
     const int g16 = lane >> 4, rr = (lane >> 2) & 3, qq = lane & 3;
 
-    for (int qs = q_begin; qs < a.Sq; qs += QT) {
-        __syncthreads();
-        for (int slab = wave; slab < TILE / 1024; slab += nw) {
-            const int idx = slab * 64 + lane;
-            const int row = idx / CPR, pc = idx % CPR;
-            const int lc = swz(row, pc);
-            const int qrow = qs + row;
+    int st_row[LPW], st_lc[LPW];
+#pragma unroll
+    for (int i = 0; i < LPW; ++i) {
+        const int idx = (wave + i * NW) * 64 + lane;
+        st_row[i] = idx / CPR;
+        st_lc[i] = swz(st_row[i], idx % CPR);
+    }
+    auto stage = [&](int t, int buf) {
+        char* qt_ = smem + buf * STAGE;
+        const int qs = q_begin + t * QT;
+#pragma unroll
+        for (int i = 0; i < LPW; ++i) {
+            const int slab = wave + i * NW;
+            const int qrow = qs + st_row[i];
             const bf16_t* pq = zero;
             const bf16_t* pd = zero;
-            if (qrow < a.Sq) {
-                pq = a.q + qbase + (long long)qrow * a.qm.pos_stride + lc * 8;
-                pd = a.dO + obase_s + (long long)qrow * a.om.pos_stride + lc * 8;
+            if (t < ntile && qrow < a.Sq) {
+                pq = a.q + qbase + (long long)qrow * a.qm.pos_stride + st_lc[i] * 8;
+                pd = a.dO + obase_s + (long long)qrow * a.om.pos_stride + st_lc[i] * 8;
             }
-            __builtin_amdgcn_global_load_lds(GLB_PTR(pq), LDS_PTR(qtile_l + slab * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(GLB_PTR(pd), LDS_PTR(dotile + slab * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(pq), LDS_PTR(qt_ + slab * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(pd), LDS_PTR(qt_ + TILE + slab * 1024), 16, 0, 0);
         }
-        if (tid < QT) {
-            const int qrow = qs + tid;
-            float l = 0.f, dd = 0.f;
-            if (qrow < a.Sq) {
-                const long long tok = (seq_base(a.om, seq) + (long long)qrow * a.om.pos_stride) / a.C;
-                l = a.lse[tok * a.nhead + head];
-                dd = a.D[tok * a.nhead + head];
+        // lse / D of the tile's 64 queries: 4 B per lane, every wave writes the same 256 B (same data)
+        {
+            const int qrow = qs + lane;
+            const float* pl = reinterpret_cast<const float*>(zero);
+            const float* pd = reinterpret_cast<const float*>(zero);
+            if (t < ntile && qrow < a.Sq) {
+                const long long tok = (otok_s + (long long)qrow * a.om.pos_stride) / a.C;
+                pl = a.lse + tok * a.nhead + head;
+                pd = a.D + tok * a.nhead + head;
             }
-            lse_l[tid] = l; D_l[tid] = dd;
+            __builtin_amdgcn_global_load_lds(GLB_PTR(pl), LDS_PTR(qt_ + 2 * TILE), 4, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(pd), LDS_PTR(qt_ + 2 * TILE + 256), 4, 0, 0);
         }
-        __syncthreads();
+    };
+
+    if (ntile > 0) {
+        stage(0, 0);
+        stage(1, 1);
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LPT) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+    int buf = 0;
+    for (int t = 0; t < ntile; ++t) {
+        const int qs = q_begin + t * QT;
+        stage(t + 2, buf == 0 ? 2 : buf - 1);
+        const char* qtile_l = smem + buf * STAGE;
+        const char* dotile = qtile_l + TILE;
+        const float* lse_l = reinterpret_cast<const float*>(qtile_l + 2 * TILE);
+        const float* D_l = lse_l + 64;
+        const bool edge = (qs + QT > a.Sq) || (key0 + 32 > a.Sk) || (a.causal && key0 + 31 > qs);
+        const uint32_t qb = attn_lds_offset(qtile_l), db = attn_lds_offset(dotile);
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
-            f32x16_t sacc, pacc;
+            // dO^T / Q^T fragments of this 32-query half for dV^T += dO^T P and dK^T += Q^T dS, requested first: they land
+            // under the S / dP products and the element-wise phase
+            bf16x4_t dlo[2][DT], dhi[2][DT], qlo[2][DT], qhi[2][DT];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int r0 = qt * 32 + 16 * s2 + 4 * (g16 >> 1) + rr, r1 = r0 + 8;
+#pragma unroll
+                for (int d = 0; d < DT; ++d) {
+                    const int col = d * 32 + 16 * (g16 & 1) + 4 * qq;
+                    const uint32_t o0 = r0 * ROWB + (swz(r0, col >> 3) << 4) + (col & 7) * 2;
+                    const uint32_t o1 = r1 * ROWB + (swz(r1, col >> 3) << 4) + (col & 7) * 2;
+                    dlo[s2][d] = attn_tr16(db + o0); dhi[s2][d] = attn_tr16(db + o1);
+                    qlo[s2][d] = attn_tr16(qb + o0); qhi[s2][d] = attn_tr16(qb + o1);
+                }
+            }
+            f32x16_t sacc, pacc, ds;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; pacc[r] = 0.f; }
             const int row = qt * 32 + (lane & 31);
@@ -764,47 +864,53 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const AttnBwdArgs a) 
                 const int off = row * ROWB + (swz(row, ks * 2 + h) << 4);
                 const bf16x8_t qfr = *reinterpret_cast<const bf16x8_t*>(qtile_l + off);
                 const bf16x8_t dofr = *reinterpret_cast<const bf16x8_t*>(dotile + off);
-                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr, kf[ks], sacc, 0, 0, 0);       // S[q][key]
-                pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dofr, vf[ks], pacc, 0, 0, 0);      // dP[q][key]
-            }
-            f32x16_t ds;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ql = qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const int qg = qs + ql;
-                const bool dead = qg >= a.Sq || ki >= a.Sk || (a.causal && ki > qg);
-                const float p = dead ? 0.f : __expf(sacc[r] * a.scale - lse_l[ql]);
-                sacc[r] = p;
-                ds[r] = p * (pacc[r] - D_l[ql]) * a.scale;
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr, kf[ks], sacc, 0, 0, 0);            // S[q][key]
+                pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dofr, vf[ks], pacc, 0, 0, 0);           // dP[q][key]
             }
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                bf16x8_t pf, df;
+            for (int g = 0; g < 4; ++g) {
+                const int ql0 = qt * 32 + 8 * g + 4 * h;                                               // rows 4 g .. 4 g + 3 of this lane
+                const f32x4_t l4 = *reinterpret_cast<const f32x4_t*>(lse_l + ql0);
+                const f32x4_t d4 = *reinterpret_cast<const f32x4_t*>(D_l + ql0);
 #pragma unroll
-                for (int e = 0; e < 8; e += 2) {
-                    const uint32_t a2 = pack_bf16x2(sacc[8 * s + e], sacc[8 * s + e + 1]);
-                    const uint32_t b2 = pack_bf16x2(ds[8 * s + e], ds[8 * s + e + 1]);
-                    pf[e] = (short)(a2 & 0xffff); pf[e + 1] = (short)(a2 >> 16);
-                    df[e] = (short)(b2 & 0xffff); df[e + 1] = (short)(b2 >> 16);
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * g + e;
+                    float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[r], c2, -l4[e] * 1.4426950408889634f));
+                    if (edge) {
+                        const int qg = qs + ql0 + e;
+                        if (qg >= a.Sq || ki >= a.Sk || (a.causal && ki > qg)) p = 0.f;
+                    }
+                    sacc[r] = p;
+                    ds[r] = p * (pacc[r] - d4[e]);                                                      // dS / scale
                 }
-                const int r0 = qt * 32 + 16 * s + 4 * (g16 >> 1) + rr, r1 = r0 + 8;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                u32x4_t pw, dw;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    pw[e] = pack_bf16x2(sacc[8 * s2 + 2 * e], sacc[8 * s2 + 2 * e + 1]);
+                    dw[e] = pack_bf16x2(ds[8 * s2 + 2 * e], ds[8 * s2 + 2 * e + 1]);
+                }
+                const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pw), df = __builtin_bit_cast(bf16x8_t, dw);
 #pragma unroll
                 for (int d = 0; d < DT; ++d) {
-                    const int col = d * 32 + 16 * (g16 & 1) + 4 * qq;
-                    const int o0 = r0 * ROWB + (swz(r0, col >> 3) << 4) + (col & 7) * 2;
-                    const int o1 = r1 * ROWB + (swz(r1, col >> 3) << 4) + (col & 7) * 2;
-                    const bf16x4_t dlo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4_t*)(dotile + o0));
-                    const bf16x4_t dhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4_t*)(dotile + o1));
-                    const bf16x4_t qlo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4_t*)(qtile_l + o0));
-                    const bf16x4_t qhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4_t*)(qtile_l + o1));
-                    const bf16x8_t doT = __builtin_shufflevector(dlo, dhi, 0, 1, 2, 3, 4, 5, 6, 7);
-                    const bf16x8_t qT = __builtin_shufflevector(qlo, qhi, 0, 1, 2, 3, 4, 5, 6, 7);
-                    dv[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(doT, pf, dv[d], 0, 0, 0);       // dV^T += dO^T P
-                    dk[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qT, df, dk[d], 0, 0, 0);        // dK^T += Q^T dS
+                    asm volatile("" : "+v"(dlo[s2][d]), "+v"(dhi[s2][d]), "+v"(qlo[s2][d]), "+v"(qhi[s2][d]));
+                    const bf16x8_t doT = __builtin_shufflevector(dlo[s2][d], dhi[s2][d], 0, 1, 2, 3, 4, 5, 6, 7);
+                    const bf16x8_t qT = __builtin_shufflevector(qlo[s2][d], qhi[s2][d], 0, 1, 2, 3, 4, 5, 6, 7);
+                    dv[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(doT, pf, dv[d], 0, 0, 0);           // dV^T += dO^T P
+                    dk[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qT, df, dk[d], 0, 0, 0);            // dK^T += Q^T dS
                 }
             }
         }
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LPT) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        buf = buf == 2 ? 0 : buf + 1;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (ki < a.Sk) {
         const long long kb = seq_base(a.dkm, seq) + (long long)ki * a.dkm.pos_stride + head * DH;
 #pragma unroll
@@ -814,7 +920,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const AttnBwdArgs a) 
                 const long long o = kb + d * 32 + 8 * g + 4 * h;
                 float fk[4], fv[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { fk[e] = dk[d][4 * g + e]; fv[e] = dv[d][4 * g + e]; }
+                for (int e = 0; e < 4; ++e) { fk[e] = dk[d][4 * g + e] * a.scale; fv[e] = dv[d][4 * g + e]; }
                 if (a.fuse_self) {
                     const u32x2_t rv = *reinterpret_cast<const u32x2_t*>(a.dq_in + o);
                     fk[0] += fv[0] + __uint_as_float(rv[0] << 16); fk[1] += fv[1] + __uint_as_float(rv[0] & 0xffff0000u);
@@ -854,16 +960,37 @@ extern "C" int genie_attention_bwd(const void* q, const void* k, const void* v, 
     else if (d_head == 64) attn_bwd_prep_kernel<64><<<pblocks, 256, 0, s>>>((const bf16_t*)dO, (const bf16_t*)out, (const bf16_t*)resid, D_ws, out_tokens, out_channels, nhead);
     else attn_bwd_prep_kernel<128><<<pblocks, 256, 0, s>>>((const bf16_t*)dO, (const bf16_t*)out, (const bf16_t*)resid, D_ws, out_tokens, out_channels, nhead);
     GENIE_CHECK_LAUNCH();
-    int nwq = (Sq + 31) / 32; if (nwq > 4) nwq = 4;
-    int nwk = (Sk + 31) / 32; if (nwk > 4) nwk = 4;
+    GENIE_CHECK_ARG(scale > 0.f, "genie_attention_bwd: scale must be positive (got %g)", (double)scale);
+    int nwq = (Sq + 31) / 32; nwq = nwq >= 3 ? 4 : nwq;
+    int nwk = (Sk + 31) / 32; nwk = nwk >= 3 ? 4 : nwk;
     const int qtiles = (Sq + 32 * nwq - 1) / (32 * nwq), ktiles = (Sk + 32 * nwk - 1) / (32 * nwk);
     const int tile = 64 * d_head * 2;
-    const int lds_q = a.kv_same ? tile : 2 * tile;
-    const int lds_k = 2 * tile + 2 * 64 * 4;
+    const int lds_q = 3 * (a.kv_same ? tile : 2 * tile);
+    const int lds_k = 3 * (2 * tile + 512);
     dim3 gq((unsigned)(nseq * qtiles), nhead), gk((unsigned)(nseq * ktiles), nhead);
-    if (d_head == 32) { attn_bwd_dq_kernel<32><<<gq, 64 * nwq, lds_q, s>>>(a); attn_bwd_dkv_kernel<32><<<gk, 64 * nwk, lds_k, s>>>(a); }
-    else if (d_head == 64) { attn_bwd_dq_kernel<64><<<gq, 64 * nwq, lds_q, s>>>(a); attn_bwd_dkv_kernel<64><<<gk, 64 * nwk, lds_k, s>>>(a); }
-    else { attn_bwd_dq_kernel<128><<<gq, 64 * nwq, lds_q, s>>>(a); attn_bwd_dkv_kernel<128><<<gk, 64 * nwk, lds_k, s>>>(a); }
+#define GENIE_ATTN_DQ(DHv, NWv)                                                                          \
+    do {                                                                                                 \
+        auto kq = a.kv_same ? attn_bwd_dq_kernel<DHv, NWv, true> : attn_bwd_dq_kernel<DHv, NWv, false>;  \
+        if (lds_q > 65536) GENIE_CHECK_ARG(hipFuncSetAttribute((const void*)kq, hipFuncAttributeMaxDynamicSharedMemorySize, lds_q) == hipSuccess, "hipFuncSetAttribute failed"); \
+        kq<<<gq, 64 * NWv, lds_q, s>>>(a);                                                               \
+    } while (0)
+#define GENIE_ATTN_DKV(DHv, NWv)                                                                         \
+    do {                                                                                                 \
+        auto kk = attn_bwd_dkv_kernel<DHv, NWv>;                                                         \
+        if (lds_k > 65536) GENIE_CHECK_ARG(hipFuncSetAttribute((const void*)kk, hipFuncAttributeMaxDynamicSharedMemorySize, lds_k) == hipSuccess, "hipFuncSetAttribute failed"); \
+        kk<<<gk, 64 * NWv, lds_k, s>>>(a);                                                               \
+    } while (0)
+#define GENIE_ATTN_BWD_DH(DHv)                                                                           \
+    do {                                                                                                 \
+        if (nwq == 1) GENIE_ATTN_DQ(DHv, 1); else if (nwq == 2) GENIE_ATTN_DQ(DHv, 2); else GENIE_ATTN_DQ(DHv, 4);      \
+        if (nwk == 1) GENIE_ATTN_DKV(DHv, 1); else if (nwk == 2) GENIE_ATTN_DKV(DHv, 2); else GENIE_ATTN_DKV(DHv, 4);   \
+    } while (0)
+    if (d_head == 32) GENIE_ATTN_BWD_DH(32);
+    else if (d_head == 64) GENIE_ATTN_BWD_DH(64);
+    else GENIE_ATTN_BWD_DH(128);
+#undef GENIE_ATTN_BWD_DH
+#undef GENIE_ATTN_DKV
+#undef GENIE_ATTN_DQ
     GENIE_CHECK_LAUNCH();
     return GENIE_OK;
 }

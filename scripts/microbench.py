@@ -70,7 +70,7 @@ def rand_cl(n, c, t, h, w, scale=1.0):
 
 
 # ------------------------------------------------------------------------------------------------
-def bench_attn(iters):
+def bench_attn(iters, only=None):
     lib = _hip.load_library()
     P = _hip.ptr
     cases = [
@@ -85,6 +85,8 @@ def bench_attn(iters):
         ('lam temporal T=16 C=256', 1, 16, 64, 64, 4, 64, 'time'),
     ]
     for name, b, t, h, w, nh, dh, mode in cases:
+        if only is not None and not any(o in name for o in only):
+            continue
         c = nh * dh
         hw, ntok = h * w, b * t * h * w
         x = rand_cl(b, c, t, h, w)
@@ -130,11 +132,11 @@ def bench_attn(iters):
 
 
 # ------------------------------------------------------------------------------------------------
-def bench_hbm(iters):
+def bench_hbm(iters, quick=False):
     lib = _hip.load_library()
     P = _hip.ptr
     B = 8
-    for (c, t, h, w, g) in [(128, 16, 64, 64, 1), (256, 16, 32, 32, 1), (512, 4, 8, 8, 1), (128, 16, 64, 64, 8)]:
+    for (c, t, h, w, g) in ([(128, 16, 64, 64, 1)] if quick else [(128, 16, 64, 64, 1), (256, 16, 32, 32, 1), (512, 4, 8, 8, 1), (128, 16, 64, 64, 8)]):
         x = rand_cl(B, c, t, h, w)
         gamma = torch.ones(c, device='cuda', requires_grad=True); beta = torch.zeros(c, device='cuda', requires_grad=True)
         nbytes = B * c * t * h * w * 2
@@ -164,6 +166,8 @@ def bench_hbm(iters):
                bytes_=npx * (8 + 128) * 2)
         report('hbm', f'head CausalConv3d 128->3 k3 B={B} fwd', timeit(lambda: head(feat), iters), flops=2.0 * npx * 128 * 3 * 27,
                bytes_=npx * (8 + 128) * 2)
+    if quick:
+        return
     # layout conversion + mse
     v32 = torch.randn(B, 3, 16, 64, 64, device='cuda')
     report('hbm', f'to_channels_last fp32->bf16 3ch B={B}', timeit(lambda: to_cl(v32), iters), bytes_=npx * (12 + 16))

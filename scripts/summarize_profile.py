@@ -40,8 +40,31 @@ for sub, counter in (('fetch', 'FETCH_SIZE'), ('write', 'WRITE_SIZE')):
         name = r['Kernel_Name'][:100]
         agg[name][0] += 1
         agg[name][1] += float(r['Counter_Value'])
-    top = sorted(agg.items(), key=lambda kv: -kv[1][1])[:12]
-    summary[counter] = [{'kernel': k, 'dispatches': v[0], 'sum': v[1], 'per_dispatch': v[1] / max(v[0], 1)} for k, v in top]
+    ranked = sorted(agg.items(), key=lambda kv: -kv[1][1])
+    rows = [{'kernel': k, 'dispatches': v[0], 'sum': v[1], 'per_dispatch': v[1] / max(v[0], 1)} for k, v in ranked]
+    summary[counter] = rows[:12]
+    summary[counter + '_all'] = rows
+
+# HBM traffic per launch of the conv kernels, keyed by the names bench.py reports.  Units and corrections as
+# /opt/skills/guides/MI355X_MICROARCH.md (HBM section) prescribes for gfx950: the counters are in KB; FETCH_SIZE reports half of
+# the bytes of 16-B/lane streaming reads (x2); WRITE_SIZE is used as reported (calibrated here on the AdamW kernel: 16 B/param
+# read, 16 B/param written incl. the gradient clear -> FETCH x 2 = 6.0 GB, WRITE = 6.0 GB for 375.6 M parameters).
+NAMES = {'igemm3d_kernel': 'igemm3_kernel<256>', 'igemm3_kernel<128': 'igemm3_kernel<128>', 'wgrad3_kernel': 'wgrad3_kernel',
+         'igemm_kernel<128, 2, 2, false>': 'igemm_kernel<128,generic>', 'wgrad_kernel<128, 128': 'wgrad_kernel<128,128>',
+         'adamw_kernel': 'adamw_kernel'}
+traffic = {}
+for rk, bk in NAMES.items():
+    f = next((r for r in summary.get('FETCH_SIZE_all', []) if rk in r['kernel']), None)
+    w = next((r for r in summary.get('WRITE_SIZE_all', []) if rk in r['kernel']), None)
+    if f and w:
+        traffic[bk] = {'bytes_per_launch': round(f['per_dispatch'] * 1024 * 2 + w['per_dispatch'] * 1024),
+                       'fetch_bytes': round(f['per_dispatch'] * 1024 * 2), 'write_bytes': round(w['per_dispatch'] * 1024),
+                       'dispatches': f['dispatches'],
+                       'source': f'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of bench.py --batch 8, profiles/{tag}_summary.json; '
+                                 'FETCH_SIZE x 2 (gfx950 correction), KB -> bytes'}
+summary['traffic'] = traffic
+summary.pop('FETCH_SIZE_all', None)
+summary.pop('WRITE_SIZE_all', None)
 
 with open(os.path.join(out, f'{tag}_summary.json'), 'w') as f:
     json.dump(summary, f, indent=1)
