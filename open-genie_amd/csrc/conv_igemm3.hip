@@ -316,20 +316,28 @@ __global__ void __launch_bounds__(512) igemm3d_kernel(const Igemm3Args p, const 
         }
     };
 
-    int a_row[TM], b_rd[TN], b_sw[TN];
+    // fragment read offsets inside an image / a weight tile, precomputed for every (shift, k-step): the XOR swizzle makes them
+    // non-additive in the k-step, and computing them per read costs ~3 VALU per ds_read (4 VALU per MFMA in total, measured)
+    unsigned a_off[3][4][TM], b_off[4][TN];
+    const int khalf = lane >> 5;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int pl = wm * 64 + i * 32 + (lane & 31);
         const int hl = pl / W;
-        a_row[i] = hl * WP + (pl - hl * W);
+        const int row0 = hl * WP + (pl - hl * W);       // image row of (pixel, dw = -1); + s for dw = s - 1
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int row = row0 + s;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) a_off[s][ks][i] = (unsigned)(row * 128 + (((ks * 2 + khalf) ^ ((row >> 1) & 7)) << 4));
+        }
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int row = wn * 64 + j * 32 + (lane & 31);
-        b_rd[j] = row * 128;
-        b_sw[j] = (row >> 1) & 7;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) b_off[ks][j] = (unsigned)(row * 128 + (((ks * 2 + khalf) ^ ((row >> 1) & 7)) << 4));
     }
-    const int khalf = lane >> 5;
 
     f32x16_t acc[TM][TN];
 #pragma unroll
@@ -340,21 +348,13 @@ __global__ void __launch_bounds__(512) igemm3d_kernel(const Igemm3Args p, const 
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     auto compute = [&](const char* abuf, int s, const char* bbuf) {
-        int a_rd[TM], a_sw[TM];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int row = a_row[i] + s;
-            a_rd[i] = row * 128;
-            a_sw[i] = (row >> 1) & 7;
-        }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             bf16x8_t af[TM], bfr[TN];
-            const int lc = ks * 2 + khalf;
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(abuf + a_rd[i] + ((lc ^ a_sw[i]) << 4));
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(abuf + a_off[s][ks][i]);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const bf16x8_t*>(bbuf + b_rd[j] + ((lc ^ b_sw[j]) << 4));
+            for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const bf16x8_t*>(bbuf + b_off[ks][j]);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll

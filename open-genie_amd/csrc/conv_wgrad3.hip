@@ -54,23 +54,52 @@ struct Wgrad3Args {
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 
+// ds_read_b64_tr_b16 with an immediate byte offset, as inline asm (outside hipcc's waitcnt bookkeeping: the caller waits)
+template <int IMM>
 __device__ __forceinline__ bf16x4_t w3_tr16(uint32_t lds_addr) {
+    static_assert(IMM >= 0 && IMM < 65536, "ds offset field is 16 bits");
     bf16x4_t v;
-    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(lds_addr));      // outside hipcc's waitcnt bookkeeping: caller waits
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "i"(IMM));
     return v;
 }
 __device__ __forceinline__ uint32_t w3_lds_offset(const void* p) {
     return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
 }
 
+// x-image rows that precede chunk pixel kk0 = 16 ks + 4 h2 because of the two pad pixels per image row: 2 * (kk0 >> log2 W).
+// (For W = 8 the lane's own k-row adds 2 * (krow >> 3) more: a per-lane constant handled in the VGPR part of the address.)
+__host__ __device__ constexpr int w3_pad_rows(int ks, int h2, int log2w) { return 2 * ((ks * 16 + 4 * h2) >> log2w); }
+
+// All fragment reads of k-step KS: dy rows 16 KS + krow (+ 4), x-image rows of the same pixels shifted by s = 0, 1, 2.
+// a_addr[i] / b_addr[p][s] hold everything that is not a compile-time constant (stage base, lane's k-row, column, swizzle).
+template <int KS, int LOG2W, int TM>
+__device__ __forceinline__ void w3_issue(const uint32_t (&a_addr)[TM], const uint32_t (&b_addr)[2][3], bf16x4_t (&alo)[TM],
+                                         bf16x4_t (&ahi)[TM], bf16x4_t (&blo)[3], bf16x4_t (&bhi)[3]) {
+    constexpr int P0 = (w3_pad_rows(KS, 0, LOG2W) >> 1) & 1, P1 = (w3_pad_rows(KS, 1, LOG2W) >> 1) & 1;   // swizzle parity
+    constexpr int X0 = (KS * 16 + w3_pad_rows(KS, 0, LOG2W)) * 256, X1 = (KS * 16 + 4 + w3_pad_rows(KS, 1, LOG2W)) * 256;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        alo[i] = w3_tr16<KS * 16 * 256>(a_addr[i]);
+        ahi[i] = w3_tr16<(KS * 16 + 4) * 256>(a_addr[i]);
+    }
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        blo[s] = w3_tr16<X0>(b_addr[P0][s]);
+        bhi[s] = w3_tr16<X1>(b_addr[P1][s]);
+    }
+}
+
+template <int LOG2W, bool SHUF>
 __global__ void __launch_bounds__(512) wgrad3_kernel(const Wgrad3Args a) {
     constexpr int BK = 64;                               // pixels per chunk
+    constexpr int W = 1 << LOG2W, WP = W + 2, HS = BK >> LOG2W;   // image rows per chunk
     constexpr int PITCH = 256;                           // bytes per LDS row (128 channels)
     constexpr int A_BYTES = BK * PITCH;                  // dy tile, 16 KB
     constexpr int X_ROUNDS = 3, X_BYTES = X_ROUNDS * 32 * PITCH;   // x image, up to 96 rows (80 used at W = 8), 24 KB
     constexpr int STAGE = A_BYTES + X_BYTES;             // 40 KB
     constexpr int NSTAGE = 3;
     constexpr int TM = 2;                                // 32-row co tiles per wave; one 32-col ci tile
+    constexpr int IMG_ROWS = HS * WP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -93,18 +122,16 @@ __global__ void __launch_bounds__(512) wgrad3_kernel(const Wgrad3Args a) {
     const int t_dt = __builtin_amdgcn_readfirstlane(tp.dt), t_dh = __builtin_amdgcn_readfirstlane(tp.dh);
     const bool do_bias = a.dbias != nullptr && tr == 0 && tile_n == 0 && wn == 0;
     const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page_w3);
-    const int W = a.W, WP = W + 2;
 
     int c_begin = split * a.chunks_per_split, c_end = c_begin + a.chunks_per_split;
     if (c_end > a.nchunks) c_end = a.nchunks;
 
-    // ---- staging state ----
-    // dy tile: 2 rounds of 32 rows; this lane's logical 16-B chunk is the same in both rounds (row & 3 is)
+    // ---- staging state (per lane, fixed for the kernel): which rows / channel chunk this lane fills in every stage ----
     const int d_row = tid >> 4;                          // + 32 * round
+    const int st_lc = (tid & 15) ^ ((d_row & 3) << 2);   // logical 16-B chunk (same in every round: round * 32 keeps row & 3)
     int d_coff;                                          // element offset of (sub-pixel, channel) inside a dy pixel, or -1
     {
-        const int lc = (tid & 15) ^ ((d_row & 3) << 2);
-        const int co = co0 + lc * 8;
+        const int co = co0 + st_lc * 8;
         if (co < a.Cout) {
             const int sub = co / a.shuf_c, ch = co - sub * a.shuf_c;
             const int r = sub % a.shuf_r, q = (sub / a.shuf_r) % a.shuf_q, p = sub / (a.shuf_r * a.shuf_q);
@@ -113,51 +140,59 @@ __global__ void __launch_bounds__(512) wgrad3_kernel(const Wgrad3Args a) {
             d_coff = -1;
         }
     }
-    // x image: 3 rounds of 32 image rows; (hl, wp) and the channel chunk are fixed per round
-    int x_pix[X_ROUNDS];                                 // chunk-local pixel of the row's home position, or -1 (padding / unused row)
-    int x_c;                                             // first channel of this lane's chunk, or -1
-    {
-        const int lc = (tid & 15) ^ ((d_row & 3) << 2);
-        const int ci = ci0 + lc * 8;
-        x_c = (ci < a.Cs && ci < ((a.Cin + 7) & ~7)) ? ci : -1;
-#pragma unroll
-        for (int i = 0; i < X_ROUNDS; ++i) {
-            const int r = i * 32 + d_row;
-            const int hl = r / WP, wp = r - hl * WP;
-            x_pix[i] = (r < a.img_rows && wp >= 1 && wp <= W) ? hl * W + wp - 1 : -1;
-        }
-    }
+    const int x_c = (ci0 + st_lc * 8 < a.Cs && ci0 + st_lc * 8 < ((a.Cin + 7) & ~7)) ? ci0 + st_lc * 8 : -1;
     const int tap_delta = (t_dt * a.H + t_dh) * W * a.Cs;
+    // x image rows: chunk-local home pixel (or -1: pad column / unused row) and its (t, h), advanced by HS image rows per stage
+    int x_pix[X_ROUNDS], x_to[X_ROUNDS], x_ho[X_ROUNDS];
+#pragma unroll
+    for (int i = 0; i < X_ROUNDS; ++i) {
+        const int r = i * 32 + d_row;
+        const int hl = r / WP, wp = r - hl * WP;
+        x_pix[i] = (r < IMG_ROWS && wp >= 1 && wp <= W && x_c >= 0) ? hl * W + wp - 1 : -1;
+        const uint32_t rowid = (uint32_t)c_begin * HS + (uint32_t)hl;          // (n, t, h) row of the first staged chunk
+        const uint32_t q2 = fd3(rowid, a.dH_);
+        x_ho[i] = (int)(rowid - q2 * a.dH_.d);
+        x_to[i] = (int)(q2 - fd3(q2, a.dT_) * a.dT_.d);
+    }
 
-    auto stage = [&](int chunk, int buf, bool live) {
+    int next_chunk = c_begin;                            // stage() is called for consecutive chunks only
+    auto stage = [&](int buf, bool live) {
         char* abase = smem + buf * STAGE;
         char* xbase = abase + A_BYTES;
-        const uint32_t mbase = (uint32_t)chunk * BK;
+        const uint32_t mbase = (uint32_t)next_chunk * BK;
+        const int left = a.M - (int)mbase;               // pixels of this chunk that exist (<= 0: none)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const uint32_t m = mbase + i * 32 + d_row;
+            const int pl = i * 32 + d_row;
             const bf16_t* q = zero;
-            if (live && m < (uint32_t)a.M && d_coff >= 0) {
-                const uint32_t q1 = m >> a.log2W, wo = m & (uint32_t)(W - 1);
-                const uint32_t q2 = fd3(q1, a.dH_), ho = q1 - q2 * a.dH_.d;
-                const uint32_t n = fd3(q2, a.dT_), to = q2 - n * a.dT_.d;
-                q = a.dy + ((((n * a.Td + to * a.dmt) * a.Hd + ho * a.dmh) * a.Wd + wo * a.dmw) * a.Cd + (uint32_t)d_coff);
+            if (live && pl < left && d_coff >= 0) {
+                if (SHUF) {
+                    const uint32_t m = mbase + pl;
+                    const uint32_t q1 = m >> LOG2W, wo = m & (uint32_t)(W - 1);
+                    const uint32_t q2 = fd3(q1, a.dH_), ho = q1 - q2 * a.dH_.d;
+                    const uint32_t n = fd3(q2, a.dT_), to = q2 - n * a.dT_.d;
+                    q = a.dy + ((((n * a.Td + to * a.dmt) * a.Hd + ho * a.dmh) * a.Wd + wo * a.dmw) * a.Cd + (uint32_t)d_coff);
+                } else {
+                    q = a.dy + ((mbase + pl) * (uint32_t)a.Cd + (uint32_t)d_coff);     // dy has the row grid's geometry: linear
+                }
             }
             __builtin_amdgcn_global_load_lds(GLB_PTR(q), LDS_PTR(abase + (i * 8 + wave) * 1024), 16, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < X_ROUNDS; ++i) {
             const bf16_t* q = zero;
-            const uint32_t m = mbase + (uint32_t)x_pix[i];
-            if (live && x_pix[i] >= 0 && m < (uint32_t)a.M && x_c >= 0) {
-                const uint32_t q1 = m >> a.log2W;
-                const uint32_t q2 = fd3(q1, a.dH_), ho = q1 - q2 * a.dH_.d;
-                const uint32_t n = fd3(q2, a.dT_), to = q2 - n * a.dT_.d;
-                const int t = (int)to + t_dt, h = (int)ho + t_dh;
-                if ((unsigned)t < (unsigned)a.T && (unsigned)h < (unsigned)a.H) q = a.src + (int)(m * (uint32_t)a.Cs + (uint32_t)(tap_delta + x_c));
-            }
+            const int t = x_to[i] + t_dt, h = x_ho[i] + t_dh;
+            if (live && x_pix[i] >= 0 && x_pix[i] < left && (unsigned)t < (unsigned)a.T && (unsigned)h < (unsigned)a.H)
+                q = a.src + (int)((mbase + (uint32_t)x_pix[i]) * (uint32_t)a.Cs + (uint32_t)(tap_delta + x_c));
             __builtin_amdgcn_global_load_lds(GLB_PTR(q), LDS_PTR(xbase + (i * 8 + wave) * 1024), 16, 0, 0);
+            // next chunk: HS image rows further
+            x_ho[i] += HS;
+            while (x_ho[i] >= a.H) {
+                x_ho[i] -= a.H;
+                x_to[i] = x_to[i] + 1 == a.T ? 0 : x_to[i] + 1;
+            }
         }
+        ++next_chunk;
     };
 
     f32x16_t acc[3][TM];
@@ -173,26 +208,28 @@ __global__ void __launch_bounds__(512) wgrad3_kernel(const Wgrad3Args a) {
     }
 
     // ---- transposing-read addresses: lane = 16 g + 4 r + q reads k-row 8 (g >> 1) + r (+ 16 kstep, + 4 second read),
-    //      channels 16 (g & 1) + 4 q .. + 3 of the 32-wide tile ----
+    //      channels 16 (g & 1) + 4 q .. + 3 of the 32-wide tile.  Everything but the stage base is constant per lane:
+    //      dy : row = kk,                    swizzle key = kk & 3 = r
+    //      x  : row = kk + 2 (kk >> LOG2W) + s, swizzle key = (r + s + 2 (parity of kk >> LOG2W)) & 3 ----
     const int g16 = lane >> 4, rr = (lane >> 2) & 3, qq = lane & 3;
     const int krow = 8 * (g16 >> 1) + rr;
-    int a_col[TM];
+    const int lane_pad = LOG2W == 3 ? 2 * (g16 >> 1) : 0;            // W = 8: k-rows 8..11 sit one image row further
+    uint32_t a_const[TM], b_const[2][3];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) a_col[i] = wm * 64 + i * 32 + 16 * (g16 & 1) + 4 * qq;
-    const int b_col = wn * 32 + 16 * (g16 & 1) + 4 * qq;
-    // x image row of chunk pixel kk (shift 0): (kk / W) * (W + 2) + kk % W;   kk = 16 ks + krow (+ 4)
-    int x_row[4][2];
+    for (int i = 0; i < TM; ++i) {
+        const int col = wm * 64 + i * 32 + 16 * (g16 & 1) + 4 * qq;
+        a_const[i] = (uint32_t)(krow * PITCH + (((col >> 3) ^ (rr << 2)) << 4) + (col & 7) * 2);
+    }
+    {
+        const int col = wn * 32 + 16 * (g16 & 1) + 4 * qq;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
+        for (int p = 0; p < 2; ++p)
 #pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2) {
-            const int kk = ks * 16 + krow + 4 * h2;
-            x_row[ks][h2] = (kk >> a.log2W) * WP + (kk & (W - 1));
-        }
-    auto frag_addr = [&](int row, int col) -> uint32_t {   // byte offset inside a [rows][128 ch] image with the (row & 3) chunk swizzle
-        const int chunk = (col >> 3) ^ ((row & 3) << 2);
-        return (uint32_t)(row * PITCH + chunk * 16 + (col & 7) * 2);
-    };
+            for (int s = 0; s < 3; ++s) {
+                const int key = (rr + s + lane_pad + 2 * p) & 3;
+                b_const[p][s] = (uint32_t)((krow + lane_pad + s) * PITCH + (((col >> 3) ^ (key << 2)) << 4) + (col & 7) * 2);
+            }
+    }
 
     bf16x8_t ones;
 #pragma unroll
@@ -202,56 +239,56 @@ __global__ void __launch_bounds__(512) wgrad3_kernel(const Wgrad3Args a) {
     const int nch = c_end - c_begin;
     if (nch > 0) {
         // prologue: two stages in flight, the first one landed
-        stage(c_begin, 0, true);
-        stage(c_begin + 1, 1, nch > 1);
+        stage(0, true);
+        stage(1, nch > 1);
         asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         int buf = 0;
         for (int c = 0; c < nch; ++c) {
             const int nbuf = buf >= 1 ? buf - 1 : NSTAGE - 1;            // (buf + 2) % 3
-            stage(c_begin + c + 2, nbuf, c + 2 < nch);                    // slot of chunk c - 1: every wave is past the barrier behind it
+            stage(nbuf, c + 2 < nch);                                     // slot of chunk c - 1: every wave is past the barrier behind it
             const uint32_t abase = smem_base + buf * STAGE;
-            const uint32_t xbase = abase + A_BYTES;
+            uint32_t a_addr[TM], b_addr[2][3];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a_addr[i] = abase + a_const[i];
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int s = 0; s < 3; ++s) b_addr[p][s] = abase + A_BYTES + b_const[p][s];
             bf16x4_t alo[2][TM], ahi[2][TM], blo[2][3], bhi[2][3];
-            auto issue = [&](int ks, int set) {
-                const int r0 = ks * 16 + krow;
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    alo[set][i] = w3_tr16(abase + frag_addr(r0, a_col[i]));
-                    ahi[set][i] = w3_tr16(abase + frag_addr(r0 + 4, a_col[i]));
-                }
-#pragma unroll
-                for (int s = 0; s < 3; ++s) {
-                    blo[set][s] = w3_tr16(xbase + frag_addr(x_row[ks][0] + s, b_col));
-                    bhi[set][s] = w3_tr16(xbase + frag_addr(x_row[ks][1] + s, b_col));
-                }
-            };
-            issue(0, 0);
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const int set = ks & 1;
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-                bf16x8_t af[TM], bfr[3];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    asm volatile("" : "+v"(alo[set][i]), "+v"(ahi[set][i]));
-                    af[i] = __builtin_shufflevector(alo[set][i], ahi[set][i], 0, 1, 2, 3, 4, 5, 6, 7);
-                }
-#pragma unroll
-                for (int s = 0; s < 3; ++s) {
-                    asm volatile("" : "+v"(blo[set][s]), "+v"(bhi[set][s]));
-                    bfr[s] = __builtin_shufflevector(blo[set][s], bhi[set][s], 0, 1, 2, 3, 4, 5, 6, 7);
-                }
-                if (ks < 3) issue(ks + 1, set ^ 1);
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-#pragma unroll
-                    for (int s = 0; s < 3; ++s) acc[s][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[s], acc[s][i], 0, 0, 0);
-                    if (do_bias) accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], ones, accb[i], 0, 0, 0);
-                }
+#define W3_CONSUME(SET)                                                                                          \
+            bf16x8_t af[TM], bfr[3];                                                                             \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                     \
+                asm volatile("" : "+v"(alo[SET][i]), "+v"(ahi[SET][i]));                                         \
+                af[i] = __builtin_shufflevector(alo[SET][i], ahi[SET][i], 0, 1, 2, 3, 4, 5, 6, 7);               \
+            }                                                                                                    \
+            _Pragma("unroll") for (int s = 0; s < 3; ++s) {                                                      \
+                asm volatile("" : "+v"(blo[SET][s]), "+v"(bhi[SET][s]));                                         \
+                bfr[s] = __builtin_shufflevector(blo[SET][s], bhi[SET][s], 0, 1, 2, 3, 4, 5, 6, 7);              \
             }
+#define W3_MFMA()                                                                                                \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                     \
+                _Pragma("unroll") for (int s = 0; s < 3; ++s)                                                    \
+                    acc[s][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[s], acc[s][i], 0, 0, 0);     \
+                if (do_bias) accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], ones, accb[i], 0, 0, 0);   \
+            }
+#define W3_STEP(KS, SET, NEXT)                                                                                   \
+            {                                                                                                    \
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                               \
+                __builtin_amdgcn_sched_barrier(0);                                                               \
+                W3_CONSUME(SET)                                                                                  \
+                NEXT                                                                                             \
+                W3_MFMA()                                                                                        \
+            }
+            w3_issue<0, LOG2W, TM>(a_addr, b_addr, alo[0], ahi[0], blo[0], bhi[0]);
+            W3_STEP(0, 0, (w3_issue<1, LOG2W, TM>(a_addr, b_addr, alo[1], ahi[1], blo[1], bhi[1]));)
+            W3_STEP(1, 1, (w3_issue<2, LOG2W, TM>(a_addr, b_addr, alo[0], ahi[0], blo[0], bhi[0]));)
+            W3_STEP(2, 0, (w3_issue<3, LOG2W, TM>(a_addr, b_addr, alo[1], ahi[1], blo[1], bhi[1]));)
+            W3_STEP(3, 1, ;)
+#undef W3_STEP
+#undef W3_MFMA
+#undef W3_CONSUME
             // chunk c + 1 (issued one iteration ago) must have landed; the stage just issued (5 glds) stays in flight
             asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -329,17 +366,29 @@ int genie_conv_wgrad3_try(const GenieWgradDesc* d, hipStream_t s) {
     a.chunks_per_split = cdiv(a.nchunks, sk);
     a.split_k = cdiv(a.nchunks, a.chunks_per_split);
     constexpr int lds = 3 * (64 * 256 + 3 * 32 * 256);
-    static bool configured = false;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)wgrad3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    void (*kern)(const Wgrad3Args) = nullptr;
+    switch (a.log2W * 2 + (shuffled ? 1 : 0)) {
+        case 6: kern = wgrad3_kernel<3, false>; break;
+        case 7: kern = wgrad3_kernel<3, true>; break;
+        case 8: kern = wgrad3_kernel<4, false>; break;
+        case 9: kern = wgrad3_kernel<4, true>; break;
+        case 10: kern = wgrad3_kernel<5, false>; break;
+        case 11: kern = wgrad3_kernel<5, true>; break;
+        case 12: kern = wgrad3_kernel<6, false>; break;
+        default: kern = wgrad3_kernel<6, true>; break;
+    }
+    static bool configured[16] = {false};
+    const int slot = a.log2W * 2 + (shuffled ? 1 : 0);
+    if (!configured[slot]) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) {
             genie_set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e));
             return GENIE_ERR_HIP;
         }
-        configured = true;
+        configured[slot] = true;
     }
     genie_note_variant(GENIE_VARIANT_WGRAD3);
-    hipLaunchKernelGGL(wgrad3_kernel, dim3((unsigned)(base * a.split_k)), dim3(512), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(base * a.split_k)), dim3(512), lds, s, a);
     GENIE_CHECK_LAUNCH();
     return GENIE_OK;
 }
