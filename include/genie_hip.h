@@ -189,6 +189,17 @@ int genie_groupnorm_bwd(const void* x, const void* dy, void* dx, int N, int64_t 
                         const float* mean, const float* rstd, float* dgamma, float* dbeta, float* dada_scale,
                         float* dada_shift, float* ws, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * BlurPooling3d with num_groups = 1 (elementwise.hip).   replaces: F.conv3d with the expanded Pascal kernel, video.py:516-534
+ * (every output channel = strided blur of the SUM over the input channels -- the reference's dense-conv behaviour).
+ * dims = {N, C, T, H, W} of the input; kernel / stride / pad = {t, h, w}; taps: device fp32 [kt*kh*kw];
+ * ws: device fp32, max(N*T*H*W, N*To*Ho*Wo) floats.  Output geometry (To, Ho, Wo) = floor((size + 2 pad - k) / stride) + 1.
+ * ------------------------------------------------------------------------------------------- */
+int genie_blur_pool3d_fwd(const void* x_cl, int cpitch, const int64_t* dims, const float* taps, const int* kernel, const int* stride,
+                          const int* pad, void* out_cl, int out_channels, int out_pitch, float* ws, void* stream);
+int genie_blur_pool3d_bwd(const void* dy_cl, int out_channels, int out_pitch, const int64_t* dims, const float* taps,
+                          const int* kernel, const int* stride, const int* pad, void* dx_cl, int cpitch, float* ws, void* stream);
+
 int genie_silu_fwd(const void* x, void* y, int64_t numel, void* stream);
 int genie_silu_bwd(const void* x, const void* dy, void* dx, int64_t numel, void* stream);
 int genie_add(const void* a, const void* b, void* y, int64_t numel, void* stream);

@@ -488,3 +488,147 @@ extern "C" int genie_pack_transpose_batched(const GeniePackJob* jobs_dev, int nj
     GENIE_CHECK_LAUNCH();
     return GENIE_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// BlurPooling3d (reference genie/module/video.py:487-537).  With num_groups = 1 the reference runs a DENSE conv3d whose every
+// (out, in) tap is the same Pascal blur kernel, i.e. every output channel is the strided blur of the SUM over the input
+// channels.  Written as what it is -- HBM-bound: one pass that sums the channels of each pixel
+// (reads x once), a stencil over that C-times-smaller fp32 field, and a broadcast store of the result to all output channels --
+// instead of a 2 M C O 27-FLOP GEMM.  Backward is the same three steps transposed.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) chan_sum_kernel(const bf16_t* __restrict__ x, long long npix, int C, int Cp, float* __restrict__ out) {
+    // a group of L = 8 lanes per pixel walks the pixel's 16-B chunks; 8 pixels per wave-instruction
+    const int lane = threadIdx.x & 63, sub = lane & 7;
+    const int nch = Cp >> 3;
+    for (long long p = ((long long)blockIdx.x * 256 + threadIdx.x) >> 3; p < npix; p += ((long long)gridDim.x * 256) >> 3) {
+        float s = 0.f;
+        for (int ch = sub; ch < nch; ch += 8) {
+            float f[8];
+            unpack8(*reinterpret_cast<const u32x4_t*>(x + p * Cp + ch * 8), f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += (ch * 8 + j < C) ? f[j] : 0.f;
+        }
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        s += __shfl_xor(s, 4, 64);
+        if (sub == 0) out[p] = s;
+    }
+}
+
+struct BlurGeom {
+    int N, T, H, W, To, Ho, Wo;
+    int kt, kh, kw, st, sh, sw, pt, ph, pw;
+};
+
+// out[n, :, to, ho, wo] = sum_taps k[a, b, c] * s[n, to st + a - pt, ho sh + b - ph, wo sw + c - pw]   (zero outside)
+__global__ void __launch_bounds__(256) blur_stencil_fwd_kernel(const float* __restrict__ s, const float* __restrict__ taps, BlurGeom g,
+                                                               bf16_t* __restrict__ out, int O, int Op) {
+    const int nch = Op >> 3;
+    const long long total = (long long)g.N * g.To * g.Ho * g.Wo * nch;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int ch = (int)(i % nch);
+        long long p = i / nch;
+        const int wo = (int)(p % g.Wo); p /= g.Wo;
+        const int ho = (int)(p % g.Ho); p /= g.Ho;
+        const int to = (int)(p % g.To);
+        const int n = (int)(p / g.To);
+        float v = 0.f;
+        for (int a = 0; a < g.kt; ++a) {
+            const int t = to * g.st + a - g.pt;
+            if ((unsigned)t >= (unsigned)g.T) continue;
+            for (int b = 0; b < g.kh; ++b) {
+                const int h = ho * g.sh + b - g.ph;
+                if ((unsigned)h >= (unsigned)g.H) continue;
+                for (int c = 0; c < g.kw; ++c) {
+                    const int w = wo * g.sw + c - g.pw;
+                    if ((unsigned)w >= (unsigned)g.W) continue;
+                    v += taps[(a * g.kh + b) * g.kw + c] * s[(((long long)n * g.T + t) * g.H + h) * g.W + w];
+                }
+            }
+        }
+        float f[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = (ch * 8 + j < O) ? v : 0.f;
+        *reinterpret_cast<u32x4_t*>(out + i * 8) = pack8(f);
+    }
+}
+
+// dx[n, :, t, h, w] = sum over taps and output positions with to st + a - pt == t (...) of k[a, b, c] * sdy[n, to, ho, wo]
+__global__ void __launch_bounds__(256) blur_stencil_bwd_kernel(const float* __restrict__ sdy, const float* __restrict__ taps, BlurGeom g,
+                                                               bf16_t* __restrict__ dx, int C, int Cp) {
+    const int nch = Cp >> 3;
+    const long long total = (long long)g.N * g.T * g.H * g.W * nch;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int ch = (int)(i % nch);
+        long long p = i / nch;
+        const int w = (int)(p % g.W); p /= g.W;
+        const int h = (int)(p % g.H); p /= g.H;
+        const int t = (int)(p % g.T);
+        const int n = (int)(p / g.T);
+        float v = 0.f;
+        for (int a = 0; a < g.kt; ++a) {
+            const int tn = t + g.pt - a;
+            if (tn < 0 || tn % g.st != 0 || tn / g.st >= g.To) continue;
+            for (int b = 0; b < g.kh; ++b) {
+                const int hn = h + g.ph - b;
+                if (hn < 0 || hn % g.sh != 0 || hn / g.sh >= g.Ho) continue;
+                for (int c = 0; c < g.kw; ++c) {
+                    const int wn = w + g.pw - c;
+                    if (wn < 0 || wn % g.sw != 0 || wn / g.sw >= g.Wo) continue;
+                    v += taps[(a * g.kh + b) * g.kw + c] * sdy[(((long long)n * g.To + tn / g.st) * g.Ho + hn / g.sh) * g.Wo + wn / g.sw];
+                }
+            }
+        }
+        float f[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = (ch * 8 + j < C) ? v : 0.f;
+        *reinterpret_cast<u32x4_t*>(dx + i * 8) = pack8(f);
+    }
+}
+
+static int blur_check(const int64_t* dims, const int* kernel, const int* stride, const int* pad, BlurGeom& g) {
+    GENIE_CHECK_ARG(dims && kernel && stride && pad, "genie_blur_pool3d: null geometry");
+    g.N = (int)dims[0]; g.T = (int)dims[2]; g.H = (int)dims[3]; g.W = (int)dims[4];
+    g.kt = kernel[0]; g.kh = kernel[1]; g.kw = kernel[2]; g.st = stride[0]; g.sh = stride[1]; g.sw = stride[2];
+    g.pt = pad[0]; g.ph = pad[1]; g.pw = pad[2];
+    GENIE_CHECK_ARG(g.kt >= 1 && g.kh >= 1 && g.kw >= 1 && g.st >= 1 && g.sh >= 1 && g.sw >= 1, "genie_blur_pool3d: bad kernel / stride");
+    g.To = (g.T + 2 * g.pt - g.kt) / g.st + 1; g.Ho = (g.H + 2 * g.ph - g.kh) / g.sh + 1; g.Wo = (g.W + 2 * g.pw - g.kw) / g.sw + 1;
+    GENIE_CHECK_ARG(g.To >= 1 && g.Ho >= 1 && g.Wo >= 1, "genie_blur_pool3d: input smaller than the kernel");
+    return GENIE_OK;
+}
+
+extern "C" int genie_blur_pool3d_fwd(const void* x_cl, int cpitch, const int64_t* dims, const float* taps, const int* kernel,
+                                     const int* stride, const int* pad, void* out_cl, int out_channels, int out_pitch, float* ws,
+                                     void* stream) {
+    GENIE_CHECK_ARG(x_cl && taps && out_cl && ws, "genie_blur_pool3d_fwd: null pointer");
+    BlurGeom g;
+    if (int rc = blur_check(dims, kernel, stride, pad, g)) return rc;
+    const int C = (int)dims[1];
+    GENIE_CHECK_ARG(cpitch % 8 == 0 && cpitch >= C && out_pitch % 8 == 0 && out_pitch >= out_channels, "genie_blur_pool3d_fwd: bad channel pitch");
+    const long long npix = (long long)g.N * g.T * g.H * g.W;
+    hipStream_t s = (hipStream_t)stream;
+    chan_sum_kernel<<<ew_grid(npix * 8), 256, 0, s>>>((const bf16_t*)x_cl, npix, C, cpitch, ws);
+    GENIE_CHECK_LAUNCH();
+    const long long total = (long long)g.N * g.To * g.Ho * g.Wo * (out_pitch >> 3);
+    blur_stencil_fwd_kernel<<<ew_grid(total), 256, 0, s>>>(ws, taps, g, (bf16_t*)out_cl, out_channels, out_pitch);
+    GENIE_CHECK_LAUNCH();
+    return GENIE_OK;
+}
+
+extern "C" int genie_blur_pool3d_bwd(const void* dy_cl, int out_channels, int out_pitch, const int64_t* dims, const float* taps,
+                                     const int* kernel, const int* stride, const int* pad, void* dx_cl, int cpitch, float* ws,
+                                     void* stream) {
+    GENIE_CHECK_ARG(dy_cl && taps && dx_cl && ws, "genie_blur_pool3d_bwd: null pointer");
+    BlurGeom g;
+    if (int rc = blur_check(dims, kernel, stride, pad, g)) return rc;
+    const int C = (int)dims[1];
+    GENIE_CHECK_ARG(cpitch % 8 == 0 && cpitch >= C && out_pitch % 8 == 0 && out_pitch >= out_channels, "genie_blur_pool3d_bwd: bad channel pitch");
+    const long long nout = (long long)g.N * g.To * g.Ho * g.Wo;
+    hipStream_t s = (hipStream_t)stream;
+    chan_sum_kernel<<<ew_grid(nout * 8), 256, 0, s>>>((const bf16_t*)dy_cl, nout, out_channels, out_pitch, ws);
+    GENIE_CHECK_LAUNCH();
+    const long long total = (long long)g.N * g.T * g.H * g.W * (cpitch >> 3);
+    blur_stencil_bwd_kernel<<<ew_grid(total), 256, 0, s>>>(ws, taps, g, (bf16_t*)dx_cl, C, cpitch);
+    GENIE_CHECK_LAUNCH();
+    return GENIE_OK;
+}

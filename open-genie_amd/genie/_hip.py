@@ -75,6 +75,8 @@ SIGNATURES = {
     'genie_groupnorm_ws_floats': (C.c_int64, [_I, _I, _I]),
     'genie_groupnorm_fwd': (C.c_int, [_P, _P, _I, _L, _I, _I, _I, _P, _P, _P, _P, _F, _I, _P, _P, _P, _P]),
     'genie_groupnorm_bwd': (C.c_int, [_P, _P, _P, _I, _L, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'genie_blur_pool3d_fwd': (C.c_int, [_P, _I, _PL, _P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), _P, _I, _I, _P, _P]),
+    'genie_blur_pool3d_bwd': (C.c_int, [_P, _I, _I, _PL, _P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), _P, _I, _P, _P]),
     'genie_silu_fwd': (C.c_int, [_P, _P, _L, _P]),
     'genie_silu_bwd': (C.c_int, [_P, _P, _P, _L, _P]),
     'genie_add': (C.c_int, [_P, _P, _P, _L, _P]),
@@ -126,6 +128,10 @@ def stream_ptr() -> int:
 
 def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
+
+
+def i32(vals) -> C.Array:
+    return (C.c_int * len(vals))(*[int(v) for v in vals])
 
 
 def i64(vals) -> C.Array:

@@ -195,6 +195,46 @@ def silu(x: Tensor) -> Tensor:
 
 
 # ------------------------------------------------------------------------------------------------
+# BlurPooling3d (num_groups = 1): channel sum -> strided Pascal stencil -> broadcast
+# ------------------------------------------------------------------------------------------------
+class _BlurPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x: Tensor, taps: Tensor, stride, pad, out_channels: int):
+        from .cl import empty_cl
+        n, c, t, h, w = x.shape
+        k = tuple(taps.shape)
+        to, ho, wo = ((sz + 2 * p - kk) // s + 1 for sz, p, kk, s in zip((t, h, w), pad, k, stride))
+        out = empty_cl(n, out_channels, to, ho, wo, x.device)
+        ws = workspace(max(n * t * h * w, n * to * ho * wo), x.device, 'blur')
+        tp = taps.detach().float().contiguous()
+        _hip.check(_hip.load_library().genie_blur_pool3d_fwd(x.data_ptr(), pitch_of(x), _hip.i64(x.shape), tp.data_ptr(), _hip.i32(k), _hip.i32(stride),
+                                                             _hip.i32(pad), out.data_ptr(), out_channels, pitch_of(out), ws.data_ptr(),
+                                                             _hip.stream_ptr()), 'genie_blur_pool3d_fwd')
+        ctx.geom = (tuple(x.shape), k, tuple(stride), tuple(pad), out_channels)
+        ctx.save_for_backward(tp)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        from .cl import empty_cl
+        (tp,) = ctx.saved_tensors
+        shape, k, stride, pad, oc = ctx.geom
+        n, c, t, h, w = shape
+        dy = to_cl(dy)
+        dx = empty_cl(n, c, t, h, w, dy.device)
+        ws = workspace(max(n * t * h * w, dy.shape[0] * dy.shape[2] * dy.shape[3] * dy.shape[4]), dy.device, 'blur')
+        _hip.check(_hip.load_library().genie_blur_pool3d_bwd(dy.data_ptr(), oc, pitch_of(dy), _hip.i64(shape), tp.data_ptr(), _hip.i32(k), _hip.i32(stride),
+                                                             _hip.i32(pad), dx.data_ptr(), pitch_of(dx), ws.data_ptr(), _hip.stream_ptr()),
+                   'genie_blur_pool3d_bwd')
+        return dx, None, None, None, None
+
+
+def blur_pool3d(x: Tensor, taps: Tensor, stride, pad, out_channels: int) -> Tensor:
+    """x: (N, C, T, H, W); taps: (kt, kh, kw) blur kernel; every one of the `out_channels` outputs = blur(sum_c x)."""
+    return _BlurPoolFn.apply(to_cl(x), taps, tuple(int(s) for s in stride), tuple(int(p) for p in pad), int(out_channels))
+
+
+# ------------------------------------------------------------------------------------------------
 # MSE against an arbitrary-strided target
 # ------------------------------------------------------------------------------------------------
 class _MseFn(torch.autograd.Function):

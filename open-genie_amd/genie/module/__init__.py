@@ -9,7 +9,7 @@ import torch.nn as nn
 
 from ..utils import Blueprint, default, exists
 from .norm import AdaptiveGroupNorm, GroupNorm, SiLU
-from .video import (CausalConv3d, CausalConvTranspose3d, DepthToSpaceTimeUpsample, DepthToSpaceUpsample,
+from .video import (BlurPooling3d, CausalConv3d, CausalConvTranspose3d, DepthToSpaceTimeUpsample, DepthToSpaceUpsample,
                     DepthToTimeUpsample, SpaceTimeDownsample, VideoResidualBlock)
 
 
@@ -33,7 +33,9 @@ def get_module(name: str):
         case 'space-time_attn':
             from .attention import SpaceTimeAttention
             return SpaceTimeAttention
-        case 'blur_pool' | 'space_downsample' | 'image-residual':
+        case 'blur_pool':
+            return BlurPooling3d
+        case 'space_downsample' | 'image-residual':
             return _out_of_scope(name)
         case 'video-residual':
             return VideoResidualBlock

@@ -173,7 +173,8 @@ class SpaceTimeDownsample(Downsample):
 
 class BlurPooling3d(nn.Module):
     """reference video.py:487-537.  With num_groups=1 the reference's dense conv sums ALL input channels into
-    every output channel; reproduced by running the same dense kernel."""
+    every output channel; computed as what it is (channel sum -> strided Pascal stencil ->
+    broadcast, ``genie_blur_pool3d_fwd``) instead of a dense GEMM."""
 
     def __init__(self, in_channels: int, kernel_size, out_channels: Optional[int] = None, time_factor: int = 2,
                  space_factor=2, num_groups: int = 1, **kwargs) -> None:
@@ -187,19 +188,10 @@ class BlurPooling3d(nn.Module):
         self.stride = (time_factor, *space_factor)
         self.kwargs, self.num_groups, self.out_channels = kwargs, num_groups, out_channels
         self.padding = tuple((k - 1) // 2 for k in ks)
-        self._ops = {}
 
     def forward(self, inp: Tensor) -> Tensor:
         inp = to_cl(inp)
-        c = inp.shape[1]
-        o = default(self.out_channels, c)
-        key = (c, o)
-        if key not in self._ops:
-            ks = tuple(self.blur.shape)
-            spec = ConvSpec(c, o, ks, tuple(self.stride), (1, 1, 1), self.padding, self.padding, None)
-            self._ops[key] = GF.ConvOp(spec)
-        ker = self.blur[None, None].expand(o, c, *self.blur.shape).contiguous()   # every (out, in) tap = the blur
-        return GF.conv3d(inp, ker, None, self._ops[key])
+        return GF.blur_pool3d(inp, self.blur, self.stride, self.padding, default(self.out_channels, inp.shape[1]))
 
     def __repr__(self):
         return f'BlurPooling3d({self.out_channels}, kernel_size={tuple(self.blur.shape)}, stride={self.stride}, padding={self.padding})'

@@ -407,3 +407,46 @@ def test_lfq_loss_and_grad(G, d, ncb, ntok, scale, dtype):
     g = zr.grad
     err = (dz.cpu() - g).abs().max().item()
     assert err <= 2e-3 * g.abs().max().item() + 1e-7, (err, g.abs().max().item())
+
+
+@pytest.mark.parametrize('c,o,ks,tf,sf,size', [(16, None, 3, 2, 2, (2, 4, 8, 8)), (40, 24, 3, 1, 2, (1, 3, 7, 9)), (128, None, (3, 3, 3), 2, (2, 2), (1, 5, 6, 6)),
+                                                (8, 3, 5, 2, 2, (2, 6, 9, 8))])
+def test_blur_pool3d(G, c, o, ks, tf, sf, size):
+    """BlurPooling3d (video.py:487-537, the dense-conv behaviour of num_groups = 1: every output channel = strided blur of the
+    channel sum), forward and backward against the oracle's F.conv3d restatement."""
+    from genie.module.video import BlurPooling3d
+    from oracle import genie_oracle as O
+    torch.manual_seed(14)
+    n, t, h, w = size
+    x = bf16_round(torch.randn(n, c, t, h, w))
+    xr = x.clone().requires_grad_(True)
+    ref = O.blur_pool3d(xr, ks, tf, sf, out_channels=o)
+    dy = bf16_round(torch.randn_like(ref))
+    ref.backward(dy)
+    m = BlurPooling3d(c, ks, out_channels=o, time_factor=tf, space_factor=sf).cuda()
+    xd = x.cuda().requires_grad_(True)
+    out = m(xd)
+    assert tuple(out.shape) == tuple(ref.shape)
+    assert_close_bf16(out, ref, 'blur pool fwd')
+    out.backward(dy.cuda())
+    assert_close_bf16(xd.grad, xr.grad, 'blur pool bwd', rms_frac=4e-3)
+
+
+def test_residual_block_with_blur_downsample(G):
+    """VideoResidualBlock(downsample=...) -- the README / test_tokenizer.py configuration of the reference (video.py:588-648):
+    blur pooling in both branches -- forward against the oracle."""
+    from genie.module.video import VideoResidualBlock
+    from oracle import genie_oracle as O
+    torch.manual_seed(15)
+    m = VideoResidualBlock(64, 128, downsample=(2, 2))
+    with torch.no_grad():
+        for p in m.parameters():
+            if p.dim() >= 2:
+                p.copy_(bf16_round(p * 0.1))
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    x = bf16_round(torch.randn(2, 64, 4, 8, 8))
+    ref = O.video_residual_block(x, sd, '', 64, 128, downsample=(2, 2))
+    out = m.cuda()(x.cuda())
+    assert tuple(out.shape) == tuple(ref.shape) == (2, 128, 2, 4, 4)
+    rel = ((out.float().cpu() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()
+    assert rel < 2e-2, rel
