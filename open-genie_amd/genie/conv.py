@@ -148,26 +148,32 @@ _tri_cache = {}
 FORCE_SPLIT_K = 0                   # experiments only: split-K factor handed to genie_conv_wgrad (0 = library chooses)
 
 
+def tri_rows(taps, hs: int, ws: int, cs: int):
+    """Pure host logic of the kw-triple schedule: group a tap list [(dt, dh, dw, wofs, c0, nch)] into one row per
+    (dt, dh, 64-channel block): [a_delta, dt, dh, wofs(dw=-1), wofs(dw=0), wofs(dw=+1), 0, 0] (struct GenieTriStep), or None when
+    the taps do not come as complete dw = -1, 0, +1 triples over whole 64-channel blocks."""
+    groups = {}
+    for (dt, dh, dw, wofs, c0, nch) in taps:
+        groups.setdefault((dt, dh, c0, nch), {})[dw] = wofs
+    if not groups or len(taps) != 3 * len(groups):
+        return None
+    rows = []
+    for (dt, dh, c0, nch), by_dw in groups.items():
+        if sorted(by_dw) != [-1, 0, 1] or nch % 64 != 0 or c0 % 8 != 0:
+            return None
+        for cb in range(nch // 64):
+            rows.append([((dt * hs + dh) * ws) * cs + c0 + cb * 64, dt, dh, by_dw[-1] + cb * 64, by_dw[0] + cb * 64, by_dw[1] + cb * 64, 0, 0])
+    return rows
+
+
 def tri_schedule(key, taps, hs: int, ws: int, cs: int):
-    """Group a tap list into (dt, dh, channel-block) steps whose three taps dw = -1, 0, +1 share one staged activation tile.
-    Returns (device int32 [n, 8], n) or None when the taps do not come as complete triples over whole 64-channel blocks."""
+    """Device copy of ``tri_rows`` (cached per device / conv / geometry): (int32 [n, 8] tensor, n) or None."""
     dev = torch.cuda.current_device()
     ck = (dev, key, hs, ws, cs)
     if ck in _tri_cache:
         return _tri_cache[ck]
-    groups = {}
-    for (dt, dh, dw, wofs, c0, nch) in taps:
-        groups.setdefault((dt, dh, c0, nch), {})[dw] = wofs
-    rows, ok = [], True
-    for (dt, dh, c0, nch), by_dw in groups.items():
-        if sorted(by_dw) != [-1, 0, 1] or nch % 64 != 0 or c0 % 8 != 0:
-            ok = False
-            break
-        for cb in range(nch // 64):
-            rows.append([((dt * hs + dh) * ws) * cs + c0 + cb * 64, dt, dh, by_dw[-1] + cb * 64, by_dw[0] + cb * 64, by_dw[1] + cb * 64, 0, 0])
-    out = None
-    if ok and rows and len(taps) == 3 * len(groups):
-        out = (torch.tensor(rows, dtype=torch.int32).cuda(), len(rows))
+    rows = tri_rows(taps, hs, ws, cs)
+    out = None if rows is None else (torch.tensor(rows, dtype=torch.int32).cuda(), len(rows))
     _tri_cache[ck] = out
     return out
 
