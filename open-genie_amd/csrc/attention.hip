@@ -95,17 +95,29 @@ __global__ void __launch_bounds__(256) rotary_ln_fwd_kernel(const bf16_t* __rest
 }
 
 // backward of u = LN(rot(x)):  dx = rot^T( LN'(du) ), dgamma += sum du * xhat, dbeta += sum du
+// One wave per token, grid-stride over tokens; a lane owns the same channels for every token, so the dgamma / dbeta partial
+// sums live in registers (the first version did two LDS atomics per element: 264 us per call at 65536 x 256) and are combined
+// once per block through LDS, then one global atomic per channel per block.
 __global__ void __launch_bounds__(256) rotary_ln_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ du,
                                                             const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx, long long ntok,
                                                             int C, long long pitch, const float* __restrict__ cs, long long pos_div,
                                                             int pos_mod, const float* __restrict__ gamma, const float* __restrict__ stats,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    extern __shared__ float sm[];     // [2][C] block-level partial sums of dgamma / dbeta
-    const int lane = threadIdx.x & 63;
-    for (int i = threadIdx.x; i < 2 * C; i += 256) sm[i] = 0.f;
-    __syncthreads();
+    extern __shared__ float sm[];     // [4 waves][2][C] partial sums of dgamma / dbeta
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nch = C >> 3;
-    for (long long tok = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); tok < ntok; tok += (long long)gridDim.x * 4) {
+    float gam[32], ag[32], ab[32];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int ch = lane + it * 64;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            gam[it * 8 + j] = (ch < nch && gamma) ? gamma[ch * 8 + j] : 1.f;
+            ag[it * 8 + j] = 0.f;
+            ab[it * 8 + j] = 0.f;
+        }
+    }
+    for (long long tok = (long long)blockIdx.x * 4 + wave; tok < ntok; tok += (long long)gridDim.x * 4) {
         const int pos = (int)((tok / pos_div) % pos_mod);
         const float* csr = cs ? cs + (long long)pos * C : nullptr;
         const float mean = stats[tok * 2], rstd = stats[tok * 2 + 1];
@@ -119,23 +131,23 @@ __global__ void __launch_bounds__(256) rotary_ln_bwd_kernel(const bf16_t* __rest
                 unpack8(*reinterpret_cast<const u32x4_t*>(x + tok * pitch + ch * 8), f);
                 unpack8(*reinterpret_cast<const u32x4_t*>(du + tok * pitch + ch * 8), d);
                 if (csr) {
+                    const f32x4_t c0 = *reinterpret_cast<const f32x4_t*>(csr + ch * 8), c1 = *reinterpret_cast<const f32x4_t*>(csr + ch * 8 + 4);
+                    const float cc[4] = {c0[0], c0[2], c1[0], c1[2]}, sn[4] = {c0[1], c0[3], c1[1], c1[3]};
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const float c = csr[ch * 8 + 2 * j], sn = csr[ch * 8 + 2 * j + 1];
                         const float a = f[2 * j], b = f[2 * j + 1];
-                        f[2 * j] = a * c - b * sn;
-                        f[2 * j + 1] = b * c + a * sn;
+                        f[2 * j] = a * cc[j] - b * sn[j];
+                        f[2 * j + 1] = b * cc[j] + a * sn[j];
                     }
                 }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const int c = ch * 8 + j;
                     const float h = (f[j] - mean) * rstd;
-                    const float gg = d[j] * (gamma ? gamma[c] : 1.f);
+                    const float gg = d[j] * gam[it * 8 + j];
                     xh[it * 8 + j] = h; g[it * 8 + j] = gg;
                     s1 += gg; s2 += gg * h;
-                    atomicAdd(&sm[c], d[j] * h);
-                    atomicAdd(&sm[C + c], d[j]);
+                    ag[it * 8 + j] += d[j] * h;
+                    ab[it * 8 + j] += d[j];
                 }
             }
         }
@@ -149,12 +161,13 @@ __global__ void __launch_bounds__(256) rotary_ln_bwd_kernel(const bf16_t* __rest
 #pragma unroll
                 for (int j = 0; j < 8; ++j) f[j] = rstd * (g[it * 8 + j] - s1 - xh[it * 8 + j] * s2);      // d/d(rotated x)
                 if (csr) {                                                                               // transpose of the rotation
+                    const f32x4_t c0 = *reinterpret_cast<const f32x4_t*>(csr + ch * 8), c1 = *reinterpret_cast<const f32x4_t*>(csr + ch * 8 + 4);
+                    const float cc[4] = {c0[0], c0[2], c1[0], c1[2]}, sn[4] = {c0[1], c0[3], c1[1], c1[3]};
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const float c = csr[ch * 8 + 2 * j], sn = csr[ch * 8 + 2 * j + 1];
                         const float a = f[2 * j], b = f[2 * j + 1];
-                        f[2 * j] = a * c + b * sn;
-                        f[2 * j + 1] = b * c - a * sn;
+                        f[2 * j] = a * cc[j] + b * sn[j];
+                        f[2 * j + 1] = b * cc[j] - a * sn[j];
                     }
                 }
                 if (dres) {
@@ -167,10 +180,22 @@ __global__ void __launch_bounds__(256) rotary_ln_bwd_kernel(const bf16_t* __rest
             }
         }
     }
+    // combine the four waves' partial sums (fixed order), one global atomic per channel per block
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int ch = lane + it * 64;
+        if (ch < nch) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                sm[(wave * 2 + 0) * C + ch * 8 + j] = ag[it * 8 + j];
+                sm[(wave * 2 + 1) * C + ch * 8 + j] = ab[it * 8 + j];
+            }
+        }
+    }
     __syncthreads();
     for (int i = threadIdx.x; i < C; i += 256) {
-        if (dgamma) atomicAdd(dgamma + i, sm[i]);
-        if (dbeta) atomicAdd(dbeta + i, sm[C + i]);
+        if (dgamma) atomicAdd(dgamma + i, sm[0 * C + i] + sm[2 * C + i] + sm[4 * C + i] + sm[6 * C + i]);
+        if (dbeta) atomicAdd(dbeta + i, sm[1 * C + i] + sm[3 * C + i] + sm[5 * C + i] + sm[7 * C + i]);
     }
 }
 
@@ -192,8 +217,8 @@ extern "C" int genie_rotary_layernorm_bwd(const void* x, const void* du, const v
     GENIE_CHECK_ARG(C % 8 == 0 && C <= 2048 && pitch >= C && pitch % 8 == 0, "genie_rotary_layernorm_bwd: bad C=%d / pitch", C);
     if (ntok == 0) return GENIE_OK;
     long long blocks = (ntok + 3) / 4;
-    if (blocks > 1024) blocks = 1024;
-    rotary_ln_bwd_kernel<<<(unsigned)blocks, 256, 2 * C * sizeof(float), (hipStream_t)stream>>>((const bf16_t*)x, (const bf16_t*)du, (const bf16_t*)dres, (bf16_t*)dx, ntok, C, pitch, cos_sin, pos_div, pos_mod, gamma, stats, dgamma, dbeta);
+    if (blocks > 2048) blocks = 2048;
+    rotary_ln_bwd_kernel<<<(unsigned)blocks, 256, 8 * C * sizeof(float), (hipStream_t)stream>>>((const bf16_t*)x, (const bf16_t*)du, (const bf16_t*)dres, (bf16_t*)dx, ntok, C, pitch, cos_sin, pos_div, pos_mod, gamma, stats, dgamma, dbeta);
     GENIE_CHECK_LAUNCH();
     return GENIE_OK;
 }

@@ -253,6 +253,7 @@ __global__ void __launch_bounds__(BM * 2) igemm3_kernel(const Igemm3Args p, cons
 // landed data to all waves (RAW) and fences the slot that the NEXT group overwrites (WAR: slot (k+4) & 3 = k & 3 was read in
 // K-tile k, the spare image was last read in K-tile 3i-1).
 // ------------------------------------------------------------------------------------------------------------------------------
+template <bool PRE>
 __global__ void __launch_bounds__(512) igemm3d_kernel(const Igemm3Args p, const GenieTriStep* __restrict__ steps) {
     constexpr int BM = 256, BN = 128, NT = 512, NWAVE = 8, WN = 2, TM = 2, TN = 2;
     constexpr int RPR = NT / 8, A_ROUNDS = 5;
@@ -381,38 +382,110 @@ __global__ void __launch_bounds__(512) igemm3d_kernel(const Igemm3Args p, const 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     raw_barrier();
 
-    int k = 0;                                          // K-tile index (3 i + s); weight tile k sits in slot k & 3
-    for (int i = 0; i < p.nsteps; ++i, k += 3) {
-        const GenieTriStep cur = steps[i];
-        const bool has_next = i + 1 < p.nsteps;
-        const GenieTriStep nxt = steps[has_next ? i + 1 : i];
-        char* const acur = A0 + (i & 1) * A_BYTES;
-        char* const anxt = A0 + ((i + 1) & 1) * A_BYTES;
-        // ---- s = 0: group = image rounds 0-2 of step i+1, then weight tile k+3 = (i+1, 0) ----
-        stage_a(nxt, has_next, 0, anxt);
-        stage_a(nxt, has_next, 1, anxt);
-        stage_a(nxt, has_next, 2, anxt);
-        __builtin_amdgcn_sched_barrier(0);              // the counted waits rely on this issue order
-        stage_b(nxt.wofs0, has_next, B0 + ((k + 3) & 3) * B_BYTES);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(acur, 0, B0 + (k & 3) * B_BYTES);
-        asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-        raw_barrier();
-        // ---- s = 1: image rounds 3, 4, then weight tile k+4 = (i+1, 1) ----
-        stage_a(nxt, has_next, 3, anxt);
-        stage_a(nxt, has_next, 4, anxt);
-        __builtin_amdgcn_sched_barrier(0);
-        stage_b(nxt.wofs1, has_next, B0 + ((k + 4) & 3) * B_BYTES);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(acur, 1, B0 + ((k + 1) & 3) * B_BYTES);
-        asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-        raw_barrier();
-        // ---- s = 2: weight tile k+5 = (i+1, 2); the new image must have landed before the barrier ----
-        stage_b(nxt.wofs2, has_next, B0 + ((k + 5) & 3) * B_BYTES);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(acur, 2, B0 + ((k + 2) & 3) * B_BYTES);
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        raw_barrier();
+    if constexpr (PRE) {
+        // Variant with the first k-step of the NEXT K-tile read before the barrier and the glds issued in the middle of the MFMA
+        // stream: after a barrier every wave starts on MFMAs it already holds operands for, instead of all eight issuing loads
+        // and then waiting an LDS round trip while the matrix pipes idle (SQ counters on the plain version: pipes 56 % busy,
+        // waves parked 37 % of their cycles).  Publication is one barrier earlier than consumption:
+        //   at the barrier ending K-tile k, weight tiles k+1 AND k+2 have landed (tile k+3 is issued during K-tile k), and at
+        //   s = 1 the image of the next step as well (all five rounds go out at s = 0) -- so the pre-read for K-tile k+1, issued
+        //   before that barrier, only touches data published at barrier k-1.
+        //   groups: s = 0: 5 image rounds then tile k+3 (7 glds), s = 1, 2: tile k+3 (2 glds); the wait at the end of K-tile k
+        //   leaves exactly group k in flight: vmcnt(7) / vmcnt(2) / vmcnt(2).
+        //   WAR: slot (k+3) & 3 = (k-1) & 3 was last read in K-tile k-1 (its pre-read targets slot k & 3); the spare image was last
+        //   read in K-tile 3i-1 and is refilled from K-tile 3i on.
+        bf16x8_t af0[TM], bf0[TN];
+        auto preread = [&](const char* abuf, int s, const char* bbuf) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af0[i] = *reinterpret_cast<const bf16x8_t*>(abuf + a_off[s][0][i]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf0[j] = *reinterpret_cast<const bf16x8_t*>(bbuf + b_off[0][j]);
+        };
+        auto mfma4 = [&](const bf16x8_t (&fa)[TM], const bf16x8_t (&fb)[TN]) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        };
+        auto read_ks = [&](const char* abuf, int s, const char* bbuf, int ks, bf16x8_t (&fa)[TM], bf16x8_t (&fb)[TN]) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8_t*>(abuf + a_off[s][ks][i]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const bf16x8_t*>(bbuf + b_off[ks][j]);
+        };
+        preread(A0, 0, B0);
+        int k = 0;
+        for (int i = 0; i < p.nsteps; ++i, k += 3) {
+            const bool has_next = i + 1 < p.nsteps;
+            const GenieTriStep nxt = steps[has_next ? i + 1 : i];
+            char* const acur = A0 + (i & 1) * A_BYTES;
+            char* const anxt = A0 + ((i + 1) & 1) * A_BYTES;
+#define GENIE_KTILE(S, ISSUE, NEXT_A, NEXT_S, WAITN)                                                              \
+            {                                                                                                    \
+                const char* bcur = B0 + ((k + S) & 3) * B_BYTES;                                                 \
+                const char* bnext = B0 + ((k + S + 1) & 3) * B_BYTES;                                            \
+                bf16x8_t fa1[TM], fb1[TN], fa2[TM], fb2[TN];                                                     \
+                read_ks(acur, S, bcur, 1, fa1, fb1);                                                             \
+                mfma4(af0, bf0);                                                                                 \
+                __builtin_amdgcn_sched_barrier(0);                                                               \
+                ISSUE                                                                                            \
+                __builtin_amdgcn_sched_barrier(0);                                                               \
+                read_ks(acur, S, bcur, 2, fa2, fb2);                                                             \
+                mfma4(fa1, fb1);                                                                                 \
+                __builtin_amdgcn_sched_barrier(0);                                                               \
+                read_ks(acur, S, bcur, 3, fa1, fb1);                                                             \
+                mfma4(fa2, fb2);                                                                                 \
+                __builtin_amdgcn_sched_barrier(0);                                                               \
+                preread(NEXT_A, NEXT_S, bnext);                                                                  \
+                mfma4(fa1, fb1);                                                                                 \
+                __builtin_amdgcn_sched_barrier(0);                                                               \
+                asm volatile("s_waitcnt vmcnt(" #WAITN ")" ::: "memory");                                        \
+                raw_barrier();                                                                                   \
+            }
+            GENIE_KTILE(0,
+                        stage_a(nxt, has_next, 0, anxt); stage_a(nxt, has_next, 1, anxt); stage_a(nxt, has_next, 2, anxt);
+                        stage_a(nxt, has_next, 3, anxt); stage_a(nxt, has_next, 4, anxt);
+                        __builtin_amdgcn_sched_barrier(0);
+                        stage_b(nxt.wofs0, has_next, B0 + ((k + 3) & 3) * B_BYTES);,
+                        acur, 1, 7)
+            GENIE_KTILE(1, stage_b(nxt.wofs1, has_next, B0 + ((k + 4) & 3) * B_BYTES);, acur, 2, 2)
+            GENIE_KTILE(2, stage_b(nxt.wofs2, has_next, B0 + ((k + 5) & 3) * B_BYTES);, anxt, 0, 2)
+#undef GENIE_KTILE
+        }
+    } else {
+        int k = 0;                                          // K-tile index (3 i + s); weight tile k sits in slot k & 3
+        for (int i = 0; i < p.nsteps; ++i, k += 3) {
+            const GenieTriStep cur = steps[i];
+            const bool has_next = i + 1 < p.nsteps;
+            const GenieTriStep nxt = steps[has_next ? i + 1 : i];
+            char* const acur = A0 + (i & 1) * A_BYTES;
+            char* const anxt = A0 + ((i + 1) & 1) * A_BYTES;
+            // ---- s = 0: group = image rounds 0-2 of step i+1, then weight tile k+3 = (i+1, 0) ----
+            stage_a(nxt, has_next, 0, anxt);
+            stage_a(nxt, has_next, 1, anxt);
+            stage_a(nxt, has_next, 2, anxt);
+            __builtin_amdgcn_sched_barrier(0);              // the counted waits rely on this issue order
+            stage_b(nxt.wofs0, has_next, B0 + ((k + 3) & 3) * B_BYTES);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(acur, 0, B0 + (k & 3) * B_BYTES);
+            asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+            raw_barrier();
+            // ---- s = 1: image rounds 3, 4, then weight tile k+4 = (i+1, 1) ----
+            stage_a(nxt, has_next, 3, anxt);
+            stage_a(nxt, has_next, 4, anxt);
+            __builtin_amdgcn_sched_barrier(0);
+            stage_b(nxt.wofs1, has_next, B0 + ((k + 4) & 3) * B_BYTES);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(acur, 1, B0 + ((k + 1) & 3) * B_BYTES);
+            asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+            raw_barrier();
+            // ---- s = 2: weight tile k+5 = (i+1, 2); the new image must have landed before the barrier ----
+            stage_b(nxt.wofs2, has_next, B0 + ((k + 5) & 3) * B_BYTES);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(acur, 2, B0 + ((k + 2) & 3) * B_BYTES);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            raw_barrier();
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     raw_barrier();
@@ -420,18 +493,19 @@ __global__ void __launch_bounds__(512) igemm3d_kernel(const Igemm3Args p, const 
     igemm_epilogue<BM, TM, TN>(a, acc, smem, m0, n0, wm, wn, tid, lane);
 }
 
+template <bool PRE>
 static int launch_igemm3d(const Igemm3Args& p, const GenieTriStep* steps, hipStream_t s) {
     constexpr int lds = 2 * (5 * 64 * 128) + 4 * 128 * 128;
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)igemm3d_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipError_t e = hipFuncSetAttribute((const void*)igemm3d_kernel<PRE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) {
             genie_set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e));
             return GENIE_ERR_HIP;
         }
         configured = true;
     }
-    hipLaunchKernelGGL(igemm3d_kernel, dim3(p.g.tiles_m * p.g.tiles_n), dim3(512), lds, s, p, steps);
+    hipLaunchKernelGGL(igemm3d_kernel<PRE>, dim3(p.g.tiles_m * p.g.tiles_n), dim3(512), lds, s, p, steps);
     GENIE_CHECK_LAUNCH();
     return GENIE_OK;
 }
@@ -490,7 +564,8 @@ int genie_conv_igemm3_try(const GenieConvDesc* d, IgemmArgs a, hipStream_t s) {
     p.dbg = d->tri_flags & ~3;
     const bool pipe = (d->tri_flags & 1) == 0;
     genie_note_variant(bm == 256 ? GENIE_VARIANT_IGEMM3_256 : GENIE_VARIANT_IGEMM3_128);
-    if (bm == 256 && (d->tri_flags & 2) == 0) return launch_igemm3d(p, d->tri_steps, s);     // deep-prefetch schedule
+    if (bm == 256 && (d->tri_flags & 2) == 0)                                                  // deep-prefetch schedules
+        return (d->tri_flags & 64) ? launch_igemm3d<false>(p, d->tri_steps, s) : launch_igemm3d<true>(p, d->tri_steps, s);
     if (bm == 256) return pipe ? launch_igemm3<256, true>(p, d->tri_steps, s) : launch_igemm3<256, false>(p, d->tri_steps, s);
     return pipe ? launch_igemm3<128, true>(p, d->tri_steps, s) : launch_igemm3<128, false>(p, d->tri_steps, s);
 }

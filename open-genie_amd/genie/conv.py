@@ -345,14 +345,33 @@ def conv_forward(x: Tensor, wpack: Tensor, bias: Optional[Tensor], spec: ConvSpe
     return out
 
 
+def _unshuffle(dy: Tensor, spec: ConvSpec, order: str) -> Tensor:
+    """Inverse of the depth-to-space-time rearrange on a gradient: (N, cf, T P, H Q, W R) -> CL (N, cf P Q R, T, H, W) with the
+    channels in natural '(c p q r)' order or in the sub-pixel-major '(p q r c)' order of the transposed weight pack.  Only the
+    slow path of upsample convs whose final channel count is not a multiple of 8 (e.g. REPR_TOK_DEC's 512 -> 3 x 16) uses it."""
+    from .cl import to_cl
+    P, Q, R = spec.shuffle
+    n, cf, tp, hq, wr = dy.shape
+    t, h, w = tp // P, hq // Q, wr // R
+    v = dy.reshape(n, cf, t, P, h, Q, w, R)
+    v = v.permute(0, 1, 3, 5, 7, 2, 4, 6) if order == 'cpqr' else v.permute(0, 3, 5, 7, 1, 2, 4, 6)
+    return to_cl(v.reshape(n, cf * P * Q * R, t, h, w).contiguous())
+
+
+def _plain(spec: ConvSpec) -> ConvSpec:
+    return ConvSpec(spec.cin, spec.cout, spec.kernel, spec.stride, spec.dilation, spec.pad_front, spec.pad_back, None)
+
+
 def conv_dgrad(dy: Tensor, wpack_bwd: Tensor, spec: ConvSpec, in_size: Triple, resid: Optional[Tensor] = None) -> Tensor:
     """Gradient w.r.t. the conv input.  dy is the CL gradient of the (shuffled) output."""
     _check_cl(dy, spec.cfinal, 'conv_dgrad')
+    if spec.shuffle is not None and spec.cfinal % 8 != 0:
+        # the gather through the shuffle wants whole 16-B channel chunks per sub-pixel: un-shuffle the gradient instead; the
+        # transposed pack of a shuffled conv is sub-pixel-major, so the plain conv over '(p q r c)' channels is the same GEMM
+        return conv_dgrad(_unshuffle(dy, spec, 'pqrc'), wpack_bwd, _plain(spec), in_size, resid)
     n = dy.shape[0]
     t, h, w = in_size
     P, Q, R = spec.shuffle if spec.shuffle is not None else (1, 1, 1)
-    if spec.shuffle is not None and spec.cfinal % 8 != 0:
-        raise NotImplementedError('conv_dgrad through a depth-to-space shuffle needs out_channels % 8 == 0')
     dx = empty_cl(n, spec.cin, t, h, w, dy.device)
     lib = _hip.load_library()
     st = spec.stride
@@ -404,6 +423,8 @@ def conv_wgrad(x: Tensor, dy: Tensor, spec: ConvSpec, dweight: Tensor, dbias: Op
     """Accumulate dW (fp32, any strides, shape (cout, cin, kt, kh, kw)) and dbias (fp32 [cout])."""
     _check_cl(x, spec.cin, 'conv_wgrad(x)')
     _check_cl(dy, spec.cfinal, 'conv_wgrad(dy)')
+    if spec.shuffle is not None and spec.cfinal % 8 != 0:
+        return conv_wgrad(x, _unshuffle(dy, spec, 'cpqr'), _plain(spec), dweight, dbias)
     n, _, t, h, w = x.shape
     to, ho, wo = spec.out_size((t, h, w))
     P, Q, R = spec.shuffle if spec.shuffle is not None else (1, 1, 1)

@@ -86,8 +86,12 @@ class _Conv3dFn(torch.autograd.Function):
         need_w = ctx.needs_input_grad[1]
         need_b = bias is not None and ctx.needs_input_grad[2]
         if need_w or need_b:
-            if DIRECT_PARAM_GRADS and weight.is_leaf and (bias is None or bias.is_leaf):
-                gw = _grad_buffer(weight)
+            # a (V, D, 1, 1, 1) view of an nn.Linear weight (the Dynamics vocabulary head) accumulates into the Linear's gradient
+            wleaf = weight if weight.is_leaf else getattr(weight, '_base', None)
+            linear_view = (wleaf is not weight and wleaf is not None and wleaf.dim() == 2 and wleaf.is_contiguous()
+                           and tuple(weight.shape) == (*wleaf.shape, 1, 1, 1))
+            if DIRECT_PARAM_GRADS and wleaf is not None and wleaf.is_leaf and (wleaf is weight or linear_view) and (bias is None or bias.is_leaf):
+                gw = _grad_buffer(wleaf).view(weight.shape) if wleaf is not weight else _grad_buffer(weight)
                 gb = _grad_buffer(bias) if need_b else None
                 conv_wgrad(x, dy, op.spec, gw, gb)
             else:

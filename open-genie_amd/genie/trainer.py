@@ -92,25 +92,28 @@ class ParamArena:
                        'genie_cast_f32_to_bf16')
         by_id = {id(p): name for name, p in root.named_parameters()}
         managed, jobs, dst_total, blocks = [], [], 0, 0
+        cands = []                                     # (weight parameter, ConvOp, spec, (cout, cin, kt, kh, kw))
         for m in root.modules():
-            if not isinstance(m, Conv3d):
-                continue
-            w = m.weight
+            if isinstance(m, Conv3d):
+                cands.append((m.weight, m.op, m.spec, tuple(m.weight.shape)))
+            elif isinstance(getattr(m, 'head', None), nn.Linear) and hasattr(m, '_head_op'):
+                # DynamicsModel's vocabulary head: Linear(D -> V) run as the 1x1x1 case of the gather-GEMM
+                cands.append((m.head.weight, m._head_op, m._head_op.spec, (*m.head.weight.shape, 1, 1, 1)))
+        for w, op, spec, (cout, cin, kt, kh, kw) in cands:
             name = by_id.get(id(w))
             if name is None or name not in self.slots:
                 continue
-            cout, cin, kt, kh, kw = w.shape
             nt = kt * kh * kw
-            if cin % 8 != 0 or tuple(w.stride()) != (nt * cin, 1, kh * kw * cin, kw * cin, cin):
+            dense = tuple(w.stride()) == ((nt * cin, 1, kh * kw * cin, kw * cin, cin) if w.dim() == 5 else (cin, 1))
+            if cin % 8 != 0 or not dense:
                 continue
             off, n = self.slots[name]
-            spec = m.spec
             coutp = (cout + 7) & ~7
             perm_c, perm_f = (spec.cfinal, spec.shuffle[0] * spec.shuffle[1] * spec.shuffle[2]) if spec.shuffle is not None else (0, 1)
             tiles_r, tiles_k = (cout + 63) // 64, (cin + 63) // 64
             jobs.append((off, dst_total, cout, nt, cin, perm_c, perm_f, tiles_r, tiles_k, blocks))
             fwd = self.mirror[off:off + n].view(cout, nt, cin)
-            managed.append((m.op, w, fwd, dst_total, (cin, nt, coutp)))
+            managed.append((op, w, fwd, dst_total, (cin, nt, coutp)))
             dst_total += (cin * nt * coutp + 63) // 64 * 64
             blocks += tiles_r * nt * tiles_k
         if not managed:

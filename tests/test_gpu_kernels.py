@@ -200,10 +200,9 @@ def test_conv_shuffle_forward_dgrad(G, cin, cf, fac, size):
     wf = G.conv.pack_weight_fwd(wt.cuda(), spec)
     out = G.conv.conv_forward(G.cl.to_cl(x.cuda()), wf, b.cuda(), spec)
     assert_close_bf16(out, ref, 'shuffle fwd')
-    if cf % 8 == 0:
-        wb = G.conv.pack_weight_bwd(wt.cuda(), spec)
-        dx = G.conv.conv_dgrad(G.cl.to_cl(dy.cuda()), wb, spec, (t, h, w))
-        assert_close_bf16(dx, xr.grad, 'shuffle dgrad')
+    wb = G.conv.pack_weight_bwd(wt.cuda(), spec)          # cf % 8 != 0 takes the un-shuffle path
+    dx = G.conv.conv_dgrad(G.cl.to_cl(dy.cuda()), wb, spec, (t, h, w))
+    assert_close_bf16(dx, xr.grad, 'shuffle dgrad')
 
 
 TRI_CASES = [
@@ -361,7 +360,8 @@ def test_conv_wgrad_triple_kernel(G, cin, cout, kernel, causal, size, shuffle, m
     torch.testing.assert_close(dw.cpu(), 2 * wt.grad, rtol=1e-3, atol=2e-3 * wt.grad.abs().max().item())
 
 
-@pytest.mark.parametrize('cin,cf,fac,size', [(64, 32, (2, 2, 2), (1, 2, 4, 4)), (128, 64, (1, 2, 2), (2, 2, 3, 5)), (64, 256, (2, 2, 2), (1, 2, 4, 4))])
+@pytest.mark.parametrize('cin,cf,fac,size', [(64, 32, (2, 2, 2), (1, 2, 4, 4)), (128, 64, (1, 2, 2), (2, 2, 3, 5)), (64, 256, (2, 2, 2), (1, 2, 4, 4)),
+                                             (64, 3, (1, 4, 4), (1, 2, 4, 4))])
 def test_conv_shuffle_wgrad(G, cin, cf, fac, size):
     from oracle import genie_oracle as O
     torch.manual_seed(7)
