@@ -223,6 +223,16 @@ int genie_lfq_loss(const void* z, int dtype, int64_t ntok, int num_codebook, int
 int genie_lfq_bwd(const void* dy, const float* dz_loss, const float* grad_loss, void* out, int dtype, int64_t ntok, int width,
                   int64_t pitch, void* stream);
 
+/* Masked token cross-entropy over bf16 logits rows (lfq.hip).   replaces: logits[mask] + F.cross_entropy in
+ * DynamicsModel.compute_loss, dynamics.py:92-97.  logits: bf16 [nrow][pitch >= V]; target: int64 [nrow]; mask: uint8 [nrow] or
+ * NULL (= all rows).  fwd: row_lse[r] = logsumexp(row r) for masked rows, *loss_sum += sum over masked rows of
+ * (lse - logit[target]) (caller zeroes it and divides by the masked-row count).  bwd: dlogits = (softmax - onehot) * *scale on
+ * masked rows (scale = upstream gradient / count, device scalar), zeros elsewhere. */
+int genie_masked_ce_fwd(const void* logits_bf16, int64_t pitch, int64_t nrow, int V, const int64_t* target, const unsigned char* mask,
+                        float* row_lse, float* loss_sum, void* stream);
+int genie_masked_ce_bwd(const void* logits_bf16, int64_t pitch, int64_t nrow, int V, const int64_t* target, const unsigned char* mask,
+                        const float* row_lse, const float* scale, void* dlogits_bf16, int64_t dpitch, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Losses and optimiser (elementwise.hip).
  * replaces: F.mse_loss (tokenizer.py:364, action.py:166) and torch.optim.AdamW (tokenizer.py:437-442).

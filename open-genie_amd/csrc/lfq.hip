@@ -363,3 +363,105 @@ extern "C" int genie_lfq_bwd(const void* dy, const float* dz_loss, const float* 
     GENIE_CHECK_LAUNCH();
     return GENIE_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Masked token cross-entropy over bf16 logits rows (DynamicsModel.compute_loss, reference genie/dynamics.py:66-99: boolean-mask
+// gather of the logits, F.cross_entropy(mean)).  The reference path materialises the gathered rows, an fp32 copy, the softmax and
+// its backward and scatters the gradient back -- eight passes over up to 2 GiB at V = 2^18.  Here: forward = ONE read pass
+// (per-row log-sum-exp + the loss), backward = one read + one write pass producing d logits (zero rows where the mask is off).
+// One 256-thread block per row, grid-stride; 16-B loads.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float ce_block_max(float v, float* red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+__device__ __forceinline__ float ce_block_sum(float v, float* red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ void __launch_bounds__(256) masked_ce_fwd_kernel(const bf16_t* __restrict__ logits, long long pitch, long long nrow, int V,
+                                                            const long long* __restrict__ target, const unsigned char* __restrict__ mask,
+                                                            float* __restrict__ row_lse, float* __restrict__ loss_sum) {
+    __shared__ float red[4];
+    const int nch = V >> 3;
+    for (long long r = blockIdx.x; r < nrow; r += gridDim.x) {
+        if (mask && !mask[r]) continue;                                  // block-uniform
+        const bf16_t* row = logits + r * pitch;
+        float m = -INFINITY, s = 0.f;                                    // online max / sum of exp per thread
+        for (int ch = threadIdx.x; ch < nch; ch += 256) {
+            float f[8];
+            unpack8(*reinterpret_cast<const u32x4_t*>(row + ch * 8), f);
+            float cm = f[0];
+#pragma unroll
+            for (int j = 1; j < 8; ++j) cm = fmaxf(cm, f[j]);
+            if (cm > m) { s *= __expf(m - cm); m = cm; }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += __expf(f[j] - m);
+        }
+        const float M = ce_block_max(m, red);
+        const float S = ce_block_sum(s * __expf(m - M), red);
+        if (threadIdx.x == 0) {
+            const float lse = M + __logf(S);
+            row_lse[r] = lse;
+            atomicAdd(loss_sum, lse - bf16_to_f32(row[target[r]]));
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) masked_ce_bwd_kernel(const bf16_t* __restrict__ logits, long long pitch, long long nrow, int V,
+                                                            const long long* __restrict__ target, const unsigned char* __restrict__ mask,
+                                                            const float* __restrict__ row_lse, const float* __restrict__ scale,
+                                                            bf16_t* __restrict__ dlogits, long long dpitch) {
+    const int nch = V >> 3;
+    const float sc = scale[0];
+    for (long long r = blockIdx.x; r < nrow; r += gridDim.x) {
+        bf16_t* drow = dlogits + r * dpitch;
+        if (mask && !mask[r]) {
+            const u32x4_t z = {0u, 0u, 0u, 0u};
+            for (int ch = threadIdx.x; ch < nch; ch += 256) *reinterpret_cast<u32x4_t*>(drow + ch * 8) = z;
+            continue;
+        }
+        const bf16_t* row = logits + r * pitch;
+        const float lse = row_lse[r];
+        const int tgt = (int)target[r];
+        for (int ch = threadIdx.x; ch < nch; ch += 256) {
+            float f[8];
+            unpack8(*reinterpret_cast<const u32x4_t*>(row + ch * 8), f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = (__expf(f[j] - lse) - ((ch * 8 + j) == tgt ? 1.f : 0.f)) * sc;
+            *reinterpret_cast<u32x4_t*>(drow + ch * 8) = pack8(f);
+        }
+    }
+}
+
+extern "C" int genie_masked_ce_fwd(const void* logits_bf16, int64_t pitch, int64_t nrow, int V, const int64_t* target,
+                                   const unsigned char* mask, float* row_lse, float* loss_sum, void* stream) {
+    GENIE_CHECK_ARG(logits_bf16 && target && row_lse && loss_sum, "genie_masked_ce_fwd: null pointer");
+    GENIE_CHECK_ARG(V >= 8 && V % 8 == 0 && pitch >= V && pitch % 8 == 0, "genie_masked_ce_fwd: V=%d / pitch must be multiples of 8", V);
+    if (nrow == 0) return GENIE_OK;
+    const unsigned grid = (unsigned)(nrow < 4096 ? nrow : 4096);
+    masked_ce_fwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((const bf16_t*)logits_bf16, pitch, nrow, V, (const long long*)target, mask, row_lse, loss_sum);
+    GENIE_CHECK_LAUNCH();
+    return GENIE_OK;
+}
+
+extern "C" int genie_masked_ce_bwd(const void* logits_bf16, int64_t pitch, int64_t nrow, int V, const int64_t* target,
+                                   const unsigned char* mask, const float* row_lse, const float* scale, void* dlogits_bf16,
+                                   int64_t dpitch, void* stream) {
+    GENIE_CHECK_ARG(logits_bf16 && target && row_lse && scale && dlogits_bf16, "genie_masked_ce_bwd: null pointer");
+    GENIE_CHECK_ARG(V >= 8 && V % 8 == 0 && pitch >= V && dpitch >= V && pitch % 8 == 0 && dpitch % 8 == 0, "genie_masked_ce_bwd: bad V / pitch");
+    if (nrow == 0) return GENIE_OK;
+    const unsigned grid = (unsigned)(nrow < 4096 ? nrow : 4096);
+    masked_ce_bwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((const bf16_t*)logits_bf16, pitch, nrow, V, (const long long*)target, mask, row_lse, scale, (bf16_t*)dlogits_bf16, dpitch);
+    GENIE_CHECK_LAUNCH();
+    return GENIE_OK;
+}

@@ -84,6 +84,8 @@ SIGNATURES = {
     'genie_lfq_loss_ws_floats': (C.c_int64, [_L, _I, _I]),
     'genie_lfq_loss': (C.c_int, [_P, _I, _L, _I, _I, _L, _F, _F, _F, _F, _P, _P, _P, _P]),
     'genie_lfq_bwd': (C.c_int, [_P, _P, _P, _P, _I, _L, _I, _L, _P]),
+    'genie_masked_ce_fwd': (C.c_int, [_P, _L, _L, _I, _P, _P, _P, _P, _P]),
+    'genie_masked_ce_bwd': (C.c_int, [_P, _L, _L, _I, _P, _P, _P, _P, _P, _L, _P]),
     'genie_mse_fwd': (C.c_int, [_P, _I, _P, _I, _PL, _PL, _P, _P, _P]),
     'genie_mse_bwd': (C.c_int, [_P, _I, _P, _I, _PL, _PL, _P, _P, _P]),
     'genie_adamw_step': (C.c_int, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _I, _P]),

@@ -70,9 +70,14 @@ class DynamicsModel(nn.Module):
         tokens = torch.masked_fill(tokens, mask, fill)
         logits, _ = self(tokens, act_id.detach())
         m = mask.squeeze()
-        logits = logits[m]
-        target = tokens[m]
-        return torch.nn.functional.cross_entropy(logits.reshape(-1, logits.shape[-1]).float(), target.reshape(-1))
+        if m.shape != tokens.shape:
+            # batch 1: the reference's mask.squeeze() drops the batch axis and its boolean indexing misbehaves; same code, same fate
+            logits = logits[m]
+            target = tokens[m]
+            return torch.nn.functional.cross_entropy(logits.reshape(-1, logits.shape[-1]).float(), target.reshape(-1))
+        # logits[m] / tokens[m] / cross_entropy(mean) of the reference, without materialising the gathered rows, their fp32 copy,
+        # the softmax and its backward: one fused pass forward, one backward (genie_masked_ce_fwd / _bwd)
+        return GF.masked_cross_entropy(logits, tokens, m)
 
     @torch.no_grad()
     def generate(self, tokens: Tensor, act_id: Tensor, steps: int = 10, which: Literal['linear', 'cosine', 'arccos'] = 'linear',

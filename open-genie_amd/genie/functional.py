@@ -324,3 +324,45 @@ class _LfqFn(torch.autograd.Function):
 
 def lfq_rows(z2d: Tensor, ncb: int, d: int, training: bool, beta: float, commit_w: float, ent_w: float, div_w: float):
     return _LfqFn.apply(z2d, ncb * d, ncb, d, training, beta, commit_w, ent_w, div_w)
+
+
+# ------------------------------------------------------------------------------------------------
+# Masked token cross-entropy over bf16 logits (DynamicsModel.compute_loss)
+# ------------------------------------------------------------------------------------------------
+class _MaskedCEFn(torch.autograd.Function):
+    """logits: (..., V) bf16 whose rows are contiguous (row pitch = stride of the last-but-one dim); target / mask: (...)."""
+
+    @staticmethod
+    def forward(ctx, logits: Tensor, target: Tensor, mask: Optional[Tensor]):
+        lib = _hip.load_library()
+        v = logits.shape[-1]
+        rows = logits.numel() // v
+        lg = logits.reshape(rows, v)                       # a view for the (B, T, H, W, V) permutation of a CL tensor
+        if lg.stride(1) != 1 or lg.dtype != torch.bfloat16:
+            raise ValueError('masked_cross_entropy: logits rows must be contiguous bf16')
+        tgt = target.reshape(rows).to(torch.int64).contiguous()
+        mk = None if mask is None else mask.reshape(rows).to(torch.uint8).contiguous()
+        lse = torch.empty(rows, dtype=torch.float32, device=logits.device)
+        acc = torch.zeros(1, dtype=torch.float32, device=logits.device)
+        _hip.check(lib.genie_masked_ce_fwd(lg.data_ptr(), lg.stride(0), rows, v, tgt.data_ptr(), _hip.ptr(mk), lse.data_ptr(), acc.data_ptr(),
+                                           _hip.stream_ptr()), 'genie_masked_ce_fwd')
+        count = (mk.sum(dtype=torch.float32) if mk is not None else torch.full((), float(rows), device=logits.device)).reshape(1)
+        ctx.save_for_backward(lg, tgt, mk, lse, count)
+        ctx.shape = tuple(logits.shape)
+        return (acc / count).reshape(())
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        lg, tgt, mk, lse, count = ctx.saved_tensors
+        rows, v = lg.shape
+        scale = (g.float().reshape(1) / count).contiguous()
+        dl = torch.empty((rows, v), dtype=torch.bfloat16, device=lg.device)
+        _hip.check(_hip.load_library().genie_masked_ce_bwd(lg.data_ptr(), lg.stride(0), rows, v, tgt.data_ptr(), _hip.ptr(mk), lse.data_ptr(),
+                                                           scale.data_ptr(), dl.data_ptr(), v, _hip.stream_ptr()), 'genie_masked_ce_bwd')
+        return dl.reshape(ctx.shape), None, None
+
+
+def masked_cross_entropy(logits: Tensor, target: Tensor, mask: Optional[Tensor] = None) -> Tensor:
+    """mean over the rows where `mask` is set of -log softmax(logits)[target]  (= F.cross_entropy(logits[mask], target[mask]))."""
+    _hip.require_gpu(logits, 'masked_cross_entropy')
+    return _MaskedCEFn.apply(logits, target, mask)

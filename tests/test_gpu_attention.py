@@ -235,3 +235,26 @@ def test_attention_core_kernels(nseq, nhead, dh, sq, sk, causal, cross):
             assert rel_rms(got, want) < 2e-2, (nm, rel_rms(got, want))
     else:
         assert rel_rms(dq, qr.grad) < 2e-2, rel_rms(dq, qr.grad)
+
+
+@pytest.mark.parametrize('rows,v,masked', [(37, 256, True), (16, 1000, True), (9, 1 << 14, False), (64, 8, True)])
+def test_masked_cross_entropy_kernel(rows, v, masked):
+    """genie_masked_ce_fwd / _bwd == F.cross_entropy(logits[mask].float(), target[mask]) and its autograd (dynamics.py:92-97)."""
+    from genie import functional as GF
+    torch.manual_seed(31)
+    logits = (torch.randn(rows, v) * 3).to(torch.bfloat16)
+    target = torch.randint(0, v, (rows,))
+    mask = (torch.rand(rows) < 0.6) if masked else None
+    if masked:
+        mask[0] = True
+    lr = logits.float().requires_grad_(True)
+    sel = mask if masked else torch.ones(rows, dtype=torch.bool)
+    ref = torch.nn.functional.cross_entropy(lr[sel], target[sel])
+    (ref * 1.7).backward()
+    ld = logits.cuda().requires_grad_(True)
+    loss = GF.masked_cross_entropy(ld, target.cuda(), mask.cuda() if masked else None)
+    assert abs(loss.item() - ref.item()) < 1e-4 * abs(ref.item()) + 1e-5, (loss.item(), ref.item())
+    (loss * 1.7).backward()
+    got, want = ld.grad.float().cpu(), lr.grad
+    assert (got[~sel] == 0).all()
+    assert (got - want).abs().max().item() <= 2 ** -8 * want.abs().max().item() + 1e-8      # one bf16 rounding of the gradient
