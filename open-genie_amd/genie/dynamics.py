@@ -90,14 +90,15 @@ class DynamicsModel(nn.Module):
         tok_id = torch.cat([tokens, code.reshape(b, 1, h, w)], dim=1)
         act = torch.cat([act_id, mock], dim=1)
         pred_tok = tok_id
-        for step, num_tokens in enumerate(schedule.tolist()):
-            if step > 0 and not bool(mask.any()):
+        remaining = h * w          # masked positions per sample, tracked on the HOST: every step paints exactly `num_tokens` of them
+        for step, num_tokens in enumerate(schedule.tolist()):     # (the schedule is a CPU tensor: no device sync here either)
+            if remaining <= 0:     # the reference's `if mask.sum() == 0: break` (dynamics.py:133) without its device->host sync
                 break
+            remaining -= num_tokens
             _, logits = self(tok_id, act)
             prob = torch.softmax(logits.float() / temp, dim=-1).reshape(b * h * w, -1)
             pred = sample_from_uniform(prob, uniforms[step].to(prob.device)) if uniforms is not None else torch.multinomial(prob, num_samples=1).squeeze(-1)
-            conf = prob.gather(-1, pred[:, None]).reshape(b, h * w).clone()
-            conf[~mask] = -inf
+            conf = prob.gather(-1, pred[:, None]).reshape(b, h * w).masked_fill(~mask, -inf)      # (boolean index_put would sync)
             idxs = torch.topk(conf, k=num_tokens, dim=-1).indices
             vals = pred.reshape(b, -1).gather(-1, idxs).to(code.dtype)
             code.scatter_(1, idxs, vals)
