@@ -391,7 +391,11 @@ def conv_dgrad(dy: Tensor, wpack_bwd: Tensor, spec: ConvSpec, in_size: Triple, r
                 d.src, d.wgt, d.dst = dy.data_ptr(), wpack_bwd.data_ptr(), dx.data_ptr()
                 d.resid = _hip.ptr(resid)
                 d.bias = None
-                d.taps, d.ntaps, d.nk, d.small_c = taps.data_ptr(), ntaps, nk, 0
+                d.taps, d.ntaps, d.nk = taps.data_ptr(), ntaps, nk
+                # narrow gradients (head conv: 3 -> pitch 8 channels): pack the taps back to back inside 64-wide K chunks instead of
+                # giving each tap its own, mostly empty, chunk.  Needs the complete tap list in pack order: stride 1, no shuffle.
+                d.small_c = 1 if (st == (1, 1, 1) and spec.shuffle is None and spec.coutp in (8, 16, 32) and ntaps <= 32
+                                  and pitch_of(dy) == spec.coutp) else 0
                 d.N, d.Ts, d.Hs, d.Ws, d.Cs = n, dy.shape[2], dy.shape[3], dy.shape[4], pitch_of(dy)
                 d.To, d.Ho, d.Wo = ao, bo, co
                 d.st, d.sh, d.sw = P, Q, R
