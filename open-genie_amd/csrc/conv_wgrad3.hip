@@ -361,6 +361,10 @@ int genie_conv_wgrad3_try(const GenieWgradDesc* d, hipStream_t s) {
             if (cand >= 1 && a.nchunks / cand >= 32) sk = cand;
         }
         if (sk == 0) sk = 1;
+        if (base * sk < 200) {                           // small problem: fill the chip even at 16 chunks per block
+            const int want = (int)((256 + base - 1) / base);
+            if (a.nchunks / want >= 16) sk = want;
+        }
         if (d->tri_mode == 1 && (base * sk < 200 || a.nchunks / sk < 16)) return 1;      // too little work: generic kernel (tri_mode 2 forces)
     }
     a.chunks_per_split = cdiv(a.nchunks, sk);
