@@ -118,6 +118,7 @@ def main():
     ap.add_argument('--batch', type=int, default=int(os.environ.get('GENIE_BENCH_BATCH', 8)), help='clips per GPU per step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-events', action='store_true')
+    ap.add_argument('--all-kernel-events', action='store_true', help='HIP events around EVERY conv launch (full conv_kernels table; costs ~4 %% of the step)')
     ap.add_argument('--dump', type=str, default='')
     args = ap.parse_args()
 
@@ -160,7 +161,7 @@ def main():
     torch.cuda.synchronize()
     prof = None
     if not args.no_kernel_events:
-        prof = gconv.PROFILER = gconv.LaunchProfiler()
+        prof = gconv.PROFILER = gconv.LaunchProfiler(only_triple=not args.all_kernel_events and not args.dump)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()

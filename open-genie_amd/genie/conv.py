@@ -30,8 +30,11 @@ class LaunchProfiler:
     """Optional per-launch HIP-event timing of the conv kernels (bench.py's roofline leg).  Events are recorded
     on the stream the kernels are launched on; nothing is synchronised until ``summary()``."""
 
-    def __init__(self) -> None:
+    def __init__(self, only_triple: bool = False) -> None:
         self.records = []          # (variant, label, flops, start_event, end_event)
+        # only_triple: time only the forward / backward-data launches that carry a kw-triple schedule (the dominant kernel).
+        # Two events around each of the ~360 conv launches of a step cost ~4 % of the step; around these ~100, under 1 %.
+        self.only_triple = only_triple
 
     def begin(self):
         ev = torch.cuda.Event(enable_timing=True)
@@ -336,7 +339,7 @@ def conv_forward(x: Tensor, wpack: Tensor, bias: Optional[Tensor], spec: ConvSpe
         sched = tri_schedule(('fwd', spec), _fwd_tap_list(spec), h, w, pitch_of(x))
         if sched is not None:
             d.tri_steps, d.n_tri_steps = sched[0].data_ptr(), sched[1]
-    t0 = PROFILER.begin() if PROFILER is not None else None
+    t0 = PROFILER.begin() if PROFILER is not None and (d.n_tri_steps > 0 or not PROFILER.only_triple) else None
     _hip.check(_hip.load_library().genie_conv_igemm(C.byref(d), _hip.stream_ptr()), 'genie_conv_igemm(fwd)')
     if t0 is not None:
         flops = 2.0 * n * to * ho * wo * spec.cout * spec.cin * spec.ntaps
@@ -376,7 +379,9 @@ def conv_dgrad(dy: Tensor, wpack_bwd: Tensor, spec: ConvSpec, in_size: Triple, r
     lib = _hip.load_library()
     st = spec.stride
     first = True
-    t0 = PROFILER.begin() if PROFILER is not None else None
+    tri_ok = (TRI_BM >= 0 and st == (1, 1, 1) and spec.shuffle is None and tuple(dy.shape[2:]) == (t, h, w) and pitch_of(dy) % 64 == 0
+              and spec.kernel[2] == 3)
+    t0 = PROFILER.begin() if PROFILER is not None and (tri_ok or not PROFILER.only_triple) else None
     for rt in range(st[0]):
         for rh in range(st[1]):
             for rw in range(st[2]):
@@ -455,7 +460,7 @@ def conv_wgrad(x: Tensor, dy: Tensor, spec: ConvSpec, dweight: Tensor, dbias: Op
     d.split_k = FORCE_SPLIT_K
     d.tri_mode = TRI_WGRAD if (TRI_WGRAD and spec.stride == (1, 1, 1) and spec.kernel[2] == 3 and spec.dilation[2] == 1
                        and spec.pad_front[2] == 1 and spec.pad_back[2] == 1 and (to, ho, wo) == (t, h, w)) else 0
-    t0 = PROFILER.begin() if PROFILER is not None else None
+    t0 = PROFILER.begin() if PROFILER is not None and not PROFILER.only_triple else None
     _hip.check(_hip.load_library().genie_conv_wgrad(C.byref(d), _hip.stream_ptr()), 'genie_conv_wgrad')
     if t0 is not None:
         flops = 2.0 * n * to * ho * wo * spec.cout * spec.cin * spec.ntaps

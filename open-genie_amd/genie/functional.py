@@ -21,6 +21,7 @@ from .cl import empty_like_cl, is_cl, pitch_of, to_cl
 from .conv import ConvSpec, conv_dgrad, conv_forward, conv_wgrad, pack_weight_bwd, pack_weight_fwd
 
 DIRECT_PARAM_GRADS = True
+FUSED_RESBLOCK = __import__('os').environ.get('GENIE_FUSED_RESBLOCK', '1') != '0'    # VideoResidualBlock as one autograd node
 
 _ws_cache = {}
 
@@ -366,3 +367,87 @@ def masked_cross_entropy(logits: Tensor, target: Tensor, mask: Optional[Tensor] 
     """mean over the rows where `mask` is set of -log softmax(logits)[target]  (= F.cross_entropy(logits[mask], target[mask]))."""
     _hip.require_gpu(logits, 'masked_cross_entropy')
     return _MaskedCEFn.apply(logits, target, mask)
+
+
+# ------------------------------------------------------------------------------------------------
+# VideoResidualBlock as ONE autograd node (reference video.py:588-648, the default configuration: GroupNorm + swish, no
+# downsampling):   out = conv_b(act(GN2(conv_a(act(GN1(x)))))) + conv_r(x)
+# Same kernels as the module-by-module composition; what the fusion buys is the backward of the fan-out at x: the 1x1x1
+# residual conv's backward-data pass takes the main branch's input gradient as its epilogue addend, so autograd never runs a
+# separate bf16 add over the activation (43 of them per step in the MAGVIT2 tokenizer).
+# ------------------------------------------------------------------------------------------------
+def _gn_fwd_raw(x: Tensor, gamma: Tensor, beta: Tensor, groups: int, eps: float, act: int):
+    n, c, t, h, w = x.shape
+    lib = _hip.load_library()
+    y = empty_like_cl(x)
+    mean = torch.empty(n * groups, dtype=torch.float32, device=x.device)
+    rstd = torch.empty_like(mean)
+    ws = workspace(lib.genie_groupnorm_ws_floats(n, c, groups), x.device, 'gn')
+    P = _hip.ptr
+    _hip.check(lib.genie_groupnorm_fwd(P(x), P(y), n, t * h * w, c, pitch_of(x), groups, P(gamma), P(beta), None, None, eps, act, P(mean), P(rstd),
+                                       P(ws), _hip.stream_ptr()), 'genie_groupnorm_fwd')
+    return y, mean, rstd
+
+
+def _gn_bwd_raw(x: Tensor, dy: Tensor, gamma: Tensor, beta: Tensor, mean: Tensor, rstd: Tensor, groups: int, act: int) -> Tensor:
+    """dx; the parameter gradients accumulate into gamma.grad / beta.grad."""
+    n, c, t, h, w = x.shape
+    lib = _hip.load_library()
+    dx = empty_like_cl(x)
+    ws = workspace(lib.genie_groupnorm_ws_floats(n, c, groups), x.device, 'gn')
+    P = _hip.ptr
+    _hip.check(lib.genie_groupnorm_bwd(P(x), P(dy), P(dx), n, t * h * w, c, pitch_of(x), groups, P(gamma), P(beta), None, None, act, P(mean), P(rstd),
+                                       P(_grad_buffer(gamma)), P(_grad_buffer(beta)), None, None, P(ws), _hip.stream_ptr()), 'genie_groupnorm_bwd')
+    return dx
+
+
+class _ResBlockFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, g1w, g1b, wa, ba, g2w, g2b, wb, bb, wr, br, ops, groups: int, eps1: float, eps2: float):
+        op_a, op_b, op_r = ops
+        xn, m1, r1 = _gn_fwd_raw(x, g1w, g1b, groups, eps1, 1)
+        h1 = conv_forward(xn, op_a.pack_fwd(wa), ba, op_a.spec)
+        hn, m2, r2 = _gn_fwd_raw(h1, g2w, g2b, groups, eps2, 1)
+        r = conv_forward(x, op_r.pack_fwd(wr), br, op_r.spec)
+        out = conv_forward(hn, op_b.pack_fwd(wb), bb, op_b.spec, resid=r)
+        ctx.ops, ctx.groups = ops, groups
+        ctx.size = tuple(x.shape[2:])
+        ctx.save_for_backward(x, xn, h1, hn, m1, r1, m2, r2, g1w, g1b, wa, ba, g2w, g2b, wb, bb, wr, br)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        x, xn, h1, hn, m1, r1, m2, r2, g1w, g1b, wa, ba, g2w, g2b, wb, bb, wr, br = ctx.saved_tensors
+        op_a, op_b, op_r = ctx.ops
+        dy = to_cl(dy)
+        gb = lambda b: _grad_buffer(b) if b is not None else None
+        d_hn = conv_dgrad(dy, op_b.pack_bwd(wb), op_b.spec, ctx.size)
+        conv_wgrad(hn, dy, op_b.spec, _grad_buffer(wb), gb(bb))
+        d_h1 = _gn_bwd_raw(h1, d_hn, g2w, g2b, m2, r2, ctx.groups, 1)
+        del d_hn
+        d_xn = conv_dgrad(d_h1, op_a.pack_bwd(wa), op_a.spec, ctx.size)
+        conv_wgrad(xn, d_h1, op_a.spec, _grad_buffer(wa), gb(ba))
+        del d_h1
+        conv_wgrad(x, dy, op_r.spec, _grad_buffer(wr), gb(br))
+        dx = None
+        if ctx.needs_input_grad[0]:
+            d_xm = _gn_bwd_raw(x, d_xn, g1w, g1b, m1, r1, ctx.groups, 1)
+            dx = conv_dgrad(dy, op_r.pack_bwd(wr), op_r.spec, ctx.size, resid=d_xm)      # dgrad of the 1x1x1 conv + main-branch gradient
+        return (dx,) + (None,) * 14
+
+
+def residual_block(x: Tensor, norm1, conv_a, norm2, conv_b, conv_r) -> Optional[Tensor]:
+    """Fused VideoResidualBlock when every piece is in the standard form (fp32 leaf parameters, direct gradient accumulation);
+    returns None when the caller must fall back to the module-by-module composition."""
+    params = [norm1.weight, norm1.bias, conv_a.weight, conv_a.bias, norm2.weight, norm2.bias, conv_b.weight, conv_b.bias, conv_r.weight, conv_r.bias]
+    if not FUSED_RESBLOCK or not DIRECT_PARAM_GRADS or not torch.is_grad_enabled():
+        return None
+    for p in params:
+        if p is not None and not (p.is_leaf and p.requires_grad and p.dtype == torch.float32):
+            return None
+    if any(p is None for p in (norm1.weight, norm1.bias, norm2.weight, norm2.bias)) or norm1.num_groups != norm2.num_groups:
+        return None
+    if not (norm1.weight.is_contiguous() and norm2.weight.is_contiguous()):
+        return None
+    return _ResBlockFn.apply(to_cl(x), norm1.weight, norm1.bias, conv_a.weight, conv_a.bias, norm2.weight, norm2.bias, conv_b.weight, conv_b.bias,
+                             conv_r.weight, conv_r.bias, (conv_a.op, conv_b.op, conv_r.op), norm1.num_groups, norm1.eps, norm2.eps)
