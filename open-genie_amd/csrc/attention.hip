@@ -14,6 +14,7 @@
 //   permutation, which is exactly what two ds_read_b64_tr_b16 per fragment deliver:
 //   O^T[d][query]   = mfma(A = V^T (transposing LDS reads), B = P^T (registers))
 // One wave = 32 queries; a workgroup of 1..4 waves shares the K/V tiles (64 keys) in LDS.
+#include <type_traits>
 #include "common.h"
 #include "genie_hip.h"
 
@@ -27,6 +28,28 @@ static __device__ __attribute__((aligned(256))) uint32_t g_zero_page_a[64];
 __device__ __forceinline__ bf16x4_t attn_tr16(uint32_t lds_addr) {
     bf16x4_t v;
     asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(lds_addr));
+    return v;
+}
+// 16-B chunk `chunk` of LDS row `row` (CPR chunks per row) lives at slot attn_swz<CPR>(row, chunk).  The key is a bijection of the
+// low row bits, so the 32-row ds_read_b128 fragment reads stay conflict-free, and its bit pattern also separates the four
+// consecutive rows of a transposing ds_read_b64_tr_b16 group (rows r and r + 2 of a 128-B-pitch tile share banks otherwise:
+// the first version's (row >> 1) & 7 key cost 31 % of the LDS cycles in conflicts, SQ_LDS_BANK_CONFLICT).
+template <int CPR>
+__device__ __forceinline__ int attn_swz(int row, int chunk) {
+    if (CPR == 16) return chunk ^ (((row & 3) << 2) | ((row >> 2) & 3));
+    if (CPR == 8) return chunk ^ ((((row >> 1) & 1) << 2) | ((row >> 2) & 3));
+    if (CPR == 4) return chunk ^ ((row >> 2) & 3);
+    return chunk;
+}
+
+template <int IMM>
+__device__ __forceinline__ bf16x4_t attn_tr16i(uint32_t lds_addr) {      // same read with a compile-time byte offset
+    bf16x4_t v;
+    if constexpr (IMM <= 65535) {                                        // fits the 16-bit offset field
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "i"(IMM));
+    } else {
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(lds_addr + (uint32_t)IMM));
+    }
     return v;
 }
 __device__ __forceinline__ uint32_t attn_lds_offset(const void* p) {
@@ -275,11 +298,7 @@ __global__ void __launch_bounds__(64 * NW) attn_fwd_kernel(const AttnArgs a) {
     const int h = lane >> 5;
     const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page_a);
 
-    auto swz = [&](int row, int chunk) -> int {   // 16-B chunk inside an LDS row (bank-conflict-free ds_read_b128 over 32 rows)
-        if (CPR >= 8) return chunk ^ ((row >> 1) & 7);
-        if (CPR == 4) return chunk ^ ((row >> 2) & 3);
-        return chunk;
-    };
+    auto swz = [&](int row, int chunk) -> int { return attn_swz<CPR>(row, chunk); };
 
     // Q fragments (B operand): Q[query][16 ks + 8 h .. + 7]
     bf16x8_t qf[KS];
@@ -345,44 +364,65 @@ __global__ void __launch_bounds__(64 * NW) attn_fwd_kernel(const AttnArgs a) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     }
-    int buf = 0;
-    for (int t = 0; t < ntile; ++t) {
+    // loop-invariant LDS offsets (inside a stage) of every fragment read: the tile loop is unrolled over the three ring slots so
+    // that the slot base is an immediate -- per tile the wave issues no address arithmetic at all (the first version spent
+    // 20 VALU instructions per MFMA, most of them here; SQ_INSTS_VALU / SQ_INSTS_MFMA)
+    uint32_t k_off[2][KS], v_off[2][2][DT][2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+        const int row = kt * 32 + (lane & 31);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) k_off[kt][ks] = (uint32_t)(row * ROWB + (swz(row, ks * 2 + h) << 4));
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int r0 = kt * 32 + 16 * s2 + 4 * (g16 >> 1) + rr, r1 = r0 + 8;
+#pragma unroll
+            for (int d = 0; d < DT; ++d) {
+                const int col = d * 32 + 16 * (g16 & 1) + 4 * qq;
+                v_off[kt][s2][d][0] = (uint32_t)(r0 * ROWB + (swz(r0, col >> 3) << 4) + (col & 7) * 2);
+                v_off[kt][s2][d][1] = (uint32_t)(r1 * ROWB + (swz(r1, col >> 3) << 4) + (col & 7) * 2);
+            }
+        }
+    }
+    const uint32_t smem_off = attn_lds_offset(smem);
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int d = 0; d < DT; ++d) { v_off[kt][s2][d][0] += smem_off; v_off[kt][s2][d][1] += smem_off; }
+
+    auto tile_body = [&](auto slot_c, int t) {
+        constexpr int SLOT = decltype(slot_c)::value;
+        constexpr int KBASE = SLOT * STAGE, VBASE = KVSAME ? KBASE : KBASE + TILE;
         const int k0 = t * KT;
-        stage(t + 2, buf == 0 ? 2 : buf - 1);                // slot of tile t - 1 (every wave is past the barrier behind it)
-        const char* ktile = smem + buf * STAGE;
-        const char* vtile = KVSAME ? ktile : ktile + TILE;
+        stage(t + 2, SLOT == 0 ? 2 : SLOT - 1);               // slot of tile t - 1 (every wave is past the barrier behind it)
 
         // ---- S^T = K Q^T for two 32-key tiles ----
         f32x16_t sacc[2];
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) sacc[kt][r] = 0.f;
-            const int row = kt * 32 + (lane & 31);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(ktile + row * ROWB + (swz(row, ks * 2 + h) << 4));
+                const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(smem + KBASE + k_off[kt][ks]);
                 sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[kt], 0, 0, 0);
             }
         }
-        // ---- V^T fragments: requested now (lane = 16 g + 4 r + q reads keys base + r, d columns 16 (g & 1) + 4 q .. + 3), they
-        //      land under the softmax arithmetic ----
+        __builtin_amdgcn_s_setprio(0);
+        // ---- V^T fragments: requested now, they land under the softmax arithmetic ----
         bf16x4_t vlo[2][2][DT], vhi[2][2][DT];
-        {
-            const uint32_t vbase = attn_lds_offset(vtile);
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
+        for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    const int r0 = kt * 32 + 16 * s2 + 4 * (g16 >> 1) + rr, r1 = r0 + 8;
+            for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-                    for (int d = 0; d < DT; ++d) {
-                        const int col = d * 32 + 16 * (g16 & 1) + 4 * qq;
-                        vlo[kt][s2][d] = attn_tr16(vbase + r0 * ROWB + (swz(r0, col >> 3) << 4) + (col & 7) * 2);
-                        vhi[kt][s2][d] = attn_tr16(vbase + r1 * ROWB + (swz(r1, col >> 3) << 4) + (col & 7) * 2);
-                    }
+                for (int d = 0; d < DT; ++d) {
+                    vlo[kt][s2][d] = attn_tr16i<VBASE>(v_off[kt][s2][d][0]);
+                    vhi[kt][s2][d] = attn_tr16i<VBASE>(v_off[kt][s2][d][1]);
                 }
-        }
         // ---- masks: only where the tile crosses the end of the keys or (causal) the diagonal of this wave's queries ----
         const bool edge = (k0 + KT > a.Sk) || (a.causal && k0 + KT - 1 > q0);
         if (edge) {
@@ -395,11 +435,19 @@ __global__ void __launch_bounds__(64 * NW) attn_fwd_kernel(const AttnArgs a) {
                 }
         }
         // ---- online softmax in the exp2 domain (lane-local + one cross-half exchange) ----
-        float tmax = sacc[0][0];
+        float tmax;
+        {   // 32 -> 1 with three-input maxima (v_max3_f32): 16 instructions instead of 32
+            float m3[11];
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sacc[kt][r]);
+            for (int g = 0; g < 10; ++g) {
+                const int e = 3 * g;
+                m3[g] = fmaxf(fmaxf(sacc[e >> 4][e & 15], sacc[(e + 1) >> 4][(e + 1) & 15]), sacc[(e + 2) >> 4][(e + 2) & 15]);
+            }
+            m3[10] = fmaxf(sacc[1][14], sacc[1][15]);
+            const float a0 = fmaxf(fmaxf(m3[0], m3[1]), m3[2]), a1 = fmaxf(fmaxf(m3[3], m3[4]), m3[5]);
+            const float a2 = fmaxf(fmaxf(m3[6], m3[7]), m3[8]), a3 = fmaxf(m3[9], m3[10]);
+            tmax = fmaxf(fmaxf(fmaxf(a0, a1), a2), a3);
+        }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
         const float m_new = fmaxf(m_run, tmax);
         if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0) {          // some lane's maximum moved: rescale (exact, alpha = 1 elsewhere)
@@ -427,6 +475,7 @@ __global__ void __launch_bounds__(64 * NW) attn_fwd_kernel(const AttnArgs a) {
         // ---- O^T += V^T P^T ----
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
@@ -443,11 +492,16 @@ __global__ void __launch_bounds__(64 * NW) attn_fwd_kernel(const AttnArgs a) {
                 }
             }
         }
+        __builtin_amdgcn_s_setprio(0);
         // tile t + 1 (issued one iteration ago) must have landed; the stage issued above stays in flight
         asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LPT) : "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        buf = buf == NSTAGE - 1 ? 0 : buf + 1;
+    };
+    for (int t = 0; t < ntile; t += 3) {
+        tile_body(std::integral_constant<int, 0>{}, t);
+        if (t + 1 < ntile) tile_body(std::integral_constant<int, 1>{}, t + 1);
+        if (t + 2 < ntile) tile_body(std::integral_constant<int, 2>{}, t + 2);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
@@ -596,11 +650,7 @@ __global__ void __launch_bounds__(64 * NW) attn_bwd_dq_kernel(const AttnBwdArgs 
     const int q0 = qtile * (32 * NW) + wave * 32;
     const int qi = q0 + (lane & 31), h = lane >> 5;
     const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page_a);
-    auto swz = [&](int row, int chunk) -> int {
-        if (CPR >= 8) return chunk ^ ((row >> 1) & 7);
-        if (CPR == 4) return chunk ^ ((row >> 2) & 3);
-        return chunk;
-    };
+    auto swz = [&](int row, int chunk) -> int { return attn_swz<CPR>(row, chunk); };
     bf16x8_t qf[KS], dof[KS];
     float lse2 = 0.f, D_q = 0.f;                  // lse * log2(e)
     {
@@ -774,11 +824,7 @@ __global__ void __launch_bounds__(64 * NW) attn_bwd_dkv_kernel(const AttnBwdArgs
     const int key0 = ktile_i * (32 * NW) + wave * 32;
     const int ki = key0 + (lane & 31), h = lane >> 5;
     const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page_a);
-    auto swz = [&](int row, int chunk) -> int {
-        if (CPR >= 8) return chunk ^ ((row >> 1) & 7);
-        if (CPR == 4) return chunk ^ ((row >> 2) & 3);
-        return chunk;
-    };
+    auto swz = [&](int row, int chunk) -> int { return attn_swz<CPR>(row, chunk); };
     bf16x8_t kf[KS], vf[KS];
     {
         const bool ok = ki < a.Sk;
