@@ -719,48 +719,57 @@ __global__ void __launch_bounds__(64 * NW) attn_bwd_dq_kernel(const AttnBwdArgs 
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     }
-    int buf = 0;
-    for (int t = 0; t < ntile; ++t) {
+    // loop-invariant fragment offsets; the tile loop is unrolled over the three ring slots so that the slot base is an immediate
+    uint32_t k_off[2][KS], t_off[2][2][DT][2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+        const int row = kt * 32 + (lane & 31);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) k_off[kt][ks] = (uint32_t)(row * ROWB + (swz(row, ks * 2 + h) << 4));
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int r0 = kt * 32 + 16 * s2 + 4 * (g16 >> 1) + rr, r1 = r0 + 8;
+#pragma unroll
+            for (int d = 0; d < DT; ++d) {
+                const int col = d * 32 + 16 * (g16 & 1) + 4 * qq;
+                t_off[kt][s2][d][0] = attn_lds_offset(smem) + (uint32_t)(r0 * ROWB + (swz(r0, col >> 3) << 4) + (col & 7) * 2);
+                t_off[kt][s2][d][1] = attn_lds_offset(smem) + (uint32_t)(r1 * ROWB + (swz(r1, col >> 3) << 4) + (col & 7) * 2);
+            }
+        }
+    }
+    auto tile_body = [&](auto slot_c, int t) {
+        constexpr int SLOT = decltype(slot_c)::value;
+        constexpr int KBASE = SLOT * STAGE, VBASE = KVSAME ? KBASE : KBASE + TILE;
         const int k0 = t * KT;
-        stage(t + 2, buf == 0 ? 2 : buf - 1);
-        const char* ktile = smem + buf * STAGE;
-        const char* vtile = KVSAME ? ktile : ktile + TILE;
+        stage(t + 2, SLOT == 0 ? 2 : SLOT - 1);
         f32x16_t sacc[2], pacc[2];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) { sacc[kt][r] = 0.f; pacc[kt][r] = 0.f; }
-            const int row = kt * 32 + (lane & 31);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const int off = row * ROWB + (swz(row, ks * 2 + h) << 4);
-                const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(ktile + off);
+                const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(smem + KBASE + k_off[kt][ks]);
                 sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[kt], 0, 0, 0);      // S^T
                 if (KVSAME) {
                     pacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, dof[ks], pacc[kt], 0, 0, 0); // dP^T (V == K)
                 } else {
-                    const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(vtile + off);
+                    const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(smem + VBASE + k_off[kt][ks]);
                     pacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks], pacc[kt], 0, 0, 0);
                 }
             }
         }
         // K^T fragments for dQ^T += K^T dS^T, requested before the element-wise phase
         bf16x4_t klo[2][2][DT], khi[2][2][DT];
-        {
-            const uint32_t kb = attn_lds_offset(ktile);
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
+        for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    const int r0 = kt * 32 + 16 * s2 + 4 * (g16 >> 1) + rr, r1 = r0 + 8;
+            for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-                    for (int d = 0; d < DT; ++d) {
-                        const int col = d * 32 + 16 * (g16 & 1) + 4 * qq;
-                        klo[kt][s2][d] = attn_tr16(kb + r0 * ROWB + (swz(r0, col >> 3) << 4) + (col & 7) * 2);
-                        khi[kt][s2][d] = attn_tr16(kb + r1 * ROWB + (swz(r1, col >> 3) << 4) + (col & 7) * 2);
-                    }
+                for (int d = 0; d < DT; ++d) {
+                    klo[kt][s2][d] = attn_tr16i<KBASE>(t_off[kt][s2][d][0]);
+                    khi[kt][s2][d] = attn_tr16i<KBASE>(t_off[kt][s2][d][1]);
                 }
-        }
         const bool edge = (k0 + KT > a.Sk) || (a.causal && k0 + KT - 1 > q0) || (q0 + 32 > a.Sq);
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
@@ -793,7 +802,11 @@ __global__ void __launch_bounds__(64 * NW) attn_bwd_dq_kernel(const AttnBwdArgs 
         asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LPT) : "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        buf = buf == 2 ? 0 : buf + 1;
+    };
+    for (int t = 0; t < ntile; t += 3) {
+        tile_body(std::integral_constant<int, 0>{}, t);
+        if (t + 1 < ntile) tile_body(std::integral_constant<int, 1>{}, t + 1);
+        if (t + 2 < ntile) tile_body(std::integral_constant<int, 2>{}, t + 2);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (qi < a.Sq) {
@@ -899,42 +912,51 @@ __global__ void __launch_bounds__(64 * NW) attn_bwd_dkv_kernel(const AttnBwdArgs
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     }
-    int buf = 0;
-    for (int t = 0; t < ntile; ++t) {
+    // loop-invariant fragment offsets; the tile loop is unrolled over the three ring slots so that the slot base is an immediate
+    uint32_t r_off[2][KS], t_off[2][2][DT][2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const int row = qt * 32 + (lane & 31);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) r_off[qt][ks] = (uint32_t)(row * ROWB + (swz(row, ks * 2 + h) << 4));
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int r0 = qt * 32 + 16 * s2 + 4 * (g16 >> 1) + rr, r1 = r0 + 8;
+#pragma unroll
+            for (int d = 0; d < DT; ++d) {
+                const int col = d * 32 + 16 * (g16 & 1) + 4 * qq;
+                t_off[qt][s2][d][0] = attn_lds_offset(smem) + (uint32_t)(r0 * ROWB + (swz(r0, col >> 3) << 4) + (col & 7) * 2);
+                t_off[qt][s2][d][1] = attn_lds_offset(smem) + (uint32_t)(r1 * ROWB + (swz(r1, col >> 3) << 4) + (col & 7) * 2);
+            }
+        }
+    }
+    auto tile_body = [&](auto slot_c, int t) {
+        constexpr int SLOT = decltype(slot_c)::value;
+        constexpr int QBASE = SLOT * STAGE, OBASE = QBASE + TILE;
         const int qs = q_begin + t * QT;
-        stage(t + 2, buf == 0 ? 2 : buf - 1);
-        const char* qtile_l = smem + buf * STAGE;
-        const char* dotile = qtile_l + TILE;
-        const float* lse_l = reinterpret_cast<const float*>(qtile_l + 2 * TILE);
+        stage(t + 2, SLOT == 0 ? 2 : SLOT - 1);
+        const float* lse_l = reinterpret_cast<const float*>(smem + QBASE + 2 * TILE);
         const float* D_l = lse_l + 64;
         const bool edge = (qs + QT > a.Sq) || (key0 + 32 > a.Sk) || (a.causal && key0 + 31 > qs);
-        const uint32_t qb = attn_lds_offset(qtile_l), db = attn_lds_offset(dotile);
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
             // dO^T / Q^T fragments of this 32-query half for dV^T += dO^T P and dK^T += Q^T dS, requested first: they land
             // under the S / dP products and the element-wise phase
             bf16x4_t dlo[2][DT], dhi[2][DT], qlo[2][DT], qhi[2][DT];
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const int r0 = qt * 32 + 16 * s2 + 4 * (g16 >> 1) + rr, r1 = r0 + 8;
+            for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
                 for (int d = 0; d < DT; ++d) {
-                    const int col = d * 32 + 16 * (g16 & 1) + 4 * qq;
-                    const uint32_t o0 = r0 * ROWB + (swz(r0, col >> 3) << 4) + (col & 7) * 2;
-                    const uint32_t o1 = r1 * ROWB + (swz(r1, col >> 3) << 4) + (col & 7) * 2;
-                    dlo[s2][d] = attn_tr16(db + o0); dhi[s2][d] = attn_tr16(db + o1);
-                    qlo[s2][d] = attn_tr16(qb + o0); qhi[s2][d] = attn_tr16(qb + o1);
+                    dlo[s2][d] = attn_tr16i<OBASE>(t_off[qt][s2][d][0]); dhi[s2][d] = attn_tr16i<OBASE>(t_off[qt][s2][d][1]);
+                    qlo[s2][d] = attn_tr16i<QBASE>(t_off[qt][s2][d][0]); qhi[s2][d] = attn_tr16i<QBASE>(t_off[qt][s2][d][1]);
                 }
-            }
             f32x16_t sacc, pacc, ds;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; pacc[r] = 0.f; }
-            const int row = qt * 32 + (lane & 31);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const int off = row * ROWB + (swz(row, ks * 2 + h) << 4);
-                const bf16x8_t qfr = *reinterpret_cast<const bf16x8_t*>(qtile_l + off);
-                const bf16x8_t dofr = *reinterpret_cast<const bf16x8_t*>(dotile + off);
+                const bf16x8_t qfr = *reinterpret_cast<const bf16x8_t*>(smem + QBASE + r_off[qt][ks]);
+                const bf16x8_t dofr = *reinterpret_cast<const bf16x8_t*>(smem + OBASE + r_off[qt][ks]);
                 sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr, kf[ks], sacc, 0, 0, 0);            // S[q][key]
                 pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dofr, vf[ks], pacc, 0, 0, 0);           // dP[q][key]
             }
@@ -979,7 +1001,11 @@ __global__ void __launch_bounds__(64 * NW) attn_bwd_dkv_kernel(const AttnBwdArgs
         asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LPT) : "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        buf = buf == 2 ? 0 : buf + 1;
+    };
+    for (int t = 0; t < ntile; t += 3) {
+        tile_body(std::integral_constant<int, 0>{}, t);
+        if (t + 1 < ntile) tile_body(std::integral_constant<int, 1>{}, t + 1);
+        if (t + 2 < ntile) tile_body(std::integral_constant<int, 2>{}, t + 2);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (ki < a.Sk) {
