@@ -269,6 +269,21 @@ struct AttnArgs {
     int kv_same;                // k == v tile (one LDS image)
 };
 
+// Epilogue staging.  In the MFMA C layout a lane holds 4 consecutive channels of ONE token row, so a direct store instruction
+// touches 32 different rows with 16 B each; measured on the T = 16 / S = 64 shapes, where the kernel is pure traffic, that
+// pattern ran at ~1.8 TB/s against 5.8 TB/s for whole 16-B chunks, 8 lanes per row.  Every kernel therefore hands its 32 x DH
+// wave tile back through LDS (fp32 where a residual / partner gradient is still to be added, so nothing is rounded twice).
+template <int DH>
+__device__ __forceinline__ void rows_put_f32(float* fl, int lr, int h, int dg, const f32x4_t f) {
+    *reinterpret_cast<f32x4_t*>(fl + lr * DH + ((dg ^ (lr & (DH / 8 - 1))) << 3) + 4 * h) = f;
+}
+template <int DH>
+__device__ __forceinline__ void rows_get_f32(const float* fl, int row, int c, float (&f)[8]) {
+    const float* src = fl + row * DH + ((c ^ (row & (DH / 8 - 1))) << 3);
+    const f32x4_t f0 = *reinterpret_cast<const f32x4_t*>(src), f1 = *reinterpret_cast<const f32x4_t*>(src + 4);
+    f[0] = f0[0]; f[1] = f0[1]; f[2] = f0[2]; f[3] = f0[3]; f[4] = f1[0]; f[5] = f1[1]; f[6] = f1[2]; f[7] = f1[3];
+}
+
 // Forward.  NW waves of 32 queries share 64-key K/V tiles that live in a ring of THREE LDS stages, DMA'd two tiles ahead
 // (counted vmcnt + raw barrier: a whole tile stays in flight across the barrier).  Softmax runs in the exp2 domain with the
 // scale folded into one FMA per score; masks are only evaluated on tiles that touch the end of the key range or the causal
@@ -505,36 +520,176 @@ __global__ void __launch_bounds__(64 * NW) attn_fwd_kernel(const AttnArgs a) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    // ---- epilogue: O / l (+ resid); lane holds, for its query, d = 32 dt + (r & 3) + 8 (r >> 2) + 4 h ----
-    if (qi < a.Sq) {
+    // ---- epilogue: O / l (+ resid) through LDS (rows_put_f32); lane holds, for its query, d = 32 dt + (r & 3) + 8 (r >> 2) + 4 h ----
+    __syncthreads();                                 // every wave is done with the ring: its memory now stages the output rows
+    {
+        float* fl = reinterpret_cast<float*>(smem) + wave * 32 * DH;
         const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
-        const long long obase = seq_base(a.om, seq) + (long long)qi * a.om.pos_stride + head * DH;
+        const int lr = lane & 31;
 #pragma unroll
         for (int d = 0; d < DT; ++d)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int dd = d * 32 + 8 * g + 4 * h;
-                float f[4];
+                f32x4_t f;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) f[e] = oacc[d][4 * g + e] * inv;
-                if (a.oattn) {                      // un-residualed output, kept for backward (D = rowsum(dO * O) needs it exactly)
-                    u32x2_t av;
-                    av[0] = pack_bf16x2(f[0], f[1]);
-                    av[1] = pack_bf16x2(f[2], f[3]);
-                    *reinterpret_cast<u32x2_t*>(a.oattn + obase + dd) = av;
-                }
-                if (a.resid) {
-                    const u32x2_t rv = *reinterpret_cast<const u32x2_t*>(a.resid + obase + dd);
-                    f[0] += __uint_as_float(rv[0] << 16); f[1] += __uint_as_float(rv[0] & 0xffff0000u);
-                    f[2] += __uint_as_float(rv[1] << 16); f[3] += __uint_as_float(rv[1] & 0xffff0000u);
-                }
-                u32x2_t ov;
-                ov[0] = pack_bf16x2(f[0], f[1]);
-                ov[1] = pack_bf16x2(f[2], f[3]);
-                *reinterpret_cast<u32x2_t*>(a.out + obase + dd) = ov;
+                rows_put_f32<DH>(fl, lr, h, d * 4 + g, f);
             }
+        const long long obase_s = seq_base(a.om, seq) + head * DH;
         // natural-log LSE of scale * s:  m * scale + ln(l)
-        if (a.lse && h == 0) a.lse[((obase - head * DH) / a.C) * a.nhead + head] = m_run * a.scale + __logf(l_run);
+        if (a.lse && h == 0 && qi < a.Sq) a.lse[((obase_s - head * DH + (long long)qi * a.om.pos_stride) / a.C) * a.nhead + head] = m_run * a.scale + __logf(l_run);
+#pragma unroll
+        for (int i = 0; i < CPR / 2; ++i) {
+            const int idx = i * 64 + lane, row = idx / CPR, c = idx % CPR;
+            if (q0 + row >= a.Sq) continue;
+            float f[8];
+            rows_get_f32<DH>(fl, row, c, f);
+            const long long o = obase_s + (long long)(q0 + row) * a.om.pos_stride + c * 8;
+            if (a.oattn) *reinterpret_cast<u32x4_t*>(a.oattn + o) = pack8(f);      // un-residualed output, kept for backward (D = rowsum(dO * O))
+            if (a.resid) {
+                float r[8];
+                unpack8(*reinterpret_cast<const u32x4_t*>(a.resid + o), r);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] += r[e];
+            }
+            *reinterpret_cast<u32x4_t*>(a.out + o) = pack8(f);
+        }
+    }
+}
+
+// Short self-attention sequences (temporal attention: S = T <= 32 frames of one pixel, attention.py:300-306).  The general
+// kernel gives such a sequence a whole 64-key tile and a 32-query wave: at T = 16 one eighth of its MFMA work is useful and
+// every block pays the ring prologue for a single tile.  Here 32 / TP sequences are packed into the 32 rows a wave owns
+// (TP = 8, 16 or 32 rows per sequence), so a wave's keys are its own rows: S^T = U U^T of those rows -- the A and the B
+// operand are the same registers -- masked block-diagonally.  Waves are independent (private LDS rows, no block barrier);
+// consecutive waves take the heads of the same rows so that a block reads whole token rows.
+template <int TP>
+__device__ __forceinline__ bool small_row_valid(int row, long long seq0, int nseq, int S) {
+    return (seq0 + row / TP < nseq) && ((row & (TP - 1)) < S);
+}
+
+template <int DH, int TP>
+__global__ void __launch_bounds__(256) attn_small_fwd_kernel(const AttnArgs a) {
+    constexpr int ROWB = DH * 2, CPR = DH / 8, WTILE = 32 * ROWB, KS = DH / 16, DT = DH / 32, PCS = WTILE / 1024, SPW = 32 / TP;
+    __shared__ __attribute__((aligned(1024))) char smem[4 * 2 * WTILE];      // per wave: 32 rows of bf16 in, 32 rows of fp32 out
+    const int lane = threadIdx.x & 63, h = lane >> 5, lr = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long wg = (long long)blockIdx.x * 4 + wave;
+    const int head = (int)(wg % a.nhead);
+    const long long seq0 = (wg / a.nhead) * SPW;
+    if (seq0 >= a.nseq) return;
+    char* lds = smem + wave * 2 * WTILE;
+    const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page_a);
+#pragma unroll
+    for (int i = 0; i < PCS; ++i) {
+        const int idx = i * 64 + lane, row = idx / CPR;
+        const bf16_t* src = zero;
+        if (small_row_valid<TP>(row, seq0, a.nseq, a.Sq))
+            src = a.k + seq_base(a.km, (int)(seq0 + row / TP)) + (long long)(row & (TP - 1)) * a.km.pos_stride + head * DH +
+                  attn_swz<CPR>(row, idx % CPR) * 8;
+        __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(lds + i * 1024), 16, 0, 0);
+    }
+    const int g16 = lane >> 4, rr = (lane >> 2) & 3, qq = lane & 3;
+    const uint32_t lds_off = attn_lds_offset(lds);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    bf16x8_t uf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) uf[ks] = *reinterpret_cast<const bf16x8_t*>(lds + lr * ROWB + (attn_swz<CPR>(lr, ks * 2 + h) << 4));
+    bf16x4_t vlo[2][DT], vhi[2][DT];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        const int r0 = 16 * s2 + 4 * (g16 >> 1) + rr, r1 = r0 + 8;
+#pragma unroll
+        for (int d = 0; d < DT; ++d) {
+            const int col = d * 32 + 16 * (g16 & 1) + 4 * qq;
+            vlo[s2][d] = attn_tr16(lds_off + (uint32_t)(r0 * ROWB + (attn_swz<CPR>(r0, col >> 3) << 4) + (col & 7) * 2));
+            vhi[s2][d] = attn_tr16(lds_off + (uint32_t)(r1 * ROWB + (attn_swz<CPR>(r1, col >> 3) << 4) + (col & 7) * 2));
+        }
+    }
+    f32x16_t sacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uf[ks], uf[ks], sacc, 0, 0, 0);
+
+    const bool q_ok = small_row_valid<TP>(lr, seq0, a.nseq, a.Sq);
+    const int qpos = lr & (TP - 1);
+    const float c2 = a.scale * 1.4426950408889634f;
+    float tmax = -1e30f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int key = (r & 3) + 8 * (r >> 2) + 4 * h, kpos = key & (TP - 1);
+        const bool ok = q_ok && ((key ^ lr) & ~(TP - 1)) == 0 && kpos < a.Sq && (!a.causal || kpos <= qpos);
+        sacc[r] = ok ? sacc[r] : -INFINITY;
+        tmax = fmaxf(tmax, sacc[r]);
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float mc = tmax * c2;
+    float l = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[r], c2, -mc));
+        sacc[r] = p;
+        l += p;
+    }
+    l += __shfl_xor(l, 32, 64);
+
+    f32x16_t oacc[DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        u32x4_t pw;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pw[e] = pack_bf16x2(sacc[8 * s2 + 2 * e], sacc[8 * s2 + 2 * e + 1]);
+        const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pw);
+#pragma unroll
+        for (int d = 0; d < DT; ++d) {
+            asm volatile("" : "+v"(vlo[s2][d]), "+v"(vhi[s2][d]));
+            const bf16x8_t vf = __builtin_shufflevector(vlo[s2][d], vhi[s2][d], 0, 1, 2, 3, 4, 5, 6, 7);
+            oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[d], 0, 0, 0);
+        }
+    }
+    // O / l goes back through the wave's LDS rows as fp32 so that the global traffic of out / o_attn / resid is whole 16-B chunks,
+    // 8 lanes per token row (the MFMA layout would store 8 B per lane into 32 different rows per instruction: measured 2x slower)
+    {
+        const float inv = l > 0.f ? 1.f / l : 0.f;
+        float* fl = reinterpret_cast<float*>(lds);
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4_t f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) f[e] = oacc[d][4 * g + e] * inv;
+                *reinterpret_cast<f32x4_t*>(fl + lr * DH + (((d * 4 + g) ^ (lr & (CPR - 1))) << 3) + 4 * h) = f;
+            }
+        if (a.lse && h == 0 && q_ok) {
+            const long long tok = (seq_base(a.om, (int)(seq0 + lr / TP)) + (long long)qpos * a.om.pos_stride) / a.C;
+            a.lse[tok * a.nhead + head] = tmax * a.scale + __logf(l);
+        }
+#pragma unroll
+        for (int i = 0; i < PCS; ++i) {
+            const int idx = i * 64 + lane, row = idx / CPR, c = idx % CPR;
+            if (!small_row_valid<TP>(row, seq0, a.nseq, a.Sq)) continue;
+            const float* src = fl + row * DH + ((c ^ (row & (CPR - 1))) << 3);
+            const f32x4_t f0 = *reinterpret_cast<const f32x4_t*>(src), f1 = *reinterpret_cast<const f32x4_t*>(src + 4);
+            float f[8] = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};
+            const long long o = seq_base(a.om, (int)(seq0 + row / TP)) + (long long)(row & (TP - 1)) * a.om.pos_stride + head * DH + c * 8;
+            if (a.oattn) *reinterpret_cast<u32x4_t*>(a.oattn + o) = pack8(f);
+            if (a.resid) {
+                float r[8];
+                unpack8(*reinterpret_cast<const u32x4_t*>(a.resid + o), r);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] += r[e];
+            }
+            *reinterpret_cast<u32x4_t*>(a.out + o) = pack8(f);
+        }
     }
 }
 
@@ -542,6 +697,15 @@ static SeqMap mk_map(const int64_t* m) {
     SeqMap s;
     s.n_inner = (int)m[0]; s.stride_outer = m[1]; s.stride_inner = m[2]; s.pos_stride = m[3];
     return s;
+}
+
+static bool same_map(const SeqMap& x, const SeqMap& y) {
+    return x.n_inner == y.n_inner && x.stride_outer == y.stride_outer && x.stride_inner == y.stride_inner && x.pos_stride == y.pos_stride;
+}
+static int small_attn_mode() {          // GENIE_ATTN_SMALL=0 sends short sequences through the general kernels (A/B timing, tests)
+    static int mode = -1;
+    if (mode < 0) { const char* e = getenv("GENIE_ATTN_SMALL"); mode = e ? atoi(e) : 1; }
+    return mode;
 }
 
 extern "C" int genie_attention_fwd(const void* q, const void* k, const void* v, const void* resid, void* out, void* o_attn, float* lse, int nseq, int nhead,
@@ -558,14 +722,30 @@ extern "C" int genie_attention_fwd(const void* q, const void* k, const void* v, 
     a.C = out_channels;
     GENIE_CHECK_ARG(out_channels >= nhead * d_head, "genie_attention_fwd: out_channels %d < nhead * d_head", out_channels);
     GENIE_CHECK_ARG(scale > 0.f, "genie_attention_fwd: scale must be positive (got %g)", (double)scale);
+    hipStream_t s = (hipStream_t)stream;
+    if (q == k && k == v && Sq == Sk && Sq <= 32 && same_map(a.qm, a.km) && small_attn_mode()) {   // packed short sequences (temporal attention)
+        const int tp = Sq <= 8 ? 8 : (Sq <= 16 ? 16 : 32);
+        const long long waves = ((long long)nseq + 32 / tp - 1) / (32 / tp) * nhead;
+        const unsigned blocks = (unsigned)((waves + 3) / 4);
+#define GENIE_ATTN_SMALL(DHv)                                                                            \
+    do {                                                                                                 \
+        if (tp == 8) attn_small_fwd_kernel<DHv, 8><<<blocks, 256, 0, s>>>(a);                            \
+        else if (tp == 16) attn_small_fwd_kernel<DHv, 16><<<blocks, 256, 0, s>>>(a);                     \
+        else attn_small_fwd_kernel<DHv, 32><<<blocks, 256, 0, s>>>(a);                                   \
+    } while (0)
+        if (d_head == 32) GENIE_ATTN_SMALL(32); else if (d_head == 64) GENIE_ATTN_SMALL(64); else GENIE_ATTN_SMALL(128);
+#undef GENIE_ATTN_SMALL
+        GENIE_CHECK_LAUNCH();
+        return GENIE_OK;
+    }
     int nw = (Sq + 31) / 32;
     nw = nw >= 3 ? 4 : nw;                                        // 1, 2 or 4 waves (every wave stages the same number of pieces)
     const int qtiles = (Sq + 32 * nw - 1) / (32 * nw);
     GENIE_CHECK_ARG((long long)nseq * qtiles < (1ll << 31) && nhead <= 65535, "genie_attention_fwd: grid too large");
     const int tile = 64 * d_head * 2;
-    const int lds = 3 * (a.kv_same ? tile : 2 * tile);
+    int lds = 3 * (a.kv_same ? tile : 2 * tile);
+    if (lds < nw * 32 * d_head * 4) lds = nw * 32 * d_head * 4;      // the epilogue stages NW x 32 fp32 rows in the ring's memory
     dim3 grid((unsigned)(nseq * qtiles), nhead, 1);
-    hipStream_t s = (hipStream_t)stream;
 #define GENIE_ATTN_FWD(DHv, NWv)                                                                         \
     do {                                                                                                 \
         auto kf_ = a.kv_same ? attn_fwd_kernel<DHv, NWv, true> : attn_fwd_kernel<DHv, NWv, false>;        \
@@ -809,8 +989,10 @@ __global__ void __launch_bounds__(64 * NW) attn_bwd_dq_kernel(const AttnBwdArgs 
         if (t + 2 < ntile) tile_body(std::integral_constant<int, 2>{}, t + 2);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (qi < a.Sq) {
-        const long long obase = seq_base(a.qm, seq) + (long long)qi * a.qm.pos_stride + head * DH;
+    __syncthreads();                                 // ring memory becomes the staging area of the dQ rows (bf16: nothing is added later)
+    {
+        char* wl = smem + wave * 32 * ROWB;
+        const int lr = lane & 31;
 #pragma unroll
         for (int d = 0; d < DT; ++d)
 #pragma unroll
@@ -818,8 +1000,16 @@ __global__ void __launch_bounds__(64 * NW) attn_bwd_dq_kernel(const AttnBwdArgs 
                 u32x2_t ov;
                 ov[0] = pack_bf16x2(dq[d][4 * g] * a.scale, dq[d][4 * g + 1] * a.scale);
                 ov[1] = pack_bf16x2(dq[d][4 * g + 2] * a.scale, dq[d][4 * g + 3] * a.scale);
-                *reinterpret_cast<u32x2_t*>(a.dq + obase + d * 32 + 8 * g + 4 * h) = ov;
+                *reinterpret_cast<u32x2_t*>(wl + lr * ROWB + (swz(lr, d * 4 + g) << 4) + 8 * h) = ov;
             }
+        const long long obase_s = seq_base(a.qm, seq) + head * DH;
+#pragma unroll
+        for (int i = 0; i < CPR / 2; ++i) {
+            const int idx = i * 64 + lane, row = idx / CPR;
+            if (q0 + row >= a.Sq) continue;
+            *reinterpret_cast<u32x4_t*>(a.dq + obase_s + (long long)(q0 + row) * a.qm.pos_stride + swz(row, idx % CPR) * 8) =
+                *reinterpret_cast<const u32x4_t*>(wl + idx * 16);
+        }
     }
 }
 
@@ -1008,30 +1198,199 @@ __global__ void __launch_bounds__(64 * NW) attn_bwd_dkv_kernel(const AttnBwdArgs
         if (t + 2 < ntile) tile_body(std::integral_constant<int, 2>{}, t + 2);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (ki < a.Sk) {
-        const long long kb = seq_base(a.dkm, seq) + (long long)ki * a.dkm.pos_stride + head * DH;
+    __syncthreads();                                 // ring memory becomes the fp32 staging area of the dK / dV rows
+    {
+        float* fl = reinterpret_cast<float*>(smem) + wave * 32 * DH;
+        const int lr = lane & 31;
+        const long long kb_s = seq_base(a.dkm, seq) + head * DH;
 #pragma unroll
         for (int d = 0; d < DT; ++d)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const long long o = kb + d * 32 + 8 * g + 4 * h;
-                float fk[4], fv[4];
+                f32x4_t f;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { fk[e] = dk[d][4 * g + e] * a.scale; fv[e] = dv[d][4 * g + e]; }
-                if (a.fuse_self) {
-                    const u32x2_t rv = *reinterpret_cast<const u32x2_t*>(a.dq_in + o);
-                    fk[0] += fv[0] + __uint_as_float(rv[0] << 16); fk[1] += fv[1] + __uint_as_float(rv[0] & 0xffff0000u);
-                    fk[2] += fv[2] + __uint_as_float(rv[1] << 16); fk[3] += fv[3] + __uint_as_float(rv[1] & 0xffff0000u);
-                    u32x2_t ov; ov[0] = pack_bf16x2(fk[0], fk[1]); ov[1] = pack_bf16x2(fk[2], fk[3]);
-                    *reinterpret_cast<u32x2_t*>(a.dk + o) = ov;
-                } else {
-                    u32x2_t ok_, ov_;
-                    ok_[0] = pack_bf16x2(fk[0], fk[1]); ok_[1] = pack_bf16x2(fk[2], fk[3]);
-                    ov_[0] = pack_bf16x2(fv[0], fv[1]); ov_[1] = pack_bf16x2(fv[2], fv[3]);
-                    *reinterpret_cast<u32x2_t*>(a.dk + o) = ok_;
-                    *reinterpret_cast<u32x2_t*>(a.dv + o) = ov_;
-                }
+                for (int e = 0; e < 4; ++e) f[e] = a.fuse_self ? __builtin_fmaf(dk[d][4 * g + e], a.scale, dv[d][4 * g + e]) : dk[d][4 * g + e] * a.scale;
+                rows_put_f32<DH>(fl, lr, h, d * 4 + g, f);
             }
+#pragma unroll
+        for (int i = 0; i < CPR / 2; ++i) {
+            const int idx = i * 64 + lane, row = idx / CPR, c = idx % CPR;
+            if (key0 + row >= a.Sk) continue;
+            float f[8];
+            rows_get_f32<DH>(fl, row, c, f);
+            const long long o = kb_s + (long long)(key0 + row) * a.dkm.pos_stride + c * 8;
+            if (a.fuse_self) {                       // dk row += dq_in row: the buffer then holds dQ + dK + dV
+                float r[8];
+                unpack8(*reinterpret_cast<const u32x4_t*>(a.dq_in + o), r);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] += r[e];
+            }
+            *reinterpret_cast<u32x4_t*>(a.dk + o) = pack8(f);
+        }
+        if (!a.fuse_self) {
+#pragma unroll
+            for (int d = 0; d < DT; ++d)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4_t f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) f[e] = dv[d][4 * g + e];
+                    rows_put_f32<DH>(fl, lr, h, d * 4 + g, f);
+                }
+#pragma unroll
+            for (int i = 0; i < CPR / 2; ++i) {
+                const int idx = i * 64 + lane, row = idx / CPR, c = idx % CPR;
+                if (key0 + row >= a.Sk) continue;
+                float f[8];
+                rows_get_f32<DH>(fl, row, c, f);
+                *reinterpret_cast<u32x4_t*>(a.dv + kb_s + (long long)(key0 + row) * a.dkm.pos_stride + c * 8) = pack8(f);
+            }
+        }
+    }
+}
+
+// Backward for the packed short sequences (see attn_small_fwd_kernel): everything a sequence needs is in the wave's own 32 rows,
+// so one kernel produces du = dQ + dK + dV.  S = U U^T is symmetric, so one product serves both orientations; dP is needed in
+// both (dP^T = U dO^T with lane = query for dQ, dP = dO U^T with lane = key for dK / dV).
+template <int DH, int TP>
+__global__ void __launch_bounds__(128) attn_small_bwd_kernel(const AttnBwdArgs a) {
+    constexpr int ROWB = DH * 2, CPR = DH / 8, WTILE = 32 * ROWB, KS = DH / 16, DT = DH / 32, PCS = WTILE / 1024, SPW = 32 / TP;
+    constexpr int WSTAGE = 2 * WTILE + 256;          // U rows | dO rows | lse [32] | D [32]
+    __shared__ __attribute__((aligned(1024))) char smem[2 * WSTAGE];
+    const int lane = threadIdx.x & 63, h = lane >> 5, lr = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long wg = (long long)blockIdx.x * 2 + wave;
+    const int head = (int)(wg % a.nhead);
+    const long long seq0 = (wg / a.nhead) * SPW;
+    if (seq0 >= a.nseq) return;
+    char* lds = smem + wave * WSTAGE;
+    const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page_a);
+#pragma unroll
+    for (int i = 0; i < PCS; ++i) {
+        const int idx = i * 64 + lane, row = idx / CPR;
+        const bf16_t* su = zero;
+        const bf16_t* sd = zero;
+        if (small_row_valid<TP>(row, seq0, a.nseq, a.Sq)) {
+            const int seq = (int)(seq0 + row / TP), pos = row & (TP - 1), c = attn_swz<CPR>(row, idx % CPR) * 8;
+            su = a.q + seq_base(a.qm, seq) + (long long)pos * a.qm.pos_stride + head * DH + c;
+            sd = a.dO + seq_base(a.om, seq) + (long long)pos * a.om.pos_stride + head * DH + c;
+        }
+        __builtin_amdgcn_global_load_lds(GLB_PTR(su), LDS_PTR(lds + i * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(GLB_PTR(sd), LDS_PTR(lds + WTILE + i * 1024), 16, 0, 0);
+    }
+    const bool my_ok = small_row_valid<TP>(lr, seq0, a.nseq, a.Sq);
+    const int mypos = lr & (TP - 1);
+    {   // lanes 0..31: lse of row lr, lanes 32..63: D of row lr
+        const float* src = reinterpret_cast<const float*>(zero);
+        if (my_ok) {
+            const long long tok = (seq_base(a.om, (int)(seq0 + lr / TP)) + (long long)mypos * a.om.pos_stride) / a.C;
+            src = (h ? a.D : a.lse) + tok * a.nhead + head;
+        }
+        __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(lds + 2 * WTILE), 4, 0, 0);
+    }
+    const int g16 = lane >> 4, rr = (lane >> 2) & 3, qq = lane & 3;
+    const uint32_t lds_off = attn_lds_offset(lds);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    bf16x8_t uf[KS], df[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int o = lr * ROWB + (attn_swz<CPR>(lr, ks * 2 + h) << 4);
+        uf[ks] = *reinterpret_cast<const bf16x8_t*>(lds + o);
+        df[ks] = *reinterpret_cast<const bf16x8_t*>(lds + WTILE + o);
+    }
+    const float* lse_l = reinterpret_cast<const float*>(lds + 2 * WTILE);
+    const float* D_l = lse_l + 32;
+    const float my_lse2 = lse_l[lr] * 1.4426950408889634f, my_D = D_l[lr];
+    bf16x4_t ulo[2][DT], uhi[2][DT], dlo[2][DT], dhi[2][DT];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        const int r0 = 16 * s2 + 4 * (g16 >> 1) + rr, r1 = r0 + 8;
+#pragma unroll
+        for (int d = 0; d < DT; ++d) {
+            const int col = d * 32 + 16 * (g16 & 1) + 4 * qq;
+            const uint32_t o0 = lds_off + (uint32_t)(r0 * ROWB + (attn_swz<CPR>(r0, col >> 3) << 4) + (col & 7) * 2);
+            const uint32_t o1 = lds_off + (uint32_t)(r1 * ROWB + (attn_swz<CPR>(r1, col >> 3) << 4) + (col & 7) * 2);
+            ulo[s2][d] = attn_tr16(o0); uhi[s2][d] = attn_tr16(o1);
+            dlo[s2][d] = attn_tr16i<WTILE>(o0); dhi[s2][d] = attn_tr16i<WTILE>(o1);
+        }
+    }
+    f32x16_t sacc, pt, pn;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; pt[r] = 0.f; pn[r] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uf[ks], uf[ks], sacc, 0, 0, 0);      // S (symmetric)
+        pt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uf[ks], df[ks], pt, 0, 0, 0);          // dP^T[key][query]
+        pn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df[ks], uf[ks], pn, 0, 0, 0);          // dP[query][key]
+    }
+    const float c2 = a.scale * 1.4426950408889634f;
+    f32x16_t dsa, dsb;               // sacc is reused for P (lane = key orientation)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4_t l4 = *reinterpret_cast<const f32x4_t*>(lse_l + 8 * g + 4 * h);
+        const f32x4_t d4 = *reinterpret_cast<const f32x4_t*>(D_l + 8 * g + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int r = 4 * g + e, row = 8 * g + 4 * h + e, rpos = row & (TP - 1);
+            const bool pair = my_ok && ((row ^ lr) & ~(TP - 1)) == 0 && rpos < a.Sq;
+            const bool ok_a = pair && (!a.causal || rpos <= mypos);          // key = row, query = this lane
+            const bool ok_b = pair && (!a.causal || mypos <= rpos);          // query = row, key = this lane
+            const float s2v = sacc[r] * c2;
+            const float pa = ok_a ? __builtin_amdgcn_exp2f(s2v - my_lse2) : 0.f;
+            const float pb = ok_b ? __builtin_amdgcn_exp2f(s2v - l4[e] * 1.4426950408889634f) : 0.f;
+            dsa[r] = pa * (pt[r] - my_D);
+            dsb[r] = pb * (pn[r] - d4[e]);
+            sacc[r] = pb;
+        }
+    }
+    f32x16_t acck[DT], accv[DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acck[d][r] = 0.f; accv[d][r] = 0.f; }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        u32x4_t wa, wb, wp;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            wa[e] = pack_bf16x2(dsa[8 * s2 + 2 * e], dsa[8 * s2 + 2 * e + 1]);
+            wb[e] = pack_bf16x2(dsb[8 * s2 + 2 * e], dsb[8 * s2 + 2 * e + 1]);
+            wp[e] = pack_bf16x2(sacc[8 * s2 + 2 * e], sacc[8 * s2 + 2 * e + 1]);
+        }
+        const bf16x8_t fa = __builtin_bit_cast(bf16x8_t, wa), fb = __builtin_bit_cast(bf16x8_t, wb), fp = __builtin_bit_cast(bf16x8_t, wp);
+#pragma unroll
+        for (int d = 0; d < DT; ++d) {
+            asm volatile("" : "+v"(ulo[s2][d]), "+v"(uhi[s2][d]), "+v"(dlo[s2][d]), "+v"(dhi[s2][d]));
+            const bf16x8_t uT = __builtin_shufflevector(ulo[s2][d], uhi[s2][d], 0, 1, 2, 3, 4, 5, 6, 7);
+            const bf16x8_t dT = __builtin_shufflevector(dlo[s2][d], dhi[s2][d], 0, 1, 2, 3, 4, 5, 6, 7);
+            acck[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uT, fa, acck[d], 0, 0, 0);       // dQ^T += K^T dS^T
+            acck[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uT, fb, acck[d], 0, 0, 0);       // dK^T += Q^T dS
+            accv[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dT, fp, accv[d], 0, 0, 0);       // dV^T += dO^T P
+        }
+    }
+    // du rows go back through the wave's U rows in LDS (all fragment reads are done) and leave as whole 16-B chunks, 8 lanes per row
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float f[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) f[e] = __builtin_fmaf(acck[d][4 * g + e], a.scale, accv[d][4 * g + e]);
+            u32x2_t ov;
+            ov[0] = pack_bf16x2(f[0], f[1]);
+            ov[1] = pack_bf16x2(f[2], f[3]);
+            *reinterpret_cast<u32x2_t*>(lds + lr * ROWB + (attn_swz<CPR>(lr, d * 4 + g) << 4) + 8 * h) = ov;
+        }
+#pragma unroll
+    for (int i = 0; i < PCS; ++i) {
+        const int idx = i * 64 + lane, row = idx / CPR;
+        if (!small_row_valid<TP>(row, seq0, a.nseq, a.Sq)) continue;
+        const u32x4_t v = *reinterpret_cast<const u32x4_t*>(lds + idx * 16);
+        *reinterpret_cast<u32x4_t*>(a.dq + seq_base(a.qm, (int)(seq0 + row / TP)) + (long long)(row & (TP - 1)) * a.qm.pos_stride + head * DH +
+                                    attn_swz<CPR>(row, idx % CPR) * 8) = v;
     }
 }
 
@@ -1058,6 +1417,21 @@ extern "C" int genie_attention_bwd(const void* q, const void* k, const void* v, 
     else attn_bwd_prep_kernel<128><<<pblocks, 256, 0, s>>>((const bf16_t*)dO, (const bf16_t*)out, (const bf16_t*)resid, D_ws, out_tokens, out_channels, nhead);
     GENIE_CHECK_LAUNCH();
     GENIE_CHECK_ARG(scale > 0.f, "genie_attention_bwd: scale must be positive (got %g)", (double)scale);
+    if (self && Sq == Sk && Sq <= 32 && same_map(a.qm, a.km) && small_attn_mode()) {
+        const int tp = Sq <= 8 ? 8 : (Sq <= 16 ? 16 : 32);
+        const long long waves = ((long long)nseq + 32 / tp - 1) / (32 / tp) * nhead;
+        const unsigned blocks = (unsigned)((waves + 1) / 2);
+#define GENIE_ATTN_SMALL(DHv)                                                                            \
+    do {                                                                                                 \
+        if (tp == 8) attn_small_bwd_kernel<DHv, 8><<<blocks, 128, 0, s>>>(a);                            \
+        else if (tp == 16) attn_small_bwd_kernel<DHv, 16><<<blocks, 128, 0, s>>>(a);                     \
+        else attn_small_bwd_kernel<DHv, 32><<<blocks, 128, 0, s>>>(a);                                   \
+    } while (0)
+        if (d_head == 32) GENIE_ATTN_SMALL(32); else if (d_head == 64) GENIE_ATTN_SMALL(64); else GENIE_ATTN_SMALL(128);
+#undef GENIE_ATTN_SMALL
+        GENIE_CHECK_LAUNCH();
+        return GENIE_OK;
+    }
     int nwq = (Sq + 31) / 32; nwq = nwq >= 3 ? 4 : nwq;
     int nwk = (Sk + 31) / 32; nwk = nwk >= 3 ? 4 : nwk;
     const int qtiles = (Sq + 32 * nwq - 1) / (32 * nwq), ktiles = (Sk + 32 * nwk - 1) / (32 * nwk);

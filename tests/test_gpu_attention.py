@@ -177,6 +177,14 @@ CORE_CASES = [
     (2, 2, 64, 150, 70, False, True),
     (4, 2, 64, 40, 40, True, False),
     (2, 4, 32, 96, 96, False, False),
+    # short self-attention sequences: the packed kernels (several sequences per wave, block-diagonal mask)
+    (7, 2, 64, 16, 16, True, False),
+    (5, 4, 32, 5, 5, True, False),
+    (9, 2, 64, 20, 20, False, False),
+    (3, 1, 128, 32, 32, True, False),
+    (11, 2, 64, 8, 8, True, False),
+    (6, 2, 64, 1, 1, True, False),
+    (130, 3, 32, 13, 13, False, False),
 ]
 
 
