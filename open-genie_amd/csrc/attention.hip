@@ -61,164 +61,230 @@ __device__ __forceinline__ uint32_t attn_lds_offset(const void* p) {
 // x, u: [ntok][C] bf16 rows (row pitch = pitch elements); pos(token) = (token / pos_div) % pos_mod
 // cs: fp32 table [npos][C] holding cos in even slots and sin in odd slots of each feature PAIR:
 //     cs[p][2i] = cos(p * freq_i), cs[p][2i+1] = sin(p * freq_i)
+// NIT = 16-B chunks per lane (C <= 512 NIT); lanes past the row read chunk 0 and contribute zeros, so the streaming part has
+// no divergent branches (the first version's per-element `gamma ? gamma[c] : 1` compiled to 64 branches with dword loads, and
+// its 64-bit (token / pos_div) % pos_mod to four division expansions: 1 TB/s).
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) rotary_ln_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ u, long long ntok, int C,
-                                                            long long pitch, const float* __restrict__ cs, long long pos_div, int pos_mod,
+__device__ __forceinline__ void rot_fwd8(float (&f)[8], const f32x4_t c0, const f32x4_t c1) {
+    const float cc[4] = {c0[0], c0[2], c1[0], c1[2]}, sn[4] = {c0[1], c0[3], c1[1], c1[3]};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float a = f[2 * j], b = f[2 * j + 1];
+        f[2 * j] = a * cc[j] - b * sn[j];          // x1 cos - x2 sin
+        f[2 * j + 1] = b * cc[j] + a * sn[j];      // x2 cos + x1 sin
+    }
+}
+__device__ __forceinline__ void rot_bwd8(float (&f)[8], const f32x4_t c0, const f32x4_t c1) {      // transpose of rot_fwd8
+    const float cc[4] = {c0[0], c0[2], c1[0], c1[2]}, sn[4] = {c0[1], c0[3], c1[1], c1[3]};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float a = f[2 * j], b = f[2 * j + 1];
+        f[2 * j] = a * cc[j] + b * sn[j];
+        f[2 * j + 1] = b * cc[j] - a * sn[j];
+    }
+}
+__device__ __forceinline__ void load8f(const float* p, float (&f)[8]) {
+    const f32x4_t a = *reinterpret_cast<const f32x4_t*>(p), b = *reinterpret_cast<const f32x4_t*>(p + 4);
+    f[0] = a[0]; f[1] = a[1]; f[2] = a[2]; f[3] = a[3]; f[4] = b[0]; f[5] = b[1]; f[6] = b[2]; f[7] = b[3];
+}
+
+// Both kernels are persistent: a wave keeps gamma / beta (and the dgamma / dbeta partial sums) in registers and walks the tokens
+// in groups of TG, all loads of a group issued before its arithmetic.  Per-token waves re-read gamma and beta every time: every
+// wave of the chip then hits the same 32 L2 lines, and that hot spot alone cost 100 us of a 128 us call (65536 x 512; 25 us
+// without gamma / beta), far more than the 2 KB / token of the cos / sin table, which is spread over pos_mod rows.
+template <int NIT, int TG, bool ROT>
+__global__ void __launch_bounds__(256) rotary_ln_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ u, int ntok, int C, long long pitch,
+                                                            const float* __restrict__ cs, unsigned pos_div, unsigned pos_mod,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                             float* __restrict__ stats /* [ntok][2] mean, rstd of the rotated row */) {
     const int lane = threadIdx.x & 63;
-    const long long tok = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tok >= ntok) return;
-    const int pos = (int)((tok / pos_div) % pos_mod);
-    const bf16_t* xr = x + tok * pitch;
-    const float* csr = cs ? cs + (long long)pos * C : nullptr;
-    float v[32];                      // up to 4 chunks of 8 per lane (C <= 2048)
-    float s = 0.f, q = 0.f;
+    const int wg = (int)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwaves = (int)gridDim.x * 4;
     const int nch = C >> 3;
+    const float invC = 1.f / (float)C;
+    int chc[NIT];
+    float ga[NIT][8], be[NIT][8];
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
+    for (int it = 0; it < NIT; ++it) {
         const int ch = lane + it * 64;
-        if (ch < nch) {
-            float f[8];
-            unpack8(*reinterpret_cast<const u32x4_t*>(xr + ch * 8), f);
-            if (csr) {
+        chc[it] = ch < nch ? ch : 0;
+        if (gamma) load8f(gamma + chc[it] * 8, ga[it]);
+        if (beta) load8f(beta + chc[it] * 8, be[it]);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float c = csr[ch * 8 + 2 * j], sn = csr[ch * 8 + 2 * j + 1];
-                    const float a = f[2 * j], b = f[2 * j + 1];
-                    f[2 * j] = a * c - b * sn;          // x1 cos - x2 sin
-                    f[2 * j + 1] = b * c + a * sn;      // x2 cos + x1 sin
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { v[it * 8 + j] = f[j]; s += f[j]; q += f[j] * f[j]; }
+        for (int j = 0; j < 8; ++j) {
+            if (!gamma) ga[it][j] = 1.f;
+            if (!beta) be[it][j] = 0.f;
         }
     }
-    s = wave_sum(s);
-    q = wave_sum(q);
-    const float mean = s / (float)C;
-    float var = q / (float)C - mean * mean;
-    var = var < 0.f ? 0.f : var;
-    const float rstd = rsqrtf(var + eps);
-    if (lane == 0 && stats) { stats[tok * 2] = mean; stats[tok * 2 + 1] = rstd; }
-    bf16_t* ur = u + tok * pitch;
+    for (int base = wg * TG; base < ntok; base += nwaves * TG) {
+        u32x4_t raw[TG][NIT];
+        f32x4_t c0[TG][NIT], c1[TG][NIT];
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int ch = lane + it * 64;
-        if (ch < nch) {
-            float f[8];
+        for (int t = 0; t < TG; ++t) {
+            const int tok = base + t < ntok ? base + t : ntok - 1;
+            const float* csr = cs + (long long)(((unsigned)tok / pos_div) % pos_mod) * C;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int c = ch * 8 + j;
-                f[j] = (v[it * 8 + j] - mean) * rstd * (gamma ? gamma[c] : 1.f) + (beta ? beta[c] : 0.f);
+            for (int it = 0; it < NIT; ++it) {
+                raw[t][it] = *reinterpret_cast<const u32x4_t*>(x + (long long)tok * pitch + chc[it] * 8);
+                if (ROT) {
+                    c0[t][it] = *reinterpret_cast<const f32x4_t*>(csr + chc[it] * 8);
+                    c1[t][it] = *reinterpret_cast<const f32x4_t*>(csr + chc[it] * 8 + 4);
+                }
             }
-            *reinterpret_cast<u32x4_t*>(ur + ch * 8) = pack8(f);
+        }
+        __builtin_amdgcn_sched_barrier(0);                           // every load of the group is in flight before its arithmetic starts
+#pragma unroll
+        for (int t = 0; t < TG; ++t) {
+            float v[NIT * 8];
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                float f[8];
+                unpack8(raw[t][it], f);
+                if (ROT) rot_fwd8(f, c0[t][it], c1[t][it]);
+                const bool ok = lane + it * 64 < nch;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float e = ok ? f[j] : 0.f;
+                    v[it * 8 + j] = e; s += e; q += e * e;
+                }
+            }
+            s = wave_sum(s);
+            q = wave_sum(q);
+            const float mean = s * invC;
+            float var = q * invC - mean * mean;
+            var = var < 0.f ? 0.f : var;
+            const float rstd = rsqrtf(var + eps);
+            const int tok = base + t;
+            if (tok < ntok) {
+                if (lane == 0 && stats) { stats[(long long)tok * 2] = mean; stats[(long long)tok * 2 + 1] = rstd; }
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    float f[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) f[j] = (v[it * 8 + j] - mean) * rstd * ga[it][j] + be[it][j];
+                    if (lane + it * 64 < nch) *reinterpret_cast<u32x4_t*>(u + (long long)tok * pitch + chc[it] * 8) = pack8(f);
+                }
+            }
         }
     }
 }
 
-// backward of u = LN(rot(x)):  dx = rot^T( LN'(du) ), dgamma += sum du * xhat, dbeta += sum du
-// One wave per token, grid-stride over tokens; a lane owns the same channels for every token, so the dgamma / dbeta partial
-// sums live in registers (the first version did two LDS atomics per element: 264 us per call at 65536 x 256) and are combined
-// once per block through LDS, then one global atomic per channel per block.
-__global__ void __launch_bounds__(256) rotary_ln_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ du,
-                                                            const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx, long long ntok,
-                                                            int C, long long pitch, const float* __restrict__ cs, long long pos_div,
-                                                            int pos_mod, const float* __restrict__ gamma, const float* __restrict__ stats,
-                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    extern __shared__ float sm[];     // [4 waves][2][C] partial sums of dgamma / dbeta
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// backward of u = LN(rot(x)):  dx = rot^T( LN'(du) ) (+ dres), dgamma += sum du * xhat, dbeta += sum du
+// A lane owns the same channels for every token, so the dgamma / dbeta partial sums live in registers (the first version did
+// two LDS atomics per element: 264 us per call at 65536 x 256).  The waves of a block combine through LDS atomics and the
+// block issues ONE global atomic per channel: with a block per 4 tokens the global atomics (2 C per block onto 2 C addresses)
+// took longer than the streaming (57 us at 8192 x 512).
+template <int NIT, int TG, int NWV, bool ROT, bool RES>
+__global__ void __launch_bounds__(64 * NWV) rotary_ln_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ du,
+                                                                 const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx, int ntok, int C,
+                                                                 long long pitch, const float* __restrict__ cs, unsigned pos_div,
+                                                                 unsigned pos_mod, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ stats, float* __restrict__ dgamma,
+                                                                 float* __restrict__ dbeta) {
+    extern __shared__ float sm[];     // [2][C] block sums of dgamma / dbeta
+    const int lane = threadIdx.x & 63;
+    const int wg = (int)blockIdx.x * NWV + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwaves = (int)gridDim.x * NWV;
     const int nch = C >> 3;
-    float gam[32], ag[32], ab[32];
+    for (int i = threadIdx.x; i < 2 * C; i += 64 * NWV) sm[i] = 0.f;
+    float gam[NIT * 8], ag[NIT * 8], ab[NIT * 8];
+    int chc[NIT];
+    float live[NIT];
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
+    for (int it = 0; it < NIT; ++it) {
         const int ch = lane + it * 64;
+        chc[it] = ch < nch ? ch : 0;
+        live[it] = ch < nch ? 1.f : 0.f;
+        float ga[8];
+        if (gamma) load8f(gamma + chc[it] * 8, ga);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            gam[it * 8 + j] = (ch < nch && gamma) ? gamma[ch * 8 + j] : 1.f;
+            gam[it * 8 + j] = gamma ? ga[j] : 1.f;
             ag[it * 8 + j] = 0.f;
             ab[it * 8 + j] = 0.f;
         }
     }
-    for (long long tok = (long long)blockIdx.x * 4 + wave; tok < ntok; tok += (long long)gridDim.x * 4) {
-        const int pos = (int)((tok / pos_div) % pos_mod);
-        const float* csr = cs ? cs + (long long)pos * C : nullptr;
-        const float mean = stats[tok * 2], rstd = stats[tok * 2 + 1];
-        float xh[32], g[32];
-        float s1 = 0.f, s2 = 0.f;
+    const float invC = 1.f / (float)C;
+    for (int base = wg * TG; base < ntok; base += nwaves * TG) {
+        u32x4_t xr[TG][NIT], dr[TG][NIT], rr[TG][NIT];
+        f32x4_t c0[TG][NIT], c1[TG][NIT];
+        float mean[TG], rstd[TG];
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int ch = lane + it * 64;
-            if (ch < nch) {
-                float f[8], d[8];
-                unpack8(*reinterpret_cast<const u32x4_t*>(x + tok * pitch + ch * 8), f);
-                unpack8(*reinterpret_cast<const u32x4_t*>(du + tok * pitch + ch * 8), d);
-                if (csr) {
-                    const f32x4_t c0 = *reinterpret_cast<const f32x4_t*>(csr + ch * 8), c1 = *reinterpret_cast<const f32x4_t*>(csr + ch * 8 + 4);
-                    const float cc[4] = {c0[0], c0[2], c1[0], c1[2]}, sn[4] = {c0[1], c0[3], c1[1], c1[3]};
+        for (int t = 0; t < TG; ++t) {
+            const int tok = base + t < ntok ? base + t : ntok - 1;
+            const float* csr = cs + (long long)(((unsigned)tok / pos_div) % pos_mod) * C;
+            mean[t] = stats[(long long)tok * 2];
+            rstd[t] = stats[(long long)tok * 2 + 1];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float a = f[2 * j], b = f[2 * j + 1];
-                        f[2 * j] = a * cc[j] - b * sn[j];
-                        f[2 * j + 1] = b * cc[j] + a * sn[j];
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float h = (f[j] - mean) * rstd;
-                    const float gg = d[j] * gam[it * 8 + j];
-                    xh[it * 8 + j] = h; g[it * 8 + j] = gg;
-                    s1 += gg; s2 += gg * h;
-                    ag[it * 8 + j] += d[j] * h;
-                    ab[it * 8 + j] += d[j];
+            for (int it = 0; it < NIT; ++it) {
+                const long long o = (long long)tok * pitch + chc[it] * 8;
+                xr[t][it] = *reinterpret_cast<const u32x4_t*>(x + o);
+                dr[t][it] = *reinterpret_cast<const u32x4_t*>(du + o);
+                if (RES) rr[t][it] = *reinterpret_cast<const u32x4_t*>(dres + o);
+                if (ROT) {
+                    c0[t][it] = *reinterpret_cast<const f32x4_t*>(csr + chc[it] * 8);
+                    c1[t][it] = *reinterpret_cast<const f32x4_t*>(csr + chc[it] * 8 + 4);
                 }
             }
         }
-        s1 = wave_sum(s1) / (float)C;
-        s2 = wave_sum(s2) / (float)C;
+        __builtin_amdgcn_sched_barrier(0);                           // every load of the group is in flight before its arithmetic starts
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int ch = lane + it * 64;
-            if (ch < nch) {
+        for (int t = 0; t < TG; ++t) {
+            const float tl = base + t < ntok ? 1.f : 0.f;            // the clamped tail tokens contribute nothing
+            float xh[NIT * 8], g[NIT * 8];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                float f[8], d[8];
+                unpack8(xr[t][it], f);
+                unpack8(dr[t][it], d);
+                if (ROT) rot_fwd8(f, c0[t][it], c1[t][it]);
+                const float lv = live[it] * tl;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float dj = d[j] * lv;
+                    const float h = (f[j] - mean[t]) * rstd[t];
+                    const float gg = dj * gam[it * 8 + j];
+                    xh[it * 8 + j] = h; g[it * 8 + j] = gg;
+                    s1 += gg; s2 += gg * h;
+                    ag[it * 8 + j] += dj * h;
+                    ab[it * 8 + j] += dj;
+                }
+            }
+            s1 = wave_sum(s1) * invC;
+            s2 = wave_sum(s2) * invC;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
                 float f[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) f[j] = rstd * (g[it * 8 + j] - s1 - xh[it * 8 + j] * s2);      // d/d(rotated x)
-                if (csr) {                                                                               // transpose of the rotation
-                    const f32x4_t c0 = *reinterpret_cast<const f32x4_t*>(csr + ch * 8), c1 = *reinterpret_cast<const f32x4_t*>(csr + ch * 8 + 4);
-                    const float cc[4] = {c0[0], c0[2], c1[0], c1[2]}, sn[4] = {c0[1], c0[3], c1[1], c1[3]};
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float a = f[2 * j], b = f[2 * j + 1];
-                        f[2 * j] = a * cc[j] + b * sn[j];
-                        f[2 * j + 1] = b * cc[j] - a * sn[j];
-                    }
-                }
-                if (dres) {
+                for (int j = 0; j < 8; ++j) f[j] = rstd[t] * (g[it * 8 + j] - s1 - xh[it * 8 + j] * s2);      // d/d(rotated x)
+                if (ROT) rot_bwd8(f, c0[t][it], c1[t][it]);
+                if (RES) {
                     float r[8];
-                    unpack8(*reinterpret_cast<const u32x4_t*>(dres + tok * pitch + ch * 8), r);
+                    unpack8(rr[t][it], r);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) f[j] += r[j];
                 }
-                *reinterpret_cast<u32x4_t*>(dx + tok * pitch + ch * 8) = pack8(f);
+                if (lane + it * 64 < nch && base + t < ntok) *reinterpret_cast<u32x4_t*>(dx + (long long)(base + t) * pitch + chc[it] * 8) = pack8(f);
             }
         }
     }
-    // combine the four waves' partial sums (fixed order), one global atomic per channel per block
+    __syncthreads();                  // sm is zeroed
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int ch = lane + it * 64;
-        if (ch < nch) {
+    for (int it = 0; it < NIT; ++it) {
+        if (lane + it * 64 < nch) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                sm[(wave * 2 + 0) * C + ch * 8 + j] = ag[it * 8 + j];
-                sm[(wave * 2 + 1) * C + ch * 8 + j] = ab[it * 8 + j];
+                atomicAdd(&sm[chc[it] * 8 + j], ag[it * 8 + j]);
+                atomicAdd(&sm[C + chc[it] * 8 + j], ab[it * 8 + j]);
             }
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < C; i += 256) {
-        if (dgamma) atomicAdd(dgamma + i, sm[0 * C + i] + sm[2 * C + i] + sm[4 * C + i] + sm[6 * C + i]);
-        if (dbeta) atomicAdd(dbeta + i, sm[1 * C + i] + sm[3 * C + i] + sm[5 * C + i] + sm[7 * C + i]);
+    for (int i = threadIdx.x; i < C; i += 64 * NWV) {
+        if (dgamma) atomicAdd(dgamma + i, sm[i]);
+        if (dbeta) atomicAdd(dbeta + i, sm[C + i]);
     }
 }
 
@@ -227,8 +293,20 @@ extern "C" int genie_rotary_layernorm_fwd(const void* x, void* u, int64_t ntok, 
     GENIE_CHECK_ARG(x && u, "genie_rotary_layernorm_fwd: null pointer");
     GENIE_CHECK_ARG(C % 8 == 0 && C <= 2048 && pitch >= C && pitch % 8 == 0, "genie_rotary_layernorm_fwd: C=%d must be a multiple of 8, <= 2048, pitch %lld", C, (long long)pitch);
     GENIE_CHECK_ARG(pos_div >= 1 && pos_mod >= 1, "genie_rotary_layernorm_fwd: bad position spec");
+    GENIE_CHECK_ARG(ntok < (1ll << 31) - 8 && pos_div < (1ll << 31), "genie_rotary_layernorm_fwd: more than 2^31 tokens");
     if (ntok == 0) return GENIE_OK;
-    rotary_ln_fwd_kernel<<<(unsigned)((ntok + 3) / 4), 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, (bf16_t*)u, ntok, C, pitch, cos_sin, pos_div, pos_mod, gamma, beta, eps, stats);
+    hipStream_t s = (hipStream_t)stream;
+#define GENIE_LN_FWD(NITv, TGv)                                                                                       \
+    do {                                                                                                              \
+        long long blocks = (ntok + 4 * TGv - 1) / (4 * TGv);                                                          \
+        if (blocks > 2048) blocks = 2048;                                                                             \
+        if (cos_sin) rotary_ln_fwd_kernel<NITv, TGv, true><<<(unsigned)blocks, 256, 0, s>>>((const bf16_t*)x, (bf16_t*)u, (int)ntok, C, pitch, cos_sin, (unsigned)pos_div, (unsigned)pos_mod, gamma, beta, eps, stats); \
+        else rotary_ln_fwd_kernel<NITv, TGv, false><<<(unsigned)blocks, 256, 0, s>>>((const bf16_t*)x, (bf16_t*)u, (int)ntok, C, pitch, cos_sin, (unsigned)pos_div, (unsigned)pos_mod, gamma, beta, eps, stats); \
+    } while (0)
+    if (C <= 512) GENIE_LN_FWD(1, 4);
+    else if (C <= 1024) GENIE_LN_FWD(2, 2);
+    else GENIE_LN_FWD(4, 1);
+#undef GENIE_LN_FWD
     GENIE_CHECK_LAUNCH();
     return GENIE_OK;
 }
@@ -238,10 +316,28 @@ extern "C" int genie_rotary_layernorm_bwd(const void* x, const void* du, const v
                                           float* dgamma, float* dbeta, void* stream) {
     GENIE_CHECK_ARG(x && du && dx && stats, "genie_rotary_layernorm_bwd: null pointer");
     GENIE_CHECK_ARG(C % 8 == 0 && C <= 2048 && pitch >= C && pitch % 8 == 0, "genie_rotary_layernorm_bwd: bad C=%d / pitch", C);
+    GENIE_CHECK_ARG(pos_div >= 1 && pos_mod >= 1, "genie_rotary_layernorm_bwd: bad position spec");
+    GENIE_CHECK_ARG(ntok < (1ll << 31) - (1 << 20) && pos_div < (1ll << 31), "genie_rotary_layernorm_bwd: more than 2^31 tokens");
     if (ntok == 0) return GENIE_OK;
-    long long blocks = (ntok + 3) / 4;
-    if (blocks > 2048) blocks = 2048;
-    rotary_ln_bwd_kernel<<<(unsigned)blocks, 256, 8 * C * sizeof(float), (hipStream_t)stream>>>((const bf16_t*)x, (const bf16_t*)du, (const bf16_t*)dres, (bf16_t*)dx, ntok, C, pitch, cos_sin, pos_div, pos_mod, gamma, stats, dgamma, dbeta);
+    hipStream_t s = (hipStream_t)stream;
+#define GENIE_LN_BWD2(NITv, NWVv, ROTv, RESv)                                                                         \
+    rotary_ln_bwd_kernel<NITv, 4 / NITv, NWVv, ROTv, RESv><<<(unsigned)blocks, 64 * NWVv, 2 * C * sizeof(float), s>>>(          \
+        (const bf16_t*)x, (const bf16_t*)du, (const bf16_t*)dres, (bf16_t*)dx, (int)ntok, C, pitch, cos_sin, (unsigned)pos_div, (unsigned)pos_mod, gamma, stats, dgamma, dbeta)
+#define GENIE_LN_BWD(NITv, NWVv)                                                                                      \
+    do {                                                                                                              \
+        long long blocks = (ntok + NWVv * (4 / NITv) - 1) / (NWVv * (4 / NITv));                                      \
+        const long long cap = 512;                                    /* about one resident round of blocks (VGPR-bound occupancy) */ \
+        if (blocks > cap) blocks = cap;                                                                               \
+        if (cos_sin && dres) GENIE_LN_BWD2(NITv, NWVv, true, true);                                                   \
+        else if (cos_sin) GENIE_LN_BWD2(NITv, NWVv, true, false);                                                     \
+        else if (dres) GENIE_LN_BWD2(NITv, NWVv, false, true);                                                        \
+        else GENIE_LN_BWD2(NITv, NWVv, false, false);                                                                 \
+    } while (0)
+    if (C <= 512) GENIE_LN_BWD(1, 8);
+    else if (C <= 1024) GENIE_LN_BWD(2, 8);
+    else GENIE_LN_BWD(4, 4);
+#undef GENIE_LN_BWD
+#undef GENIE_LN_BWD2
     GENIE_CHECK_LAUNCH();
     return GENIE_OK;
 }

@@ -72,10 +72,22 @@ __device__ __forceinline__ u32x4_t pack8(const float* f) {
     return v;
 }
 
+// Wave-wide sum, result in every lane.  Four DPP adds reduce each 16-lane row in place (quad_perm, row_half_mirror, row_mirror),
+// the four row sums are combined through readlane.  The ds_bpermute butterfly this replaces cost six dependent LDS round trips
+// per sum (about 800 cycles in the one-wave-per-token LayerNorm kernels).  Call with all 64 lanes active.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_f32<0xB1>(v);        // quad_perm [1, 0, 3, 2]
+    v += dpp_f32<0x4E>(v);        // quad_perm [2, 3, 0, 1]
+    v += dpp_f32<0x141>(v);       // row_half_mirror
+    v += dpp_f32<0x140>(v);       // row_mirror
+    const int b = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+    return (r0 + r1) + (r2 + r3);
 }
 
 __device__ __forceinline__ float silu_f(float z) { return z / (1.f + __expf(-z)); }
