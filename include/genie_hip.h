@@ -109,7 +109,8 @@ typedef struct GenieConvDesc {
     int32_t n_tri_steps;
     int32_t tri_bm;
     int32_t tri_flags;
-    int32_t reserved0;
+    int32_t pointwise;    /* 1: plain GEMM rows -- one tap with dt = dh = dw = 0, c0 = 0, wofs = 0 and nch = 64 * nk (a 1x1x1 stride-1
+                             convolution or a Linear layer): eligible for the persistent GEMM kernel (conv_gemm.hip) */
 } GenieConvDesc;
 
 int genie_conv_igemm(const GenieConvDesc* desc, void* stream);
@@ -121,6 +122,7 @@ int genie_conv_igemm(const GenieConvDesc* desc, void* stream);
 #define GENIE_VARIANT_IGEMM_32_SMALLC 3
 #define GENIE_VARIANT_IGEMM3_128 4
 #define GENIE_VARIANT_IGEMM3_256 5
+#define GENIE_VARIANT_GEMM_PW 6
 #define GENIE_VARIANT_WGRAD_128 8
 #define GENIE_VARIANT_WGRAD_128x32 9
 #define GENIE_VARIANT_WGRAD_32x128 10

@@ -280,6 +280,7 @@ static int launch_igemm(const IgemmArgs& a, hipStream_t s) {
 }
 
 int genie_conv_igemm3_try(const GenieConvDesc* d, IgemmArgs a, hipStream_t s);   // conv_igemm3.hip
+int genie_conv_gemm_try(const GenieConvDesc* d, IgemmArgs a, hipStream_t s);     // conv_gemm.hip
 
 extern "C" int genie_conv_igemm(const GenieConvDesc* d, void* stream) {
     GENIE_CHECK_ARG(d, "genie_conv_igemm: null descriptor");
@@ -321,7 +322,9 @@ extern "C" int genie_conv_igemm(const GenieConvDesc* d, void* stream) {
     a.split_k = 1; a.chunks_per_split = a.nk; a.ws = nullptr; a.ws_ld = 0;
     a.tiles_n = cdiv(a.Nstore, 128);
     {
-        const int rc = genie_conv_igemm3_try(d, a, s);
+        int rc = genie_conv_gemm_try(d, a, s);
+        if (rc <= 0) return rc;
+        rc = genie_conv_igemm3_try(d, a, s);
         if (rc <= 0) return rc;
     }
     if (a.Nstore <= 32) {

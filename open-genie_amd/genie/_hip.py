@@ -37,7 +37,7 @@ class GenieConvDesc(C.Structure):
                 ('shuf_c', C.c_int32), ('shuf_q', C.c_int32), ('shuf_r', C.c_int32), ('act', C.c_int32),
                 ('splitk_ws', C.c_void_p), ('splitk_ws_bytes', C.c_int64),
                 ('tri_steps', C.c_void_p), ('n_tri_steps', C.c_int32), ('tri_bm', C.c_int32), ('tri_flags', C.c_int32),
-                ('reserved0', C.c_int32)]
+                ('pointwise', C.c_int32)]
 
 
 class GenieWgradDesc(C.Structure):

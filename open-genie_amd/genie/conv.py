@@ -62,7 +62,7 @@ PROFILER: Optional[LaunchProfiler] = None
 
 
 VARIANT_NAMES = {0: 'igemm_kernel<128,generic>', 1: 'igemm_kernel<128,smallc>', 2: 'igemm_kernel<32,generic>', 3: 'igemm_kernel<32,smallc>',
-                 4: 'igemm3_kernel<128>', 5: 'igemm3_kernel<256>', 8: 'wgrad_kernel<128,128>', 9: 'wgrad_kernel<128,32>',
+                 4: 'igemm3_kernel<128>', 5: 'igemm3_kernel<256>', 6: 'gemm_pw_kernel', 8: 'wgrad_kernel<128,128>', 9: 'wgrad_kernel<128,32>',
                  10: 'wgrad_kernel<32,128>', 11: 'wgrad3_kernel'}
 
 
@@ -283,6 +283,12 @@ _splitk_cache = {}
 SPLITK_WS_FLOATS = 16 << 20          # 64 MiB of fp32 partial tiles per device
 
 
+def _is_pointwise(spec: 'ConvSpec') -> bool:
+    """1x1x1, stride 1, no padding, no shuffle: the conv (and its input gradient) is a plain GEMM over the pixel rows."""
+    return (spec.kernel == (1, 1, 1) and spec.stride == (1, 1, 1) and spec.shuffle is None and spec.pad_front == (0, 0, 0)
+            and spec.pad_back == (0, 0, 0))
+
+
 def _splitk_ws(device) -> Tensor:
     key = device.index if device.index is not None else torch.cuda.current_device()
     buf = _splitk_cache.get(key)
@@ -335,6 +341,7 @@ def conv_forward(x: Tensor, wpack: Tensor, bias: Optional[Tensor], spec: ConvSpe
     ws = _splitk_ws(x.device)
     d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), ws.numel() * 4
     d.tri_bm, d.tri_flags = TRI_BM, TRI_FLAGS
+    d.pointwise = int(_is_pointwise(spec) and spec.cinp % 64 == 0)
     if TRI_BM >= 0 and spec.stride == (1, 1, 1) and (to, ho, wo) == (t, h, w) and not d.small_c and pitch_of(x) % 64 == 0:
         sched = tri_schedule(('fwd', spec), _fwd_tap_list(spec), h, w, pitch_of(x))
         if sched is not None:
@@ -414,6 +421,7 @@ def conv_dgrad(dy: Tensor, wpack_bwd: Tensor, spec: ConvSpec, in_size: Triple, r
                 ws = _splitk_ws(dy.device)
                 d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), ws.numel() * 4
                 d.tri_bm, d.tri_flags = TRI_BM, TRI_FLAGS
+                d.pointwise = int(_is_pointwise(spec) and spec.coutp % 64 == 0)
                 if (TRI_BM >= 0 and st == (1, 1, 1) and spec.shuffle is None and tuple(dy.shape[2:]) == (t, h, w)
                         and pitch_of(dy) % 64 == 0):
                     sched = tri_schedule(('dgrad', spec), dgrad_taps(spec, (0, 0, 0), pitch_of(dy), want_list=True), h, w, pitch_of(dy))

@@ -252,6 +252,44 @@ def test_conv_triple_kernel(G, cin, cout, kernel, causal, size, bm, flags, monke
     assert_close_bf16(dx, xr.grad, 'triple dgrad')
 
 
+PW_CASES = [
+    # cin, cout, (n, t, h, w), residual + SiLU epilogue
+    (128, 640, (2, 8, 32, 32), False),       # wide tile: 64 x 3 tiles (the last column tile half empty), K = 128
+    (192, 1280, (2, 7, 33, 31), True),       # M = 14322: partial last row tile; 56 x 5 tiles; K = 192
+    (64, 2048, (1, 5, 32, 33), False),       # K = 64; 21 x 8 = 168 tiles: the last round is partial (the wide "vocabulary" side)
+    (512, 128, (2, 16, 32, 40), True),       # 256 x 128 tile: 160 row tiles, one column tile, eight K tiles; wide dgrad
+]
+
+
+@pytest.mark.parametrize('cin,cout,size,fused', PW_CASES)
+def test_conv_pointwise_gemm_kernel(G, cin, cout, size, fused):
+    """conv_gemm.hip (persistent GEMM for 1x1x1 convolutions / Linear layers): forward (bias, residual, SiLU epilogue) and
+    backward-data against F.conv3d; the library must report that the GEMM kernel really ran."""
+    torch.manual_seed(13)
+    n, t, h, w = size
+    x = bf16_round(torch.randn(n, cin, t, h, w))
+    wt = bf16_round(torch.randn(cout, cin, 1, 1, 1) / cin ** 0.5)
+    b = torch.randn(cout)
+    r = bf16_round(torch.randn(n, cout, t, h, w)) if fused else None
+    xr = x.clone().requires_grad_(True)
+    ref = F.conv3d(xr, wt, b)
+    dy = bf16_round(torch.randn_like(ref))
+    ref.backward(dy)
+    if fused:
+        ref = F.silu(ref + r)
+    spec = G.conv.same_spec(cin, cout, (1, 1, 1))
+    lib = G.hip.load_library()
+    out = G.conv.conv_forward(G.cl.to_cl(x.cuda()), G.conv.pack_weight_fwd(wt.cuda(), spec), b.cuda(), spec,
+                              resid=G.cl.to_cl(r.cuda()) if fused else None, act=1 if fused else 0)
+    assert lib.genie_last_conv_variant() == 6, lib.genie_last_conv_variant()
+    assert_close_bf16(out, ref, 'pointwise fwd')
+    dx = G.conv.conv_dgrad(G.cl.to_cl(dy.cuda()), G.conv.pack_weight_bwd(wt.cuda(), spec), spec, (t, h, w))
+    m = n * t * h * w
+    if cout % 64 == 0 and cin >= 96 and -(-m // 256) * -(-cin // (256 if cin > 128 else 128)) >= 160:
+        assert lib.genie_last_conv_variant() == 6, lib.genie_last_conv_variant()
+    assert_close_bf16(dx, xr.grad, 'pointwise dgrad')
+
+
 def test_conv_triple_shuffle_and_residual(G, monkeypatch):
     """The triple kernel under the depth-to-space-time store pattern (upsample conv) and with the residual add in the epilogue."""
     from oracle import genie_oracle as O
