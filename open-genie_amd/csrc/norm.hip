@@ -83,36 +83,43 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const bf16_t* __restrict_
     }
 }
 
-// ---- finalize: one 256-thread block per (n, group) sums the per-block partials of the group's channels (fixed order, fp64)
-//      and writes mean / rstd ----
-__device__ __forceinline__ double block_sum_256(double v, double* red) {
+// ---- finalize: one 1024-thread block per (n, group) sums the per-block partials of the group's channels (fixed order, fp64)
+//      and writes mean / rstd.  It is a pure latency chain between the two streaming passes (92 launches per training step), so
+//      the loads are spread over 16 waves and issued 8 deep; the (block, channel) cursor advances without divisions ----
+#define GN_FIN_THREADS 1024
+__device__ __forceinline__ double block_sum_fin(double v, double* red) {     // red: GN_FIN_THREADS / 64 doubles
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     __syncthreads();                                    // red may still be read from a previous call
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
-    return red[0] + red[1] + red[2] + red[3];
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < GN_FIN_THREADS / 64; ++w) t += red[w];
+    return t;
 }
 
-__global__ void __launch_bounds__(256) gn_finalize_kernel(const float* __restrict__ part, GnGeom g, float eps,
-                                                          float* __restrict__ mean, float* __restrict__ rstd) {
-    __shared__ double red[4];
+__global__ void __launch_bounds__(GN_FIN_THREADS) gn_finalize_kernel(const float* __restrict__ part, GnGeom g, float eps,
+                                                                     float* __restrict__ mean, float* __restrict__ rstd) {
+    __shared__ double red[GN_FIN_THREADS / 64];
     const int n = blockIdx.y, grp = blockIdx.x, tid = threadIdx.x;
     const int cg = g.C / g.G;
-    // the group's partials: nblk rows of cg (sum, sumsq) pairs = nblk * cg pairs; thread t takes pairs t, t + 256, ... of the
-    // flattened list (independent loads, fixed order per thread)
+    // the group's partials: nblk rows of cg (sum, sumsq) pairs; thread t takes pairs t, t + 1024, ... of the flattened list
     double s = 0.0, q = 0.0;
     const float* base = part + ((long long)n * g.nblk * g.Cp + (long long)grp * cg) * 2;
     const int total = g.nblk * cg;
-#pragma unroll 4
-    for (int f = tid; f < total; f += 256) {
-        const int blk = f / cg, ci = f - blk * cg;
+    const int dblk = GN_FIN_THREADS / cg, dci = GN_FIN_THREADS % cg;
+    int blk = tid / cg, ci = tid % cg;
+#pragma unroll 8
+    for (int f = tid; f < total; f += GN_FIN_THREADS) {
         const float2 v = *reinterpret_cast<const float2*>(base + ((long long)blk * g.Cp + ci) * 2);
         s += (double)v.x;
         q += (double)v.y;
+        blk += dblk; ci += dci;
+        if (ci >= cg) { ci -= cg; ++blk; }
     }
-    s = block_sum_256(s, red);
-    q = block_sum_256(q, red);
+    s = block_sum_fin(s, red);
+    q = block_sum_fin(q, red);
     if (tid == 0) {
         const double cnt = (double)cg * (double)g.npix;
         const double m = s / cnt;
@@ -183,7 +190,7 @@ extern "C" int genie_groupnorm_fwd(const void* x, void* y, int N, int64_t npix, 
     hipStream_t s = (hipStream_t)stream;
     gn_stats_kernel<<<dim3(g.nblk, N), 256, 0, s>>>((const bf16_t*)x, g, ws);
     GENIE_CHECK_LAUNCH();
-    gn_finalize_kernel<<<dim3(G, N), 256, 0, s>>>(ws, g, eps, mean, rstd);
+    gn_finalize_kernel<<<dim3(G, N), GN_FIN_THREADS, 0, s>>>(ws, g, eps, mean, rstd);
     GENIE_CHECK_LAUNCH();
     gn_apply_kernel<<<dim3(g.nblk, N), 256, 0, s>>>((const bf16_t*)x, (bf16_t*)y, g, gamma, beta, ada_scale, ada_shift, mean, rstd, act);
     GENIE_CHECK_LAUNCH();
@@ -250,28 +257,29 @@ __global__ void __launch_bounds__(256) gn_bwd_reduce_kernel(const bf16_t* __rest
     }
 }
 
-// backward finalize: one 256-thread block per (n, group).  Thread t owns channels t, t + 256, ... of the group: totals over the
-// blocks (fixed order, fp64) -> parameter gradients, then the group totals -> k2, k3 of  dx = k1 * dz + k2 * x + k3.
-__global__ void __launch_bounds__(256) gn_bwd_finalize_kernel(const float* __restrict__ part, GnGeom g, const float* __restrict__ gamma,
-                                                              const float* __restrict__ beta, const float* __restrict__ ada_s,
-                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                              float* __restrict__ dada_s, float* __restrict__ dada_b,
-                                                              float* __restrict__ kcoef) {
-    __shared__ double red[4];
+// backward finalize: one 1024-thread block per (n, group).  tpc threads share a channel (each sums a slice of the blocks, loads 8
+// deep), combined in a fixed order through LDS: totals over the blocks (fp64) -> parameter gradients, then the group totals ->
+// k2, k3 of  dx = k1 * dz + k2 * x + k3.
+__global__ void __launch_bounds__(GN_FIN_THREADS) gn_bwd_finalize_kernel(const float* __restrict__ part, GnGeom g, const float* __restrict__ gamma,
+                                                                         const float* __restrict__ beta, const float* __restrict__ ada_s,
+                                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                         float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                         float* __restrict__ dada_s, float* __restrict__ dada_b,
+                                                                         float* __restrict__ kcoef) {
+    __shared__ double red[GN_FIN_THREADS / 64];
+    __shared__ double part_s[GN_FIN_THREADS][2];
     const int n = blockIdx.y, grp = blockIdx.x, tid = threadIdx.x;
     const int cg = g.C / g.G;
-    // tpc threads share a channel (each sums a slice of the blocks), combined in a fixed order through LDS
-    __shared__ double part_s[256][2];
-    const int tpc = cg >= 256 ? 1 : (cg > 128 ? 1 : (cg > 64 ? 2 : (cg > 32 ? 4 : 8)));
-    const int cpp = 256 / tpc;                           // channels per pass
+    int tpc = 1;
+    while (tpc < 32 && cg * tpc * 2 <= GN_FIN_THREADS) tpc *= 2;     // power of two, cg * tpc <= 1024
+    const int cpp = GN_FIN_THREADS / tpc;                            // channels per pass
     double P1 = 0.0, P2 = 0.0;
     for (int c0 = 0; c0 < cg; c0 += cpp) {
         const int ci = c0 + tid / tpc, sub = tid % tpc;
         double s1 = 0.0, s2 = 0.0;
         if (ci < cg) {
             const float* o = part + ((long long)n * g.nblk * g.Cp + (grp * cg + ci)) * 2;
-#pragma unroll 4
+#pragma unroll 8
             for (int blk = sub; blk < g.nblk; blk += tpc) {
                 const float2 v = *reinterpret_cast<const float2*>(o + (long long)blk * g.Cp * 2);
                 s1 += (double)v.x;
@@ -295,8 +303,8 @@ __global__ void __launch_bounds__(256) gn_bwd_finalize_kernel(const float* __res
             P2 += (double)(float)((double)(ga * as) * s2);
         }
     }
-    P1 = block_sum_256(P1, red);
-    P2 = block_sum_256(P2, red);
+    P1 = block_sum_fin(P1, red);
+    P2 = block_sum_fin(P2, red);
     if (tid == 0) {
         const double M = (double)cg * (double)g.npix;
         const double rs = (double)rstd[n * g.G + grp], mu = (double)mean[n * g.G + grp];
@@ -366,7 +374,7 @@ extern "C" int genie_groupnorm_bwd(const void* x, const void* dy, void* dx, int 
     float* kcoef = chan + (long long)N * cpitch * 4;
     gn_bwd_reduce_kernel<<<dim3(g.nblk, N), 256, 0, s>>>((const bf16_t*)x, (const bf16_t*)dy, g, gamma, beta, ada_scale, ada_shift, mean, rstd, act, ws);
     GENIE_CHECK_LAUNCH();
-    gn_bwd_finalize_kernel<<<dim3(G, N), 256, 0, s>>>(ws, g, gamma, beta, ada_scale, mean, rstd, dgamma, dbeta, dada_scale, dada_shift, kcoef);
+    gn_bwd_finalize_kernel<<<dim3(G, N), GN_FIN_THREADS, 0, s>>>(ws, g, gamma, beta, ada_scale, mean, rstd, dgamma, dbeta, dada_scale, dada_shift, kcoef);
     GENIE_CHECK_LAUNCH();
     gn_bwd_apply_kernel<<<dim3(g.nblk, N), 256, 0, s>>>((const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, g, gamma, beta, ada_scale, ada_shift, mean, rstd, kcoef, act);
     GENIE_CHECK_LAUNCH();
