@@ -79,6 +79,20 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16_t (&ac
                     if (n < a.Ncols) bias4[e] = a.bias[a.perm_f > 1 ? (n % a.perm_c) * a.perm_f + n / a.perm_c : n];
                 }
             }
+            // residual rows of this column tile: all loads are issued before the first use (one load + dependent add per group
+            // serialised TM * 4 global round trips per column tile -- the 1x1 shortcut dgrad, which is pure traffic, ran at half
+            // the speed of the same GEMM without a residual)
+            u32x2_t rres[TM][4];
+            if (a.resid) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int ro = rowoff[wm * (TM * 32) + i * 32 + 8 * g + 4 * khalf + jq];
+                        rres[i][g] = u32x2_t{0u, 0u};
+                        if (ro >= 0 && colok) rres[i][g] = *reinterpret_cast<const u32x2_t*>(a.resid + (unsigned)ro + coloff);
+                    }
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -107,7 +121,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16_t (&ac
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] += bias4[e];
                     if (a.resid) {
-                        const u32x2_t rv = *reinterpret_cast<const u32x2_t*>(a.resid + (unsigned)ro + coloff);
+                        const u32x2_t rv = rres[i][g];
                         v[0] += __uint_as_float(rv[0] << 16); v[1] += __uint_as_float(rv[0] & 0xffff0000u);
                         v[2] += __uint_as_float(rv[1] << 16); v[3] += __uint_as_float(rv[1] & 0xffff0000u);
                     }
