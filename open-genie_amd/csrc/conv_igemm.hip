@@ -213,18 +213,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmArgs a) {
 
     // ---- split-K: dump the fp32 partial tile, the finish kernel does bias / resid / act / layout ----
     if (a.split_k > 1) {
-        float* wsp = a.ws + (size_t)blockIdx.y * a.M * a.ws_ld;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn * (TN * 32) + j * 32 + (lane & 31);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int r16 = 0; r16 < 16; ++r16) {
-                    const int m = m0 + wm * (TM * 32) + i * 32 + (r16 & 3) + 8 * (r16 >> 2) + 4 * khalf;
-                    if (m < a.M && n < a.ws_ld) wsp[(size_t)m * a.ws_ld + n] = acc[i][j][r16];
-                }
-        }
+        igemm_store_partials<TM, TN>(a, acc, blockIdx.y, m0, n0, wm, wn, lane);
         return;
     }
 
@@ -253,6 +242,15 @@ __global__ void __launch_bounds__(256) igemm_splitk_finish_kernel(const IgemmArg
     }
 }
 
+int genie_igemm_splitk_finish(const IgemmArgs& a, hipStream_t s) {      // also used by the kw-triple kernels (conv_igemm3.hip)
+    long long total = (long long)a.M * a.Nstore;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(igemm_splitk_finish_kernel, dim3(grid), dim3(256), 0, s, a);
+    GENIE_CHECK_LAUNCH();
+    return GENIE_OK;
+}
+
 template <int BN, int WM, int WN, bool SMALLC>
 static int launch_igemm(const IgemmArgs& a, hipStream_t s) {
     constexpr int STAGE = 128 * 128 + BN * 128;
@@ -269,13 +267,7 @@ static int launch_igemm(const IgemmArgs& a, hipStream_t s) {
     }
     hipLaunchKernelGGL(k, dim3(a.tiles_m * a.tiles_n, a.split_k > 1 ? a.split_k : 1), dim3(256), lds, s, a);
     GENIE_CHECK_LAUNCH();
-    if (a.split_k > 1) {
-        long long total = (long long)a.M * a.Nstore;
-        int grid = (int)((total + 255) / 256);
-        if (grid > 4096) grid = 4096;
-        hipLaunchKernelGGL(igemm_splitk_finish_kernel, dim3(grid), dim3(256), 0, s, a);
-        GENIE_CHECK_LAUNCH();
-    }
+    if (a.split_k > 1) return genie_igemm_splitk_finish(a, s);
     return GENIE_OK;
 }
 

@@ -45,6 +45,12 @@ __global__ void __launch_bounds__(BM * 2) igemm3_kernel(const Igemm3Args p, cons
     constexpr int B_LOADS = BN / RPR;                   // 2 (512 threads) or 4 (256 threads)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const IgemmArgs& a = p.g;
+    int nsteps = p.nsteps;
+    if (a.split_k > 1) {                                // blockIdx.y = K split: a contiguous range of the step table
+        const int s0 = (int)blockIdx.y * a.chunks_per_split;
+        steps += s0;
+        nsteps = nsteps - s0 < a.chunks_per_split ? nsteps - s0 : a.chunks_per_split;
+    }
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -201,9 +207,9 @@ __global__ void __launch_bounds__(BM * 2) igemm3_kernel(const Igemm3Args p, cons
     sync_all();
 
     int kpar = 0;                                       // parity of the current K-tile (selects the weight buffer)
-    for (int i = 0; i < p.nsteps; ++i) {
+    for (int i = 0; i < nsteps; ++i) {
         const GenieTriStep cur = steps[i];
-        const bool has_next = i + 1 < p.nsteps;
+        const bool has_next = i + 1 < nsteps;
         const GenieTriStep nxt = steps[has_next ? i + 1 : i];
         char* const acur = A0 + (i & 1) * A_BYTES;
         char* const anxt = A0 + ((i + 1) & 1) * A_BYTES;
@@ -233,6 +239,10 @@ __global__ void __launch_bounds__(BM * 2) igemm3_kernel(const Igemm3Args p, cons
         kpar ^= 1;
     }
 
+    if (a.split_k > 1) {
+        igemm_store_partials<TM, TN>(a, acc, blockIdx.y, m0, n0, wm, wn, lane);
+        return;
+    }
     igemm_epilogue<BM, TM, TN>(a, acc, smem, m0, n0, wm, wn, tid, lane);
 }
 
@@ -262,6 +272,12 @@ __global__ void __launch_bounds__(512) igemm3d_kernel(const Igemm3Args p, const 
     static_assert(B_LOADS == 2, "the counted waits below assume 2 weight glds per thread per K-tile");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const IgemmArgs& a = p.g;
+    int nsteps = p.nsteps;
+    if (a.split_k > 1) {                                // blockIdx.y = K split: a contiguous range of the step table
+        const int s0 = (int)blockIdx.y * a.chunks_per_split;
+        steps += s0;
+        nsteps = nsteps - s0 < a.chunks_per_split ? nsteps - s0 : a.chunks_per_split;
+    }
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -415,8 +431,8 @@ __global__ void __launch_bounds__(512) igemm3d_kernel(const Igemm3Args p, const 
         };
         preread(A0, 0, B0);
         int k = 0;
-        for (int i = 0; i < p.nsteps; ++i, k += 3) {
-            const bool has_next = i + 1 < p.nsteps;
+        for (int i = 0; i < nsteps; ++i, k += 3) {
+            const bool has_next = i + 1 < nsteps;
             const GenieTriStep nxt = steps[has_next ? i + 1 : i];
             char* const acur = A0 + (i & 1) * A_BYTES;
             char* const anxt = A0 + ((i + 1) & 1) * A_BYTES;
@@ -454,9 +470,9 @@ __global__ void __launch_bounds__(512) igemm3d_kernel(const Igemm3Args p, const 
         }
     } else {
         int k = 0;                                          // K-tile index (3 i + s); weight tile k sits in slot k & 3
-        for (int i = 0; i < p.nsteps; ++i, k += 3) {
+        for (int i = 0; i < nsteps; ++i, k += 3) {
             const GenieTriStep cur = steps[i];
-            const bool has_next = i + 1 < p.nsteps;
+            const bool has_next = i + 1 < nsteps;
             const GenieTriStep nxt = steps[has_next ? i + 1 : i];
             char* const acur = A0 + (i & 1) * A_BYTES;
             char* const anxt = A0 + ((i + 1) & 1) * A_BYTES;
@@ -490,8 +506,14 @@ __global__ void __launch_bounds__(512) igemm3d_kernel(const Igemm3Args p, const 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     raw_barrier();
 
+    if (a.split_k > 1) {
+        igemm_store_partials<TM, TN>(a, acc, blockIdx.y, m0, n0, wm, wn, lane);
+        return;
+    }
     igemm_epilogue<BM, TM, TN>(a, acc, smem, m0, n0, wm, wn, tid, lane);
 }
+
+int genie_igemm_splitk_finish(const IgemmArgs& a, hipStream_t s);      // conv_igemm.hip
 
 template <bool PRE>
 static int launch_igemm3d(const Igemm3Args& p, const GenieTriStep* steps, hipStream_t s) {
@@ -505,8 +527,9 @@ static int launch_igemm3d(const Igemm3Args& p, const GenieTriStep* steps, hipStr
         }
         configured = true;
     }
-    hipLaunchKernelGGL(igemm3d_kernel<PRE>, dim3(p.g.tiles_m * p.g.tiles_n), dim3(512), lds, s, p, steps);
+    hipLaunchKernelGGL(igemm3d_kernel<PRE>, dim3(p.g.tiles_m * p.g.tiles_n, p.g.split_k > 1 ? p.g.split_k : 1), dim3(512), lds, s, p, steps);
     GENIE_CHECK_LAUNCH();
+    if (p.g.split_k > 1) return genie_igemm_splitk_finish(p.g, s);
     return GENIE_OK;
 }
 
@@ -524,8 +547,9 @@ static int launch_igemm3(const Igemm3Args& p, const GenieTriStep* steps, hipStre
         }
         configured = true;
     }
-    hipLaunchKernelGGL(k, dim3(p.g.tiles_m * p.g.tiles_n), dim3(NT), lds, s, p, steps);
+    hipLaunchKernelGGL(k, dim3(p.g.tiles_m * p.g.tiles_n, p.g.split_k > 1 ? p.g.split_k : 1), dim3(NT), lds, s, p, steps);
     GENIE_CHECK_LAUNCH();
+    if (p.g.split_k > 1) return genie_igemm_splitk_finish(p.g, s);
     return GENIE_OK;
 }
 
@@ -540,10 +564,27 @@ int genie_conv_igemm3_try(const GenieConvDesc* d, IgemmArgs a, hipStream_t s) {
     if (d->Ts >= 32768 || d->Hs >= 65536) return 1;
     int bm = d->tri_bm;
     const int tiles_n = cdiv(a.Nstore, 128);
+    int split = 1, per_split = d->n_tri_steps;
     if (bm == 0) {
         const long long t128 = (long long)cdiv(a.M, 128) * tiles_n, t256 = (long long)cdiv(a.M, 256) * tiles_n;
-        if (t128 < 256) return 1;                        // few tiles: the generic kernel's split-K fills the chip better
-        bm = (256 % W == 0 && t256 >= 512) ? 256 : 128;
+        static const int mode = getenv("GENIE_TRI_SPLITK") ? atoi(getenv("GENIE_TRI_SPLITK")) : 1;
+        if (t256 <= 128 && mode && d->splitk_ws && 256 % W == 0 && a.M >= 1024) {
+            // Few tiles (low-resolution layers): split the step table over blockIdx.y so that the 256-row deep-prefetch kernel
+            // still gets one block per CU; fp32 partials go to the split-K scratch and igemm_splitk_finish_kernel finishes
+            // (512 -> 512 @ 4x8x8, B = 8: 486 -> 524 TFLOP/s against the generic kernel's split-K on a box that ran 5 % slow).
+            int sk = (int)(256 / t256);
+            per_split = cdiv(d->n_tri_steps, sk);
+            if (per_split < 6) per_split = 6;                                    // >= 18 K tiles per block
+            sk = cdiv(d->n_tri_steps, per_split);
+            if (sk >= 2 && (long long)sk * a.M * a.Nstore * 4 <= d->splitk_ws_bytes) {
+                split = sk;
+                bm = 256;
+            }
+        }
+        if (bm == 0) {
+            if (t128 < 256) return 1;                    // few tiles: the generic kernel's split-K fills the chip better
+            bm = (256 % W == 0 && t256 >= 512) ? 256 : 128;
+        }
     }
     if (bm != 128 && bm != 256) {
         genie_set_error("genie_conv_igemm: tri_bm must be 0, 128 or 256 (got %d)", bm);
@@ -557,7 +598,10 @@ int genie_conv_igemm3_try(const GenieConvDesc* d, IgemmArgs a, hipStream_t s) {
     p.g = a;
     p.g.tiles_m = cdiv(a.M, bm);
     p.g.tiles_n = tiles_n;
-    p.g.split_k = 1;
+    p.g.split_k = split;
+    p.g.chunks_per_split = per_split;                   // steps per split
+    p.g.ws = split > 1 ? (float*)d->splitk_ws : nullptr;
+    p.g.ws_ld = a.Nstore;
     p.nsteps = d->n_tri_steps;
     p.WP = W + 2;
     p.img_rows = (bm / W) * (W + 2);

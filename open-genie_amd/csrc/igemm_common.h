@@ -162,3 +162,23 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16_t (&ac
         }
     }
 }
+
+// split-K: dump the wave's fp32 partial tile to ws[split][m][n]; igemm_splitk_finish_kernel (conv_igemm.hip) sums the splits and
+// applies bias / resid / act / the destination mapping.
+template <int TM, int TN>
+__device__ __forceinline__ void igemm_store_partials(const IgemmArgs& a, f32x16_t (&acc)[TM][TN], int split, int m0, int n0, int wm, int wn,
+                                                     int lane) {
+    float* wsp = a.ws + (size_t)split * a.M * a.ws_ld;
+    const int khalf = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * (TN * 32) + j * 32 + (lane & 31);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r16 = 0; r16 < 16; ++r16) {
+                const int m = m0 + wm * (TM * 32) + i * 32 + (r16 & 3) + 8 * (r16 >> 2) + 4 * khalf;
+                if (m < a.M && n < a.ws_ld) wsp[(size_t)m * a.ws_ld + n] = acc[i][j][r16];
+            }
+    }
+}

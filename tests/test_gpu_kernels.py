@@ -290,6 +290,32 @@ def test_conv_pointwise_gemm_kernel(G, cin, cout, size, fused):
     assert_close_bf16(dx, xr.grad, 'pointwise dgrad')
 
 
+@pytest.mark.parametrize('cin,cout,size', [(128, 128, (2, 4, 16, 16)), (256, 192, (1, 8, 16, 8)), (512, 512, (8, 4, 8, 8))])
+def test_conv_triple_split_k(G, cin, cout, size, monkeypatch):
+    """Low-resolution layers: too few row tiles to fill the chip, so the kw-triple step table is split over blockIdx.y (fp32
+    partial tiles + finish kernel).  Automatic tile choice must pick the 256-row triple kernel; forward (bias) and backward-data."""
+    monkeypatch.setattr(G.conv, 'TRI_BM', 0)
+    monkeypatch.setattr(G.conv, 'TRI_FLAGS', 0)
+    torch.manual_seed(14)
+    n, t, h, w = size
+    x = bf16_round(torch.randn(n, cin, t, h, w))
+    wt = bf16_round(torch.randn(cout, cin, 3, 3, 3) / (cin * 27) ** 0.5)
+    b = torch.randn(cout)
+    xr = x.clone().requires_grad_(True)
+    ref = F.conv3d(xr, wt, b, padding=1)
+    dy = bf16_round(torch.randn_like(ref))
+    ref.backward(dy)
+    spec = G.conv.same_spec(cin, cout, (3, 3, 3))
+    lib = G.hip.load_library()
+    out = G.conv.conv_forward(G.cl.to_cl(x.cuda()), G.conv.pack_weight_fwd(wt.cuda(), spec), b.cuda(), spec)
+    assert lib.genie_last_conv_variant() == 5, lib.genie_last_conv_variant()
+    assert_close_bf16(out, ref, 'split-K triple fwd')
+    dx = G.conv.conv_dgrad(G.cl.to_cl(dy.cuda()), G.conv.pack_weight_bwd(wt.cuda(), spec), spec, (t, h, w))
+    if cout % 64 == 0:
+        assert lib.genie_last_conv_variant() == 5, lib.genie_last_conv_variant()
+    assert_close_bf16(dx, xr.grad, 'split-K triple dgrad')
+
+
 def test_conv_triple_shuffle_and_residual(G, monkeypatch):
     """The triple kernel under the depth-to-space-time store pattern (upsample conv) and with the residual add in the epilogue."""
     from oracle import genie_oracle as O
