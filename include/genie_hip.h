@@ -123,6 +123,7 @@ int genie_conv_igemm(const GenieConvDesc* desc, void* stream);
 #define GENIE_VARIANT_IGEMM3_128 4
 #define GENIE_VARIANT_IGEMM3_256 5
 #define GENIE_VARIANT_GEMM_PW 6
+#define GENIE_VARIANT_IGEMM3_256_SPLITK 7
 #define GENIE_VARIANT_WGRAD_128 8
 #define GENIE_VARIANT_WGRAD_128x32 9
 #define GENIE_VARIANT_WGRAD_32x128 10

@@ -263,7 +263,7 @@ __global__ void __launch_bounds__(BM * 2) igemm3_kernel(const Igemm3Args p, cons
 // landed data to all waves (RAW) and fences the slot that the NEXT group overwrites (WAR: slot (k+4) & 3 = k & 3 was read in
 // K-tile k, the spare image was last read in K-tile 3i-1).
 // ------------------------------------------------------------------------------------------------------------------------------
-template <bool PRE>
+template <bool PRE, bool SPLITK>
 __global__ void __launch_bounds__(512) igemm3d_kernel(const Igemm3Args p, const GenieTriStep* __restrict__ steps) {
     constexpr int BM = 256, BN = 128, NT = 512, NWAVE = 8, WN = 2, TM = 2, TN = 2;
     constexpr int RPR = NT / 8, A_ROUNDS = 5;
@@ -273,7 +273,7 @@ __global__ void __launch_bounds__(512) igemm3d_kernel(const Igemm3Args p, const 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const IgemmArgs& a = p.g;
     int nsteps = p.nsteps;
-    if (a.split_k > 1) {                                // blockIdx.y = K split: a contiguous range of the step table
+    if (SPLITK) {                                       // blockIdx.y = K split: a contiguous range of the step table
         const int s0 = (int)blockIdx.y * a.chunks_per_split;
         steps += s0;
         nsteps = nsteps - s0 < a.chunks_per_split ? nsteps - s0 : a.chunks_per_split;
@@ -506,7 +506,7 @@ __global__ void __launch_bounds__(512) igemm3d_kernel(const Igemm3Args p, const 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     raw_barrier();
 
-    if (a.split_k > 1) {
+    if (SPLITK) {
         igemm_store_partials<TM, TN>(a, acc, blockIdx.y, m0, n0, wm, wn, lane);
         return;
     }
@@ -515,22 +515,27 @@ __global__ void __launch_bounds__(512) igemm3d_kernel(const Igemm3Args p, const 
 
 int genie_igemm_splitk_finish(const IgemmArgs& a, hipStream_t s);      // conv_igemm.hip
 
-template <bool PRE>
-static int launch_igemm3d(const Igemm3Args& p, const GenieTriStep* steps, hipStream_t s) {
+template <bool PRE, bool SPLITK>
+static int launch_igemm3d_t(const Igemm3Args& p, const GenieTriStep* steps, hipStream_t s) {
     constexpr int lds = 2 * (5 * 64 * 128) + 4 * 128 * 128;
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)igemm3d_kernel<PRE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipError_t e = hipFuncSetAttribute((const void*)igemm3d_kernel<PRE, SPLITK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) {
             genie_set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e));
             return GENIE_ERR_HIP;
         }
         configured = true;
     }
-    hipLaunchKernelGGL(igemm3d_kernel<PRE>, dim3(p.g.tiles_m * p.g.tiles_n, p.g.split_k > 1 ? p.g.split_k : 1), dim3(512), lds, s, p, steps);
+    hipLaunchKernelGGL((igemm3d_kernel<PRE, SPLITK>), dim3(p.g.tiles_m * p.g.tiles_n, SPLITK ? p.g.split_k : 1), dim3(512), lds, s, p, steps);
     GENIE_CHECK_LAUNCH();
-    if (p.g.split_k > 1) return genie_igemm_splitk_finish(p.g, s);
+    if (SPLITK) return genie_igemm_splitk_finish(p.g, s);
     return GENIE_OK;
+}
+
+template <bool PRE>
+static int launch_igemm3d(const Igemm3Args& p, const GenieTriStep* steps, hipStream_t s) {
+    return p.g.split_k > 1 ? launch_igemm3d_t<PRE, true>(p, steps, s) : launch_igemm3d_t<PRE, false>(p, steps, s);
 }
 
 template <int BM, bool PIPE>
@@ -607,7 +612,7 @@ int genie_conv_igemm3_try(const GenieConvDesc* d, IgemmArgs a, hipStream_t s) {
     p.img_rows = (bm / W) * (W + 2);
     p.dbg = d->tri_flags & ~3;
     const bool pipe = (d->tri_flags & 1) == 0;
-    genie_note_variant(bm == 256 ? GENIE_VARIANT_IGEMM3_256 : GENIE_VARIANT_IGEMM3_128);
+    genie_note_variant(split > 1 ? GENIE_VARIANT_IGEMM3_256_SPLITK : (bm == 256 ? GENIE_VARIANT_IGEMM3_256 : GENIE_VARIANT_IGEMM3_128));
     if (bm == 256 && (d->tri_flags & 2) == 0)                                                  // deep-prefetch schedules
         return (d->tri_flags & 64) ? launch_igemm3d<false>(p, d->tri_steps, s) : launch_igemm3d<true>(p, d->tri_steps, s);
     if (bm == 256) return pipe ? launch_igemm3<256, true>(p, d->tri_steps, s) : launch_igemm3<256, false>(p, d->tri_steps, s);

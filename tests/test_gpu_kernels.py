@@ -308,11 +308,11 @@ def test_conv_triple_split_k(G, cin, cout, size, monkeypatch):
     spec = G.conv.same_spec(cin, cout, (3, 3, 3))
     lib = G.hip.load_library()
     out = G.conv.conv_forward(G.cl.to_cl(x.cuda()), G.conv.pack_weight_fwd(wt.cuda(), spec), b.cuda(), spec)
-    assert lib.genie_last_conv_variant() == 5, lib.genie_last_conv_variant()
+    assert lib.genie_last_conv_variant() == 7, lib.genie_last_conv_variant()
     assert_close_bf16(out, ref, 'split-K triple fwd')
     dx = G.conv.conv_dgrad(G.cl.to_cl(dy.cuda()), G.conv.pack_weight_bwd(wt.cuda(), spec), spec, (t, h, w))
     if cout % 64 == 0:
-        assert lib.genie_last_conv_variant() == 5, lib.genie_last_conv_variant()
+        assert lib.genie_last_conv_variant() == 7, lib.genie_last_conv_variant()
     assert_close_bf16(dx, xr.grad, 'split-K triple dgrad')
 
 
