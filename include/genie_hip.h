@@ -104,7 +104,8 @@ typedef struct GenieConvDesc {
      * blocks): DEVICE pointer to n_tri_steps entries covering the same K range as `taps`.  tri_bm: 0 = choose the row tile,
      * 128 / 256 = force it, -1 = ignore the schedule; tri_flags (debug / A-B timing) bit 0: drain every barrier instead of
      * counted waits, bit 1: one-tile-ahead schedule for the 256-row tile instead of the deep-prefetch one; bits 2-5: timing ablations
-     * (wrong results). */
+     * (wrong results); bit 6: deep-prefetch schedule without the pre-read; bit 7: persistent form of the 256-row kernel (one
+     * block per CU walks its tiles); bit 8: 4 waves of 128 x 64 instead of 8 of 64 x 64 (both measured, neither faster). */
     const GenieTriStep* tri_steps;
     int32_t n_tri_steps;
     int32_t tri_bm;

@@ -263,13 +263,16 @@ __global__ void __launch_bounds__(BM * 2) igemm3_kernel(const Igemm3Args p, cons
 // landed data to all waves (RAW) and fences the slot that the NEXT group overwrites (WAR: slot (k+4) & 3 = k & 3 was read in
 // K-tile k, the spare image was last read in K-tile 3i-1).
 // ------------------------------------------------------------------------------------------------------------------------------
-template <bool PRE, bool SPLITK>
-__global__ void __launch_bounds__(512) igemm3d_kernel(const Igemm3Args p, const GenieTriStep* __restrict__ steps) {
-    constexpr int BM = 256, BN = 128, NT = 512, NWAVE = 8, WN = 2, TM = 2, TN = 2;
-    constexpr int RPR = NT / 8, A_ROUNDS = 5;
+// NWAVE = 8: 2 waves per SIMD, 64 x 64 per wave.  NWAVE = 4 (PRE only): ONE wave per SIMD owning 128 x 64 (TM = 4) -- no contention for
+// the matrix pipe between co-resident waves, 6 fragment reads per 8 MFMAs instead of 4 per 4, four waves at the barrier instead
+// of eight; each thread issues twice the DMA pieces.
+template <bool PRE, bool SPLITK, int NWAVE>
+__global__ void __launch_bounds__(64 * NWAVE) igemm3d_kernel(const Igemm3Args p, const GenieTriStep* __restrict__ steps) {
+    constexpr int BM = 256, BN = 128, NT = 64 * NWAVE, WN = 2, WM = NWAVE / WN, TM = BM / (WM * 32), TN = 2;
+    constexpr int RPR = NT / 8, A_ROUNDS = 320 / RPR;
     constexpr int A_BYTES = A_ROUNDS * RPR * 128, B_BYTES = BN * 128;
-    constexpr int B_LOADS = BN / RPR;                   // 2
-    static_assert(B_LOADS == 2, "the counted waits below assume 2 weight glds per thread per K-tile");
+    constexpr int B_LOADS = BN / RPR;                   // 2 (8 waves) or 4 (4 waves)
+    static_assert(NWAVE == 8 || (NWAVE == 4 && PRE), "the 4-wave form exists for the pre-read schedule only");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const IgemmArgs& a = p.g;
     int nsteps = p.nsteps;
@@ -339,7 +342,7 @@ __global__ void __launch_bounds__(512) igemm3d_kernel(const Igemm3Args p, const 
     const int khalf = lane >> 5;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        const int pl = wm * 64 + i * 32 + (lane & 31);
+        const int pl = wm * (TM * 32) + i * 32 + (lane & 31);
         const int hl = pl / W;
         const int row0 = hl * WP + (pl - hl * W);       // image row of (pixel, dw = -1); + s for dw = s - 1
 #pragma unroll
@@ -351,7 +354,7 @@ __global__ void __launch_bounds__(512) igemm3d_kernel(const Igemm3Args p, const 
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int row = wn * 64 + j * 32 + (lane & 31);
+        const int row = wn * (TN * 32) + j * 32 + (lane & 31);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) b_off[ks][j] = (unsigned)(row * 128 + (((ks * 2 + khalf) ^ ((row >> 1) & 7)) << 4));
     }
@@ -455,17 +458,16 @@ __global__ void __launch_bounds__(512) igemm3d_kernel(const Igemm3Args p, const 
                 preread(NEXT_A, NEXT_S, bnext);                                                                  \
                 mfma4(fa1, fb1);                                                                                 \
                 __builtin_amdgcn_sched_barrier(0);                                                               \
-                asm volatile("s_waitcnt vmcnt(" #WAITN ")" ::: "memory");                                        \
+                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WAITN) : "memory");                                    \
                 raw_barrier();                                                                                   \
             }
             GENIE_KTILE(0,
-                        stage_a(nxt, has_next, 0, anxt); stage_a(nxt, has_next, 1, anxt); stage_a(nxt, has_next, 2, anxt);
-                        stage_a(nxt, has_next, 3, anxt); stage_a(nxt, has_next, 4, anxt);
+                        _Pragma("unroll") for (int ar = 0; ar < A_ROUNDS; ++ar) stage_a(nxt, has_next, ar, anxt);
                         __builtin_amdgcn_sched_barrier(0);
                         stage_b(nxt.wofs0, has_next, B0 + ((k + 3) & 3) * B_BYTES);,
-                        acur, 1, 7)
-            GENIE_KTILE(1, stage_b(nxt.wofs1, has_next, B0 + ((k + 4) & 3) * B_BYTES);, acur, 2, 2)
-            GENIE_KTILE(2, stage_b(nxt.wofs2, has_next, B0 + ((k + 5) & 3) * B_BYTES);, anxt, 0, 2)
+                        acur, 1, A_ROUNDS + B_LOADS)
+            GENIE_KTILE(1, stage_b(nxt.wofs1, has_next, B0 + ((k + 4) & 3) * B_BYTES);, acur, 2, B_LOADS)
+            GENIE_KTILE(2, stage_b(nxt.wofs2, has_next, B0 + ((k + 5) & 3) * B_BYTES);, anxt, 0, B_LOADS)
 #undef GENIE_KTILE
         }
     } else {
@@ -515,19 +517,249 @@ __global__ void __launch_bounds__(512) igemm3d_kernel(const Igemm3Args p, const 
 
 int genie_igemm_splitk_finish(const IgemmArgs& a, hipStream_t s);      // conv_igemm.hip
 
-template <bool PRE, bool SPLITK>
+// ------------------------------------------------------------------------------------------------------------------------------
+// Persistent form of igemm3d_kernel<true, false>: one block per CU walks its tiles and the K-tile stream of the schedule above
+// runs straight through tile boundaries -- during the LAST step of a tile the image and the three weight tiles of the next
+// tile's first step are issued (loader state = row addresses / coordinates / weight rows of the tile being LOADED, switched at
+// the start of that last step), and the pre-read before the last barrier already holds the next tile's first MFMA operands.
+// A 128-channel layer is 18 steps = 54 K-tiles per tile: the pipeline fill (image + three weight tiles, then a full drain) and
+// the epilogue were ~10 % of a tile's time with one tile per launch slot.  The epilogue's row offsets live in their own KiB
+// behind the rings (the DMA of the next tile is in flight while it runs); its stores only make the counted waits of the next
+// K-tiles more conservative (loads retire in order among themselves).
+// ------------------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(512) igemm3p_kernel(const Igemm3Args p, const GenieTriStep* __restrict__ steps) {
+    constexpr int BM = 256, BN = 128, NT = 512, NWAVE = 8, WN = 2, TM = 2, TN = 2;
+    constexpr int RPR = NT / 8, A_ROUNDS = 5;
+    constexpr int A_BYTES = A_ROUNDS * RPR * 128, B_BYTES = BN * 128;
+    constexpr int B_LOADS = BN / RPR;                   // 2
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const IgemmArgs& a = p.g;
+    const int nsteps = p.nsteps;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int W = a.Wo, H = a.Ho, T = a.To, WP = p.WP;
+    const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page3);
+    const int ntiles = a.tiles_m * a.tiles_n, G = (int)gridDim.x;
+
+    // tile `it` of this block: rounds of G tiles, consecutive ids of a round on one XCD, tile_n fastest (as the one-tile kernel)
+    auto tile_of = [&](int it, int& m0, int& n0) -> bool {
+        const int base = it * G;
+        const int left = ntiles - base;
+        if (left <= 0) return false;
+        const int g = left < G ? left : G;
+        if ((int)blockIdx.x >= g) return false;
+        const int id = base + xcd_tile_id(g, blockIdx.x);
+        m0 = (id / a.tiles_n) * BM;
+        n0 = (id % a.tiles_n) * BN;
+        return true;
+    };
+
+    // ---- loader state: the tile whose steps are being ISSUED ----
+    unsigned a_base[A_ROUNDS];
+    int a_th[A_ROUNDS];
+    bool b_ok[B_LOADS];
+    const bf16_t* b_ptr[B_LOADS];
+    bool l_live;
+    auto loader_setup = [&](int it) {
+        int m0, n0;
+        l_live = tile_of(it, m0, n0);
+        if (!l_live) return;
+        const int row0_id = m0 / W;
+#pragma unroll
+        for (int i = 0; i < A_ROUNDS; ++i) {
+            const int r = i * RPR + (tid >> 3);
+            const int lc = (tid & 7) ^ ((r >> 1) & 7);
+            const int hl = r / WP, w = r - hl * WP - 1;
+            const int rowid = row0_id + hl;
+            const long long m = (long long)rowid * W + w;
+            const bool valid = r < p.img_rows && w >= 0 && w < W && m < a.M;
+            a_base[i] = valid ? (unsigned)m * (unsigned)a.Cs + lc * 8 : 0u;
+            a_th[i] = valid ? ((((rowid / H) % T) << 16) | (rowid % H)) : (int)0x80000000;
+        }
+#pragma unroll
+        for (int j = 0; j < B_LOADS; ++j) {
+            const int row = j * RPR + (tid >> 3);
+            const int lc = (tid & 7) ^ ((row >> 1) & 7);
+            const int n = n0 + row;
+            b_ok[j] = n < a.Ncols;
+            const int wr = b_ok[j] ? (a.perm_f > 1 ? (n % a.perm_c) * a.perm_f + n / a.perm_c : n) : 0;
+            b_ptr[j] = a.wgt + (size_t)wr * a.w_row_stride + lc * 8;
+        }
+    };
+    auto stage_a = [&](const GenieTriStep& e, bool live, int i, char* abuf) {
+        const int t = (a_th[i] >> 16) + e.dt, h = (a_th[i] & 0xffff) + e.dh;
+        const bool ok = live & ((unsigned)t < (unsigned)T) & ((unsigned)h < (unsigned)H);
+        const bf16_t* q = a.src + (int)(a_base[i] + (unsigned)e.a_delta);
+        q = ok ? q : zero;
+        __builtin_amdgcn_global_load_lds(GLB_PTR(q), LDS_PTR(abuf + (i * NWAVE + wave) * 1024), 16, 0, 0);
+    };
+    auto stage_b = [&](int wofs, bool live, char* bbuf) {
+#pragma unroll
+        for (int j = 0; j < B_LOADS; ++j) {
+            const bf16_t* q = (live & b_ok[j]) ? b_ptr[j] + wofs : zero;
+            __builtin_amdgcn_global_load_lds(GLB_PTR(q), LDS_PTR(bbuf + (j * NWAVE + wave) * 1024), 16, 0, 0);
+        }
+    };
+
+    unsigned a_off[3][4][TM], b_off[4][TN];
+    const int khalf = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int pl = wm * 64 + i * 32 + (lane & 31);
+        const int hl = pl / W;
+        const int row0 = hl * WP + (pl - hl * W);       // image row of (pixel, dw = -1); + s for dw = s - 1
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int row = row0 + s;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) a_off[s][ks][i] = (unsigned)(row * 128 + (((ks * 2 + khalf) ^ ((row >> 1) & 7)) << 4));
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int row = wn * 64 + j * 32 + (lane & 31);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) b_off[ks][j] = (unsigned)(row * 128 + (((ks * 2 + khalf) ^ ((row >> 1) & 7)) << 4));
+    }
+
+    f32x16_t acc[TM][TN];
+    auto raw_barrier = [&]() {
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    char* const A0 = smem;
+    char* const B0 = smem + 2 * A_BYTES;                // four weight slots
+    char* const epi = B0 + 4 * B_BYTES;                 // 1 KiB of row offsets for the epilogue
+
+    // ---- prologue (once per block): image 0 and weight tiles 0, 1, 2 of the first tile ----
+    loader_setup(0);
+    {
+        const GenieTriStep e = steps[0];
+#pragma unroll
+        for (int i = 0; i < A_ROUNDS; ++i) stage_a(e, l_live, i, A0);
+        stage_b(e.wofs0, l_live, B0);
+        stage_b(e.wofs1, l_live, B0 + B_BYTES);
+        stage_b(e.wofs2, l_live, B0 + 2 * B_BYTES);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    raw_barrier();
+
+    bf16x8_t af0[TM], bf0[TN];
+    auto preread = [&](const char* abuf, int s, const char* bbuf) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af0[i] = *reinterpret_cast<const bf16x8_t*>(abuf + a_off[s][0][i]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf0[j] = *reinterpret_cast<const bf16x8_t*>(bbuf + b_off[0][j]);
+    };
+    auto mfma4 = [&](const bf16x8_t (&fa)[TM], const bf16x8_t (&fb)[TN]) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    };
+    auto read_ks = [&](const char* abuf, int s, const char* bbuf, int ks, bf16x8_t (&fa)[TM], bf16x8_t (&fb)[TN]) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8_t*>(abuf + a_off[s][ks][i]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const bf16x8_t*>(bbuf + b_off[ks][j]);
+    };
+    preread(A0, 0, B0);
+
+    int k = 0;                                          // K-tile counter of the whole stream: weight tile k sits in slot k & 3
+    int ip = 0;                                         // step counter parity: the image of the current step sits in A0 + ip * A_BYTES
+    for (int it = 0;; ++it) {
+        int m0, n0;
+        if (!tile_of(it, m0, n0)) break;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int i = 0; i < nsteps; ++i, k += 3, ip ^= 1) {
+            const bool last = i + 1 == nsteps;
+            if (last) loader_setup(it + 1);             // every load of this tile is out: the loader moves on to the next tile
+            const bool has_next = last ? l_live : true;
+            const GenieTriStep nxt = steps[last ? 0 : i + 1];
+            char* const acur = A0 + ip * A_BYTES;
+            char* const anxt = A0 + (ip ^ 1) * A_BYTES;
+#define GENIE_KTILE(S, ISSUE, NEXT_A, NEXT_S, WAITN)                                                              \
+            {                                                                                                    \
+                const char* bcur = B0 + ((k + S) & 3) * B_BYTES;                                                 \
+                const char* bnext = B0 + ((k + S + 1) & 3) * B_BYTES;                                            \
+                bf16x8_t fa1[TM], fb1[TN], fa2[TM], fb2[TN];                                                     \
+                read_ks(acur, S, bcur, 1, fa1, fb1);                                                             \
+                mfma4(af0, bf0);                                                                                 \
+                __builtin_amdgcn_sched_barrier(0);                                                               \
+                ISSUE                                                                                            \
+                __builtin_amdgcn_sched_barrier(0);                                                               \
+                read_ks(acur, S, bcur, 2, fa2, fb2);                                                             \
+                mfma4(fa1, fb1);                                                                                 \
+                __builtin_amdgcn_sched_barrier(0);                                                               \
+                read_ks(acur, S, bcur, 3, fa1, fb1);                                                             \
+                mfma4(fa2, fb2);                                                                                 \
+                __builtin_amdgcn_sched_barrier(0);                                                               \
+                preread(NEXT_A, NEXT_S, bnext);                                                                  \
+                mfma4(fa1, fb1);                                                                                 \
+                __builtin_amdgcn_sched_barrier(0);                                                               \
+                asm volatile("s_waitcnt vmcnt(" #WAITN ")" ::: "memory");                                        \
+                raw_barrier();                                                                                   \
+            }
+            GENIE_KTILE(0,
+                        stage_a(nxt, has_next, 0, anxt); stage_a(nxt, has_next, 1, anxt); stage_a(nxt, has_next, 2, anxt);
+                        stage_a(nxt, has_next, 3, anxt); stage_a(nxt, has_next, 4, anxt);
+                        __builtin_amdgcn_sched_barrier(0);
+                        stage_b(nxt.wofs0, has_next, B0 + ((k + 3) & 3) * B_BYTES);,
+                        acur, 1, 7)
+            GENIE_KTILE(1, stage_b(nxt.wofs1, has_next, B0 + ((k + 4) & 3) * B_BYTES);, acur, 2, 2)
+            GENIE_KTILE(2, stage_b(nxt.wofs2, has_next, B0 + ((k + 5) & 3) * B_BYTES);, anxt, 0, 2)
+#undef GENIE_KTILE
+        }
+        igemm_epilogue<BM, TM, TN>(a, acc, epi, m0, n0, wm, wn, tid, lane);
+        __syncthreads();                                // the next tile's epilogue rewrites the row offsets
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+static int launch_igemm3p(const Igemm3Args& p, const GenieTriStep* steps, hipStream_t s) {
+    constexpr int lds = 2 * (5 * 64 * 128) + 4 * 128 * 128 + 1024;
+    static bool configured = false;
+    static int ncu = 0;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute((const void*)igemm3p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (e == hipSuccess) e = hipGetDevice(&dev);
+        if (e == hipSuccess) e = hipGetDeviceProperties(&prop, dev);
+        if (e != hipSuccess) {
+            genie_set_error("igemm3p setup failed: %s", hipGetErrorString(e));
+            return GENIE_ERR_HIP;
+        }
+        ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        configured = true;
+    }
+    const int ntiles = p.g.tiles_m * p.g.tiles_n;
+    hipLaunchKernelGGL(igemm3p_kernel, dim3(ntiles < ncu ? ntiles : ncu), dim3(512), lds, s, p, steps);
+    GENIE_CHECK_LAUNCH();
+    return GENIE_OK;
+}
+
+
+template <bool PRE, bool SPLITK, int NWAVE = 8>
 static int launch_igemm3d_t(const Igemm3Args& p, const GenieTriStep* steps, hipStream_t s) {
     constexpr int lds = 2 * (5 * 64 * 128) + 4 * 128 * 128;
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)igemm3d_kernel<PRE, SPLITK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipError_t e = hipFuncSetAttribute((const void*)igemm3d_kernel<PRE, SPLITK, NWAVE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) {
             genie_set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e));
             return GENIE_ERR_HIP;
         }
         configured = true;
     }
-    hipLaunchKernelGGL((igemm3d_kernel<PRE, SPLITK>), dim3(p.g.tiles_m * p.g.tiles_n, SPLITK ? p.g.split_k : 1), dim3(512), lds, s, p, steps);
+    hipLaunchKernelGGL((igemm3d_kernel<PRE, SPLITK, NWAVE>), dim3(p.g.tiles_m * p.g.tiles_n, SPLITK ? p.g.split_k : 1), dim3(64 * NWAVE), lds, s, p, steps);
     GENIE_CHECK_LAUNCH();
     if (SPLITK) return genie_igemm_splitk_finish(p.g, s);
     return GENIE_OK;
@@ -610,11 +842,22 @@ int genie_conv_igemm3_try(const GenieConvDesc* d, IgemmArgs a, hipStream_t s) {
     p.nsteps = d->n_tri_steps;
     p.WP = W + 2;
     p.img_rows = (bm / W) * (W + 2);
-    p.dbg = d->tri_flags & ~3;
+    p.dbg = d->tri_flags & 60;                          // bits 2-5: timing ablations
     const bool pipe = (d->tri_flags & 1) == 0;
     genie_note_variant(split > 1 ? GENIE_VARIANT_IGEMM3_256_SPLITK : (bm == 256 ? GENIE_VARIANT_IGEMM3_256 : GENIE_VARIANT_IGEMM3_128));
-    if (bm == 256 && (d->tri_flags & 2) == 0)                                                  // deep-prefetch schedules
+    if (bm == 256 && (d->tri_flags & 2) == 0) {                                                // deep-prefetch schedules
+        // bit 7: the persistent form.  Measured A/B on one box (B = 8 step): the kernel itself +1 % (1117 -> 1128 TFLOP/s averaged over
+        // its launches), the step unchanged (87.8 ms both ways) -- the pipeline fill / drain per tile is not what holds the
+        // one-tile kernel at 56 % MFMA-busy.  Kept selectable, off by default.
+        if ((d->tri_flags & 128) && split == 1 && (d->tri_flags & 64) == 0 && p.dbg == 0) return launch_igemm3p(p, d->tri_steps, s);
+        // bit 8 (or GENIE_TRI_W4=1): one wave per SIMD (4 waves of 128 x 64).  Measured A/B on one box: 1122 -> 1071 TFLOP/s averaged over
+        // the launches of a step (-4.5 %; split-K layers 616 -> 584): a single wave per SIMD does not cover its own LDS / barrier
+        // latencies, two co-resident waves do.  Kept selectable, off by default.
+        static const int w4 = getenv("GENIE_TRI_W4") ? atoi(getenv("GENIE_TRI_W4")) : 0;
+        if (((d->tri_flags & 256) || w4) && (d->tri_flags & 64) == 0 && p.dbg == 0)
+            return split > 1 ? launch_igemm3d_t<true, true, 4>(p, d->tri_steps, s) : launch_igemm3d_t<true, false, 4>(p, d->tri_steps, s);
         return (d->tri_flags & 64) ? launch_igemm3d<false>(p, d->tri_steps, s) : launch_igemm3d<true>(p, d->tri_steps, s);
+    }
     if (bm == 256) return pipe ? launch_igemm3<256, true>(p, d->tri_steps, s) : launch_igemm3<256, false>(p, d->tri_steps, s);
     return pipe ? launch_igemm3<128, true>(p, d->tri_steps, s) : launch_igemm3<128, false>(p, d->tri_steps, s);
 }

@@ -218,7 +218,7 @@ TRI_CASES = [
 
 
 @pytest.mark.parametrize('bm', [128, 256])
-@pytest.mark.parametrize('flags', [0, 1, 2])
+@pytest.mark.parametrize('flags', [0, 1, 2, 256])     # 256: one wave per SIMD (4 waves of 128 x 64) for the 256-row tile
 @pytest.mark.parametrize('cin,cout,kernel,causal,size', TRI_CASES)
 def test_conv_triple_kernel(G, cin, cout, kernel, causal, size, bm, flags, monkeypatch):
     """conv_igemm3.hip (kw-triples share one staged activation tile): forward and backward-data against the oracle, both row
@@ -314,6 +314,36 @@ def test_conv_triple_split_k(G, cin, cout, size, monkeypatch):
     if cout % 64 == 0:
         assert lib.genie_last_conv_variant() == 7, lib.genie_last_conv_variant()
     assert_close_bf16(dx, xr.grad, 'split-K triple dgrad')
+
+
+@pytest.mark.parametrize('cin,cout,causal,size', [(64, 128, False, (2, 9, 64, 64)), (128, 192, True, (2, 5, 64, 64)), (64, 128, True, (3, 11, 32, 32))])
+def test_conv_triple_persistent_kernel(G, cin, cout, causal, size, monkeypatch):
+    """More 256-row tiles than CUs: the persistent kw-triple kernel walks several tiles per block (the DMA stream runs through the
+    tile boundaries; the last round of tiles is partial).  Forward with bias + residual, backward-data."""
+    monkeypatch.setattr(G.conv, 'TRI_BM', 256)
+    monkeypatch.setattr(G.conv, 'TRI_FLAGS', 128)
+    torch.manual_seed(15)
+    n, t, h, w = size
+    x = bf16_round(torch.randn(n, cin, t, h, w))
+    wt = bf16_round(torch.randn(cout, cin, 3, 3, 3) / (cin * 27) ** 0.5)
+    b = torch.randn(cout)
+    r = bf16_round(torch.randn(n, cout, t, h, w))
+    xr = x.clone().requires_grad_(True)
+    if causal:
+        from oracle import genie_oracle as O
+        ref = O.causal_conv3d(xr, wt, b, stride=(1, 1, 1))
+        spec = G.conv.causal_spec(cin, cout, (3, 3, 3))
+    else:
+        ref = F.conv3d(xr, wt, b, padding=1)
+        spec = G.conv.same_spec(cin, cout, (3, 3, 3))
+    dy = bf16_round(torch.randn_like(ref))
+    ref.backward(dy)
+    lib = G.hip.load_library()
+    out = G.conv.conv_forward(G.cl.to_cl(x.cuda()), G.conv.pack_weight_fwd(wt.cuda(), spec), b.cuda(), spec, resid=G.cl.to_cl(r.cuda()))
+    assert lib.genie_last_conv_variant() == 5, lib.genie_last_conv_variant()
+    assert_close_bf16(out, ref + r, 'persistent triple fwd')
+    dx = G.conv.conv_dgrad(G.cl.to_cl(dy.cuda()), G.conv.pack_weight_bwd(wt.cuda(), spec), spec, (t, h, w))
+    assert_close_bf16(dx, xr.grad, 'persistent triple dgrad')
 
 
 def test_conv_triple_shuffle_and_residual(G, monkeypatch):
