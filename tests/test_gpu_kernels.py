@@ -103,6 +103,8 @@ def _gn_ref(x, G_, gamma, beta, ada_s, ada_b, act):
 @pytest.mark.parametrize('N,C,G_,thw,ada,act', [
     (2, 128, 1, (4, 16, 16), False, True), (2, 512, 8, (2, 8, 8), True, False), (1, 24, 3, (3, 5, 7), False, True),
     (3, 64, 64, (2, 4, 4), True, True), (2, 16, 8, (1, 4, 4), False, False),
+    (2, 512, 1, (4, 8, 8), True, True),          # the low-resolution 512-channel layers, adaptive scale / shift
+    (1, 64, 1, (8, 64, 64), False, True),        # G = 1, 4 MiB sample: several blocks per sample
 ])
 def test_groupnorm_fwd_bwd(G, N, C, G_, thw, ada, act):
     torch.manual_seed(2)
