@@ -312,6 +312,9 @@ def test_conv_triple_split_k(G, cin, cout, size, monkeypatch):
     out = G.conv.conv_forward(G.cl.to_cl(x.cuda()), G.conv.pack_weight_fwd(wt.cuda(), spec), b.cuda(), spec)
     assert lib.genie_last_conv_variant() == 7, lib.genie_last_conv_variant()
     assert_close_bf16(out, ref, 'split-K triple fwd')
+    r = bf16_round(torch.randn_like(ref))                 # the finish kernel's residual + SiLU branch
+    out = G.conv.conv_forward(G.cl.to_cl(x.cuda()), G.conv.pack_weight_fwd(wt.cuda(), spec), b.cuda(), spec, resid=G.cl.to_cl(r.cuda()), act=1)
+    assert_close_bf16(out, F.silu(ref.detach() + r), 'split-K triple fwd + residual + SiLU')
     dx = G.conv.conv_dgrad(G.cl.to_cl(dy.cuda()), G.conv.pack_weight_bwd(wt.cuda(), spec), spec, (t, h, w))
     if cout % 64 == 0:
         assert lib.genie_last_conv_variant() == 7, lib.genie_last_conv_variant()
