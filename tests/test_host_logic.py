@@ -137,3 +137,23 @@ def test_kw_triple_schedule_host_logic():
     assert gconv.tri_rows(gconv._fwd_tap_list(gconv.same_spec(72, 64, (3, 3, 3))), 8, 8, 72) is None
     dil = gconv.ConvSpec(64, 64, (1, 1, 3), (1, 1, 1), (1, 1, 2), (0, 0, 2), (0, 0, 2), None)
     assert gconv.tri_rows(gconv._fwd_tap_list(dil), 8, 8, 64) is None
+
+
+def test_conv_variant_table_matches_header():
+    """Every GENIE_VARIANT_* id of include/genie_hip.h has a name in genie.conv.VARIANT_NAMES (bench.py keys its roofline on them)."""
+    import re
+    from genie import conv
+    hdr = open(os.path.join(ROOT, 'include', 'genie_hip.h')).read()
+    ids = {int(v): k for k, v in re.findall(r'#define (GENIE_VARIANT_\w+) (\d+)', hdr)}
+    assert ids and set(ids) == set(conv.VARIANT_NAMES), (sorted(ids.items()), sorted(conv.VARIANT_NAMES))
+    assert conv.VARIANT_NAMES[6] == 'gemm_pw_kernel' and 'splitk' in conv.VARIANT_NAMES[7]
+
+
+def test_pointwise_spec_detection():
+    """Only 1x1x1, stride-1, unpadded, unshuffled convolutions are declared as plain GEMMs (GenieConvDesc.pointwise)."""
+    from genie import conv
+    assert conv._is_pointwise(conv.same_spec(128, 256, (1, 1, 1)))
+    assert not conv._is_pointwise(conv.same_spec(128, 256, (3, 3, 3)))
+    assert not conv._is_pointwise(conv.causal_spec(128, 256, (1, 1, 1), stride=(1, 2, 2)))
+    assert not conv._is_pointwise(conv.causal_spec(64, 64 * 8, (1, 1, 1), shuffle=(2, 2, 2)))
+    assert not conv._is_pointwise(conv.causal_spec(64, 64, (2, 1, 1)))          # causal front padding in time
