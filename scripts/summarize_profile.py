@@ -63,6 +63,22 @@ for rk, bk in NAMES.items():
                        'source': f'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of bench.py --batch 8, profiles/{tag}_summary.json; '
                                  'FETCH_SIZE x 2 (gfx950 correction), KB -> bytes'}
 summary['traffic'] = traffic
+
+# The roofline of bench.py divides by HIP-event time around each launch; rocprofv3's own average for the same kernel must agree.
+bur = os.path.join(out, 'bench_under_rocprof.json')
+if stats and os.path.exists(bur):
+    try:
+        line = [l for l in open(bur).read().strip().splitlines() if l.startswith('{')][-1]
+        roof = json.loads(line).get('roofline', {})
+        rk = next((k for k, v in NAMES.items() if v == roof.get('kernel')), None)
+        row = next((r for r in csv.DictReader(open(stats)) if rk and rk in r['Name']), None)
+        if row and roof.get('avg_launch_ms'):
+            ev_us, rp_us = roof['avg_launch_ms'] * 1e3, float(row['AverageNs']) / 1e3
+            summary['duration_agreement'] = {'kernel': roof['kernel'], 'rocprof_symbol': row['Name'][:100], 'rocprof_calls': int(row['Calls']),
+                                             'rocprof_avg_us': round(rp_us, 1), 'bench_hip_event_avg_us': round(ev_us, 1),
+                                             'ratio_event_over_rocprof': round(ev_us / rp_us, 4)}
+    except Exception as e:                                    # the summary is still useful without this cross-check
+        summary['duration_agreement'] = {'error': repr(e)}
 summary.pop('FETCH_SIZE_all', None)
 summary.pop('WRITE_SIZE_all', None)
 
