@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GENIE_ABI_VERSION 2
+#define GENIE_ABI_VERSION 3
 
 #define GENIE_F32 0
 #define GENIE_BF16 1
@@ -236,6 +236,19 @@ int genie_masked_ce_fwd(const void* logits_bf16, int64_t pitch, int64_t nrow, in
                         float* row_lse, float* loss_sum, void* stream);
 int genie_masked_ce_bwd(const void* logits_bf16, int64_t pitch, int64_t nrow, int V, const int64_t* target, const unsigned char* mask,
                         const float* row_lse, const float* scale, void* dlogits_bf16, int64_t dpitch, void* stream);
+
+/* MaskGIT sampling step (maskgit.hip).   replaces: softmax(logits / temp) + torch.multinomial + gather (confidence) and
+ * topk + gather + scatter_ of DynamicsModel.generate, dynamics.py:138-158.  The multinomial draw is an inverse-CDF draw from an
+ * INJECTED uniform per row (device RNG streams are not reproducible across devices; oracle/genie_oracle.py::sample_from_uniform):
+ *   p = softmax(row / temp) in fp32;  pred = #{ j : cumsum_f64(p)_j <= u * sum(p) } clamped to V - 1;  conf = p[pred].
+ * Row r of the (rows, V) logits lives at element offset (r / rows_per_sample) * sample_stride + (r % rows_per_sample) * pitch
+ * (so the last-frame slice logits[:, -1] of a (B, T, h, w, V) tensor is addressed in place).  dtype GENIE_BF16 or GENIE_F32. */
+int genie_maskgit_sample(const void* logits, int dtype, int64_t rows, int64_t rows_per_sample, int64_t sample_stride, int64_t pitch,
+                         int64_t V, const float* u, float temp, int64_t* pred, float* conf, void* stream);
+/* per sample b < batch: the k positions with the largest conf among those with mask != 0 (ties: lower index) get
+ * code[b][i] = pred[b][i], mask[b][i] = 0.  conf / pred / code / mask: [batch][n], n <= 32768. */
+int genie_maskgit_paint(const float* conf, const int64_t* pred, int64_t batch, int64_t n, int64_t k, int64_t* code,
+                        unsigned char* mask, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Losses and optimiser (elementwise.hip).

@@ -17,6 +17,7 @@
 #include <type_traits>
 #include "common.h"
 #include "genie_hip.h"
+#include "attn_args.h"
 
 static __device__ __attribute__((aligned(256))) uint32_t g_zero_page_a[64];
 
@@ -345,26 +346,6 @@ extern "C" int genie_rotary_layernorm_bwd(const void* x, const void* du, const v
 // ------------------------------------------------------------------------------------------------
 // attention core
 // ------------------------------------------------------------------------------------------------
-struct SeqMap {
-    int n_inner;
-    long long stride_outer, stride_inner, pos_stride;
-};
-
-__device__ __forceinline__ long long seq_base(const SeqMap& m, int seq) {
-    return (long long)(seq / m.n_inner) * m.stride_outer + (long long)(seq % m.n_inner) * m.stride_inner;
-}
-
-struct AttnArgs {
-    const bf16_t* q; const bf16_t* k; const bf16_t* v; const bf16_t* resid; bf16_t* out; bf16_t* oattn;
-    float* lse;                 // [token][nhead], token = (element offset of the token row) / C  (may be null)
-    int C;                      // channels per token row (= nhead * DH for the q/out tensor)
-    SeqMap qm, km, om;          // q/out/resid share qm for addressing of q; om for out & resid
-    int nseq, nhead, Sq, Sk;
-    float scale;
-    int causal;
-    int kv_same;                // k == v tile (one LDS image)
-};
-
 // Epilogue staging.  In the MFMA C layout a lane holds 4 consecutive channels of ONE token row, so a direct store instruction
 // touches 32 different rows with 16 B each; measured on the T = 16 / S = 64 shapes, where the kernel is pure traffic, that
 // pattern ran at ~1.8 TB/s against 5.8 TB/s for whole 16-B chunks, 8 lanes per row.  Every kernel therefore hands its 32 x DH
@@ -808,7 +789,7 @@ extern "C" int genie_attention_fwd(const void* q, const void* k, const void* v, 
                                    int d_head, int Sq, int Sk, const int64_t* q_map, const int64_t* kv_map, const int64_t* out_map, float scale,
                                    int causal, int out_channels, void* stream) {
     GENIE_CHECK_ARG(q && k && v && out && q_map && kv_map && out_map, "genie_attention_fwd: null pointer");
-    GENIE_CHECK_ARG(d_head == 32 || d_head == 64 || d_head == 128, "genie_attention_fwd: d_head %d not in {32, 64, 128}", d_head);
+    GENIE_CHECK_ARG(d_head == 8 || d_head == 16 || d_head == 32 || d_head == 64 || d_head == 128, "genie_attention_fwd: d_head %d not in {8, 16, 32, 64, 128}", d_head);
     GENIE_CHECK_ARG(nseq >= 1 && nhead >= 1 && Sq >= 1 && Sk >= 1, "genie_attention_fwd: empty problem");
     AttnArgs a;
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.resid = (const bf16_t*)resid; a.out = (bf16_t*)out; a.oattn = (bf16_t*)o_attn; a.lse = lse;
@@ -819,6 +800,7 @@ extern "C" int genie_attention_fwd(const void* q, const void* k, const void* v, 
     GENIE_CHECK_ARG(out_channels >= nhead * d_head, "genie_attention_fwd: out_channels %d < nhead * d_head", out_channels);
     GENIE_CHECK_ARG(scale > 0.f, "genie_attention_fwd: scale must be positive (got %g)", (double)scale);
     hipStream_t s = (hipStream_t)stream;
+    if (d_head < 32) return genie_attn_narrow_fwd(a, d_head, s);                                     // fp32 VALU kernels (attention_narrow.hip)
     if (q == k && k == v && Sq == Sk && Sq <= 32 && same_map(a.qm, a.km) && small_attn_mode()) {   // packed short sequences (temporal attention)
         const int tp = Sq <= 8 ? 8 : (Sq <= 16 ? 16 : 32);
         const long long waves = ((long long)nseq + 32 / tp - 1) / (32 / tp) * nhead;
@@ -897,17 +879,6 @@ __global__ void __launch_bounds__(256) attn_bwd_prep_kernel(const bf16_t* __rest
         if (ch < nch && (ch % LPH) == 0) D[tok * nhead + ch / LPH] = acc;
     }
 }
-
-struct AttnBwdArgs {
-    const bf16_t* q; const bf16_t* k; const bf16_t* v; const bf16_t* dO;
-    const float* lse; const float* D;
-    bf16_t* dq; bf16_t* dk; bf16_t* dv;      // dq: q-map addressing; dk/dv: kv-map addressing (dkv kernel)
-    const bf16_t* dq_in;                      // dkv kernel, fused self-attention: dk row += dq_in row (then dk holds dQ + dK + dV)
-    SeqMap qm, km, om, dkm;
-    int nseq, nhead, Sq, Sk, C, Ckv;
-    float scale;
-    int causal, kv_same, fuse_self;
-};
 
 // Both backward kernels share the forward's structure: 64-row tiles in a ring of three LDS stages DMA'd two tiles ahead with
 // counted waits, exp2-domain probabilities p = exp2(c s - lse log2 e), masks only on edge tiles, transposing LDS reads (asm)
@@ -1497,7 +1468,7 @@ extern "C" int genie_attention_bwd(const void* q, const void* k, const void* v, 
                                    int Sk, const int64_t* q_map, const int64_t* kv_map, const int64_t* out_map, const int64_t* dkv_map,
                                    float scale, int causal, int out_channels, int64_t out_tokens, void* stream) {
     GENIE_CHECK_ARG(q && k && v && out && dO && lse && D_ws && dq, "genie_attention_bwd: null pointer");
-    GENIE_CHECK_ARG(d_head == 32 || d_head == 64 || d_head == 128, "genie_attention_bwd: d_head %d not in {32, 64, 128}", d_head);
+    GENIE_CHECK_ARG(d_head == 8 || d_head == 16 || d_head == 32 || d_head == 64 || d_head == 128, "genie_attention_bwd: d_head %d not in {8, 16, 32, 64, 128}", d_head);
     const bool self = (q == k && k == v);
     GENIE_CHECK_ARG(self || (dk && dv), "genie_attention_bwd: dk/dv required when k/v differ from q");
     AttnBwdArgs a;
@@ -1506,7 +1477,10 @@ extern "C" int genie_attention_bwd(const void* q, const void* k, const void* v, 
     a.qm = mk_map(q_map); a.km = mk_map(kv_map); a.om = mk_map(out_map); a.dkm = dkv_map ? mk_map(dkv_map) : a.km;
     a.nseq = nseq; a.nhead = nhead; a.Sq = Sq; a.Sk = Sk; a.C = out_channels; a.Ckv = 0; a.scale = scale; a.causal = causal;
     a.kv_same = (k == v) ? 1 : 0; a.fuse_self = self ? 1 : 0;
+    a.out = (const bf16_t*)out; a.resid = (const bf16_t*)resid;
     hipStream_t s = (hipStream_t)stream;
+    GENIE_CHECK_ARG(scale > 0.f, "genie_attention_bwd: scale must be positive (got %g)", (double)scale);
+    if (d_head < 32) return genie_attn_narrow_bwd(a, d_head, s);                                     // D + dQ, then dK / dV (attention_narrow.hip)
     const unsigned pblocks = (unsigned)((out_tokens + 3) / 4);
     if (d_head == 32) attn_bwd_prep_kernel<32><<<pblocks, 256, 0, s>>>((const bf16_t*)dO, (const bf16_t*)out, (const bf16_t*)resid, D_ws, out_tokens, out_channels, nhead);
     else if (d_head == 64) attn_bwd_prep_kernel<64><<<pblocks, 256, 0, s>>>((const bf16_t*)dO, (const bf16_t*)out, (const bf16_t*)resid, D_ws, out_tokens, out_channels, nhead);

@@ -1,0 +1,41 @@
+// Argument blocks shared by the attention kernel families (attention.hip: MFMA flash kernels for d_head 32 / 64 / 128;
+// attention_narrow.hip: fp32 VALU kernels for d_head 8 / 16).
+#pragma once
+#include "common.h"
+
+struct SeqMap {
+    int n_inner;
+    long long stride_outer, stride_inner, pos_stride;
+};
+
+__device__ __forceinline__ long long seq_base(const SeqMap& m, int seq) {
+    return (long long)(seq / m.n_inner) * m.stride_outer + (long long)(seq % m.n_inner) * m.stride_inner;
+}
+
+struct AttnArgs {
+    const bf16_t* q; const bf16_t* k; const bf16_t* v; const bf16_t* resid; bf16_t* out; bf16_t* oattn;
+    float* lse;                 // [token][nhead], token = (element offset of the token row) / C  (may be null)
+    int C;                      // channels per token row (= nhead * DH for the q/out tensor)
+    SeqMap qm, km, om;          // q/out/resid share qm for addressing of q; om for out & resid
+    int nseq, nhead, Sq, Sk;
+    float scale;
+    int causal;
+    int kv_same;                // k == v tile (one LDS image)
+};
+
+struct AttnBwdArgs {
+    const bf16_t* q; const bf16_t* k; const bf16_t* v; const bf16_t* dO;
+    const float* lse; const float* D;
+    const bf16_t* out; const bf16_t* resid;   // narrow kernels: D is computed in the dQ kernel (out = o_attn when resid is null)
+    bf16_t* dq; bf16_t* dk; bf16_t* dv;      // dq: q-map addressing; dk/dv: kv-map addressing (dkv kernel)
+    const bf16_t* dq_in;                      // dkv kernel, fused self-attention: dk row += dq_in row (then dk holds dQ + dK + dV)
+    SeqMap qm, km, om, dkm;
+    int nseq, nhead, Sq, Sk, C, Ckv;
+    float scale;
+    int causal, kv_same, fuse_self;
+};
+
+
+// d_head 8 / 16 (attention_narrow.hip); same contracts as the MFMA kernels behind genie_attention_fwd / genie_attention_bwd
+int genie_attn_narrow_fwd(const AttnArgs& a, int d_head, hipStream_t s);
+int genie_attn_narrow_bwd(const AttnBwdArgs& a, int d_head, hipStream_t s);

@@ -29,14 +29,6 @@ class _ActRearrange(nn.Module):
         return x[:, :, None, None, :]
 
 
-def sample_from_uniform(prob: Tensor, u: Tensor) -> Tensor:
-    """Inverse-CDF categorical draw from injected uniforms: #(cumsum(prob) <= u * total), clamped.  Used instead of
-    torch.multinomial when ``generate(..., uniforms=...)`` is given so token ids are reproducible across devices."""
-    cdf = prob.double().cumsum(-1)
-    thr = (u.double() * cdf[:, -1])[:, None]
-    return (cdf <= thr).sum(-1).clamp(max=prob.shape[-1] - 1)
-
-
 class DynamicsModel(nn.Module):
     def __init__(self, desc: Blueprint, tok_vocab: int, act_vocab: int, embed_dim: int) -> None:
         super().__init__()
@@ -79,33 +71,50 @@ class DynamicsModel(nn.Module):
         # the softmax and its backward: one fused pass forward, one backward (genie_masked_ce_fwd / _bwd)
         return GF.masked_cross_entropy(logits, tokens, m)
 
+    def _last_frame_logits(self, tokens: Tensor, act_id: Tensor) -> Tensor:
+        """logits[:, -1] of ``forward`` -- (B, h, w, V) bf16 -- with the vocabulary head applied to the last frame only (the head is
+        row-wise, so these are the same numbers; at V = 2^18 the other T frames are 94 % of the head GEMM)."""
+        x = self._trunk(tokens, act_id)
+        return self._head(x[:, -1:])[:, 0]
+
     @torch.no_grad()
     def generate(self, tokens: Tensor, act_id: Tensor, steps: int = 10, which: Literal['linear', 'cosine', 'arccos'] = 'linear',
-                 temp: float = 1., topk: int = 50, masked_tok: int = 0, uniforms: Optional[Tensor] = None) -> Tensor:
+                 temp: float = 1., topk: int = 50, masked_tok: int = 0, uniforms: Optional[Tensor] = None,
+                 feedback: bool = False, trace: Optional[list] = None) -> Tensor:
+        """MaskGIT sampling (reference dynamics.py:101-165) with the whole per-step chain on the device:
+        softmax -> categorical draw -> confidence -> top-k -> scatter are two HIP kernels (genie_maskgit_sample / _paint) and the
+        loop never synchronises with the host (the reference syncs at ``mask.sum() == 0`` every step).
+
+        ``uniforms`` (steps, B*h*w) injects the noise of the categorical draws (inverse CDF), which makes token ids reproducible
+        and comparable with the CPU oracle; without it the uniforms come from the device RNG (``torch.rand``), which is the same
+        distribution as the reference's ``torch.multinomial``.  Reference quirks kept by default: painted codes are never fed back
+        into the context (dynamics.py:128,136 -- the logits are therefore the same at every step and are computed ONCE here) and
+        ``topk`` is unused.  ``feedback=True`` is the opt-in repair: the painted codes replace the masked frame before each step."""
         b, t, h, w = tokens.shape
+        n = h * w
+        dev = tokens.device
         schedule = self.get_schedule(steps, shape=(h, w), which=which)
-        mask = torch.ones(b, h * w, dtype=torch.bool, device=tokens.device)
-        code = torch.full((b, h * w), masked_tok, device=tokens.device, dtype=tokens.dtype)
-        mock = torch.zeros(b, 1, dtype=act_id.dtype, device=tokens.device)
-        tok_id = torch.cat([tokens, code.reshape(b, 1, h, w)], dim=1)
-        act = torch.cat([act_id, mock], dim=1)
-        pred_tok = tok_id
-        remaining = h * w          # masked positions per sample, tracked on the HOST: every step paints exactly `num_tokens` of them
+        mask = torch.ones(b, n, dtype=torch.uint8, device=dev)
+        code = torch.full((b, n), masked_tok, dtype=torch.int64, device=dev)
+        act = torch.cat([act_id, torch.zeros(b, 1, dtype=act_id.dtype, device=dev)], dim=1)
+        tok_id = torch.cat([tokens, code.reshape(b, 1, h, w).to(tokens.dtype)], dim=1)
+        logits = None
+        remaining = n              # masked positions per sample, tracked on the HOST: every step paints exactly `num_tokens` of them
         for step, num_tokens in enumerate(schedule.tolist()):     # (the schedule is a CPU tensor: no device sync here either)
             if remaining <= 0:     # the reference's `if mask.sum() == 0: break` (dynamics.py:133) without its device->host sync
                 break
             remaining -= num_tokens
-            _, logits = self(tok_id, act)
-            prob = torch.softmax(logits.float() / temp, dim=-1).reshape(b * h * w, -1)
-            pred = sample_from_uniform(prob, uniforms[step].to(prob.device)) if uniforms is not None else torch.multinomial(prob, num_samples=1).squeeze(-1)
-            conf = prob.gather(-1, pred[:, None]).reshape(b, h * w).masked_fill(~mask, -inf)      # (boolean index_put would sync)
-            idxs = torch.topk(conf, k=num_tokens, dim=-1).indices
-            vals = pred.reshape(b, -1).gather(-1, idxs).to(code.dtype)
-            code.scatter_(1, idxs, vals)
-            mask.scatter_(1, idxs, False)
-            pred_tok = torch.cat([tokens, code.reshape(b, 1, h, w)], dim=1)
+            if logits is None or feedback:
+                logits = self._last_frame_logits(tok_id, act)                       # (B, h, w, V) bf16
+            u = uniforms[step] if uniforms is not None else torch.rand(b * n, device=dev)
+            pred, conf = GF.maskgit_sample(logits, u, temp)
+            if trace is not None:
+                trace.append({'logits': logits, 'pred': pred.clone(), 'conf': conf.clone(), 'mask_before': mask.clone(), 'k': num_tokens})
+            GF.maskgit_paint(conf, pred, num_tokens, code, mask)
+            if feedback:
+                tok_id[:, -1] = code.reshape(b, h, w).to(tok_id.dtype)
         assert mask.sum() == 0, f'Not all tokens were predicted. {mask.sum()} tokens left.'
-        return pred_tok
+        return torch.cat([tokens, code.reshape(b, 1, h, w).to(tokens.dtype)], dim=1)
 
     def get_schedule(self, steps: int, shape, which: Literal['linear', 'cosine', 'arccos'] = 'linear') -> Tensor:
         n = prod(shape)

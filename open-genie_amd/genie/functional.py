@@ -370,6 +370,53 @@ def masked_cross_entropy(logits: Tensor, target: Tensor, mask: Optional[Tensor] 
 
 
 # ------------------------------------------------------------------------------------------------
+# MaskGIT sampling step (DynamicsModel.generate)
+# ------------------------------------------------------------------------------------------------
+def maskgit_sample(logits: Tensor, u: Tensor, temp: float = 1.):
+    """logits: (B, n, V) or (B, h, w, V) bf16/fp32 view whose rows (last dim) are contiguous and whose positions are evenly pitched
+    inside a sample; u: (B * n,) uniforms in [0, 1).  Returns (pred int64 (B, n), conf fp32 (B, n)): the inverse-CDF draw from
+    softmax(logits / temp) and its probability (reference dynamics.py:138-143 with injected noise)."""
+    _hip.require_gpu(logits, 'maskgit_sample')
+    if logits.dim() == 4:
+        b, h, w, v = logits.shape
+        if h > 1 and w > 1 and logits.stride(1) != w * logits.stride(2):
+            logits = logits.contiguous()
+        n, pitch = h * w, (logits.stride(2) if w > 1 else logits.stride(1))
+    else:
+        b, n, v = logits.shape
+        pitch = logits.stride(1)
+    if logits.dtype not in (torch.bfloat16, torch.float32):
+        logits = logits.float()
+    if (v > 1 and logits.stride(-1) != 1) or (n > 1 and pitch < v):
+        logits = logits.reshape(b, n, v).contiguous()
+        pitch = v
+    if n == 1:
+        pitch = v
+    sample_stride = logits.stride(0) if b > 1 else n * pitch
+    u = u.reshape(-1).to(device=logits.device, dtype=torch.float32).contiguous()
+    if u.numel() != b * n:
+        raise ValueError(f'maskgit_sample: {u.numel()} uniforms for {b * n} rows')
+    pred = torch.empty((b, n), dtype=torch.int64, device=logits.device)
+    conf = torch.empty((b, n), dtype=torch.float32, device=logits.device)
+    dt = _hip.GENIE_F32 if logits.dtype == torch.float32 else _hip.GENIE_BF16
+    _hip.check(_hip.load_library().genie_maskgit_sample(logits.data_ptr(), dt, b * n, n, sample_stride, pitch, v, u.data_ptr(), float(temp),
+                                                        pred.data_ptr(), conf.data_ptr(), _hip.stream_ptr()), 'genie_maskgit_sample')
+    return pred, conf
+
+
+def maskgit_paint(conf: Tensor, pred: Tensor, k: int, code: Tensor, mask: Tensor) -> None:
+    """In place: per sample, the k most confident still-masked positions take their sampled token and leave the mask
+    (reference dynamics.py:146-158).  conf fp32 / pred int64 / code int64 / mask uint8, all (B, n) contiguous."""
+    _hip.require_gpu(conf, 'maskgit_paint')
+    b, n = conf.shape
+    for t, dt in ((conf, torch.float32), (pred, torch.int64), (code, torch.int64), (mask, torch.uint8)):
+        if t.dtype != dt or not t.is_contiguous() or tuple(t.shape) != (b, n):
+            raise ValueError('maskgit_paint: conf fp32 / pred int64 / code int64 / mask uint8, contiguous (B, n)')
+    _hip.check(_hip.load_library().genie_maskgit_paint(conf.data_ptr(), pred.data_ptr(), b, n, int(k), code.data_ptr(), mask.data_ptr(),
+                                                       _hip.stream_ptr()), 'genie_maskgit_paint')
+
+
+# ------------------------------------------------------------------------------------------------
 # VideoResidualBlock as ONE autograd node (reference video.py:588-648, the default configuration: GroupNorm + swish, no
 # downsampling):   out = conv_b(act(GN2(conv_a(act(GN1(x)))))) + conv_r(x)
 # Same kernels as the module-by-module composition; what the fusion buys is the backward of the fan-out at x: the 1x1x1

@@ -556,10 +556,29 @@ def sample_from_uniform(prob: Tensor, u: Tensor) -> Tensor:
     return (cdf <= thr).sum(-1).clamp(max=prob.shape[-1] - 1)
 
 
+def maskgit_sample_step(logits: Tensor, u: Tensor, temp: float = 1.) -> Tuple[Tensor, Tensor]:
+    """dynamics.py:138-143 for one step: prob = softmax(logits / temp) packed to (rows, V); pred = categorical draw (inverse CDF
+    with the injected uniforms instead of torch.multinomial); conf = prob[pred].  Returns (pred int64 (rows,), conf fp32 (rows,))."""
+    prob = torch.softmax(logits / temp, dim=-1).reshape(-1, logits.shape[-1])
+    pred = sample_from_uniform(prob, u)
+    return pred, prob.gather(-1, pred[:, None])[:, 0]
+
+
+def maskgit_paint_step(conf: Tensor, pred: Tensor, mask: Tensor, code: Tensor, k: int) -> None:
+    """dynamics.py:146-158 for one step, in place: conf[~mask] = -inf; idxs = topk(conf, k); code[idxs] = pred[idxs];
+    mask[idxs] = False.  conf / pred / mask / code: (B, h*w)."""
+    conf = conf.clone()
+    conf[~mask] = -math.inf
+    idxs = torch.topk(conf, k=k, dim=-1).indices
+    code.scatter_(1, idxs, pred.gather(-1, idxs).to(code.dtype))
+    mask.scatter_(1, idxs, False)
+
+
 def dynamics_generate(tokens: Tensor, act_id: Tensor, sd: SD, desc, uniforms: Tensor, steps: int = 10,
-                      which: str = 'linear', temp: float = 1., masked_tok: int = 0) -> Tensor:
+                      which: str = 'linear', temp: float = 1., masked_tok: int = 0, trace: Optional[list] = None) -> Tensor:
     """dynamics.py:101-165 with injected noise.  uniforms: (steps, B*H*W).  QUIRK 9: painted codes are
-    never fed back into tok_id (dynamics.py:128,136)."""
+    never fed back into tok_id (dynamics.py:128,136).  `trace` (optional list) receives per-step dicts with the probabilities'
+    source logits, the draws and the mask before painting (used by the parity tests to explain every mismatch)."""
     b, t, h, w = tokens.shape
     schedule = maskgit_schedule(steps, (h, w), which)
     mask = torch.ones(b, h * w, dtype=torch.bool)
@@ -571,14 +590,11 @@ def dynamics_generate(tokens: Tensor, act_id: Tensor, sd: SD, desc, uniforms: Te
         if mask.sum() == 0:
             break
         _, logits = dynamics_forward(tok_id, act, sd, desc)
-        prob = torch.softmax(logits / temp, dim=-1).reshape(b * h * w, -1)
-        pred = sample_from_uniform(prob, uniforms[step])
-        conf = prob.gather(-1, pred[:, None]).reshape(b, h * w).clone()
-        conf[~mask] = -math.inf
-        idxs = torch.topk(conf, k=k, dim=-1).indices
-        vals = pred.reshape(b, -1).gather(-1, idxs).to(code.dtype)
-        code.scatter_(1, idxs, vals)
-        mask.scatter_(1, idxs, False)
+        pred, conf = maskgit_sample_step(logits, uniforms[step], temp)
+        pred, conf = pred.reshape(b, -1), conf.reshape(b, -1)
+        if trace is not None:
+            trace.append({'logits': logits, 'pred': pred.clone(), 'conf': conf.clone(), 'mask_before': mask.clone(), 'k': k})
+        maskgit_paint_step(conf, pred, mask, code, k)
         pred_tok = torch.cat([tokens, code.reshape(b, 1, h, w)], dim=1)
     assert mask.sum() == 0
     return pred_tok

@@ -88,3 +88,13 @@ def test_dynamics():
     assert O.maskgit_schedule(7, (8, 8), 'arccos').tolist() == g['schedule_arccos_7_8x8']
     with pytest.raises(ValueError):
         O.maskgit_schedule(5, (4, 4), 'nope')
+
+
+def test_dynamics_generate_token_ids():
+    """MaskGIT token ids: the oracle's loop == the real reference's generate() (torch.multinomial replaced by the injected-noise
+    draw, tests/golden/make_golden_generate.py), bit for bit, on the reference's own test configuration."""
+    g = load('dynamics_generate.pt')
+    for name, e in g.items():
+        gen = O.dynamics_generate(e['tokens'], e['act'], e['sd'], e['desc'], e['uniforms'], steps=e['steps'], which=e['which'], temp=e['temp'])
+        assert gen.dtype == e['gen'].dtype and torch.equal(gen, e['gen']), name
+        assert torch.equal(gen[:, :-1], e['tokens'])

@@ -195,3 +195,19 @@ def test_dynamics():
     assert O.maskgit_schedule(10, (16, 16)).tolist() == m.get_schedule(10, (16, 16)).tolist() == [1, 6, 11, 17, 23, 28, 34, 40, 46, 50]
     for which in ('cosine', 'arccos'):
         assert O.maskgit_schedule(7, (8, 8), which).tolist() == m.get_schedule(7, (8, 8), which).tolist()
+
+
+def test_dynamics_generate_injected_noise():
+    """The reference's generate() with torch.multinomial swapped for the inverse-CDF draw == oracle.dynamics_generate, bit for bit."""
+    import sys
+    sys.path.insert(0, __import__('os').path.join(__import__('os').path.dirname(__file__), 'golden'))
+    from make_golden_generate import reference_generate
+    ref = import_reference()
+    for seed, (b, t, h, w), steps, which, temp in [(1, (2, 3, 4, 4), 6, 'linear', 1.), (2, (3, 2, 5, 3), 4, 'cosine', 0.8), (3, (2, 4, 6, 6), 9, 'arccos', 1.3)]:
+        torch.manual_seed(seed)
+        m = ref.DynamicsModel(copy.deepcopy(DYN_DESC), tok_vocab=64, act_vocab=5, embed_dim=32).eval()
+        tok, act = torch.randint(0, 64, (b, t, h, w)), torch.randint(0, 5, (b, t))
+        u = torch.rand(steps, b * h * w)
+        gen, _ = reference_generate(m, tok, act, u, steps, which=which, temp=temp)
+        mine = O.dynamics_generate(tok, act, sd_of(m), DYN_DESC, u, steps=steps, which=which, temp=temp)
+        assert torch.equal(gen, mine), (seed, (gen != mine).sum().item())
