@@ -120,7 +120,21 @@ def main():
     ap.add_argument('--no-kernel-events', action='store_true')
     ap.add_argument('--all-kernel-events', action='store_true', help='HIP events around EVERY conv launch (full conv_kernels table; costs ~4 %% of the step)')
     ap.add_argument('--dump', type=str, default='')
+    ap.add_argument('--grad-compress', choices=['none', 'bf16'], default=os.environ.get('GENIE_GRAD_COMPRESS', 'none'),
+                    help='gradient all-reduce payload: fp32 (exact, default) or bf16 (half the xGMI bytes)')
+    ap.add_argument('--dp-loopback', action='store_true', help='N = 1 only: run the RCCL bucket all-reduces on a single-rank group (side-stream path on one GPU)')
     args = ap.parse_args()
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # launched plainly (`python bench.py --gpus N`): become the launcher -- one rank per GPU, rendezvous on 127.0.0.1
+        import socket
+        if torch.cuda.device_count() < args.gpus:
+            raise SystemExit(f'bench.py --gpus {args.gpus}: only {torch.cuda.device_count()} GPU(s) visible; refusing to run a smaller job under that label')
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        os.execv(sys.executable, [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+                                  '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__), *sys.argv[1:]])
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -132,7 +146,12 @@ def main():
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', device_id=dev)
-    assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    if world != args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}')
+    if args.dp_loopback and world == 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
 
     from genie import MAGVIT2_DEC_DESC, MAGVIT2_ENC_DESC, VideoTokenizer, conv as gconv
     from genie.trainer import DataParallel, ParamArena
@@ -141,8 +160,8 @@ def main():
     model = VideoTokenizer(MAGVIT2_ENC_DESC, MAGVIT2_DEC_DESC, d_codebook=18, gan_loss_weight=0., perc_loss_weight=0.).to(dev).train()
     arena = ParamArena(model)
     arena.attach_weight_packs(model)                       # bf16 packs ride on the optimiser kernel + one batched transpose
-    dp = DataParallel(arena.grads)
-    if world > 1:                                          # decoder gradients reduce while the encoder is still in backward
+    dp = DataParallel(arena.grads, compress=args.grad_compress, loopback=args.dp_loopback)
+    if dp.active:                                          # decoder gradients reduce while the encoder is still in backward
         cuts = [model.dec_layers[i] for i in (0, 6, 12, 18)] + [model.enc_layers[i] for i in (6, 12)]
         dp.install_overlap_hooks(arena, model, sorted(cuts, key=lambda mm: arena.offset_of(mm, model) or 0))
     B = args.batch
@@ -195,6 +214,9 @@ def main():
         'config': {'workload': 'configs[1]: VideoTokenizer (MAGVIT2_ENC/DEC_DESC, d_codebook=18) training, 16x64x64 random clips, bf16 activations / fp32 master weights; '
                                'step = encode + LFQ(train) + decode + MSE + quant loss + backward + AdamW (R-fwd loss)',
                    'clips_per_gpu': B, 'global_batch': B * world, 'clip': list(CLIP), 'params': 375554837, 'parallelism': f'dp{world}',
+                   'grad_allreduce': {'payload': 'fp32' if args.grad_compress == 'none' else 'bf16', 'buckets': len(dp.buckets),
+                                      'bytes_per_step': dp.bytes_reduced // max(1, args.steps + args.warmup), 'overlapped_with_backward': dp.active,
+                                      'loopback': bool(args.dp_loopback and world == 1)},
                    'final_loss': round(scal[0].item(), 5)},
         'model_tflops_per_gpu': round(TRAIN_GFLOP_PER_CLIP * B * args.steps / elapsed / 1e3, 2),
     }
@@ -230,7 +252,7 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline()
     print(json.dumps(out))
-    if world > 1:
+    if world > 1 or dist.is_initialized():
         dist.destroy_process_group()
 
 

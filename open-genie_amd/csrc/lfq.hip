@@ -392,7 +392,7 @@ __global__ void __launch_bounds__(256) masked_ce_fwd_kernel(const bf16_t* __rest
                                                             const long long* __restrict__ target, const unsigned char* __restrict__ mask,
                                                             float* __restrict__ row_lse, float* __restrict__ loss_sum) {
     __shared__ float red[4];
-    const int nch = V >> 3;
+    const int nch = (V + 7) >> 3;                                        // a ragged last chunk reads pad columns (pitch >= 8 * nch) and masks them
     for (long long r = blockIdx.x; r < nrow; r += gridDim.x) {
         if (mask && !mask[r]) continue;                                  // block-uniform
         const bf16_t* row = logits + r * pitch;
@@ -400,6 +400,10 @@ __global__ void __launch_bounds__(256) masked_ce_fwd_kernel(const bf16_t* __rest
         for (int ch = threadIdx.x; ch < nch; ch += 256) {
             float f[8];
             unpack8(*reinterpret_cast<const u32x4_t*>(row + ch * 8), f);
+            if (ch * 8 + 8 > V) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) f[j] = (ch * 8 + j < V) ? f[j] : -INFINITY;
+            }
             float cm = f[0];
 #pragma unroll
             for (int j = 1; j < 8; ++j) cm = fmaxf(cm, f[j]);
@@ -412,7 +416,9 @@ __global__ void __launch_bounds__(256) masked_ce_fwd_kernel(const bf16_t* __rest
         if (threadIdx.x == 0) {
             const float lse = M + __logf(S);
             row_lse[r] = lse;
-            atomicAdd(loss_sum, lse - bf16_to_f32(row[target[r]]));
+            const long long t = target[r];
+            // F.cross_entropy raises on a target outside [0, V); a kernel cannot, so the loss is poisoned instead of reading out of bounds
+            atomicAdd(loss_sum, (t >= 0 && t < V) ? lse - bf16_to_f32(row[t]) : __builtin_nanf(""));
         }
     }
 }
@@ -421,7 +427,7 @@ __global__ void __launch_bounds__(256) masked_ce_bwd_kernel(const bf16_t* __rest
                                                             const long long* __restrict__ target, const unsigned char* __restrict__ mask,
                                                             const float* __restrict__ row_lse, const float* __restrict__ scale,
                                                             bf16_t* __restrict__ dlogits, long long dpitch) {
-    const int nch = V >> 3;
+    const int nch = (V + 7) >> 3;
     const float sc = scale[0];
     for (long long r = blockIdx.x; r < nrow; r += gridDim.x) {
         bf16_t* drow = dlogits + r * dpitch;
@@ -437,7 +443,7 @@ __global__ void __launch_bounds__(256) masked_ce_bwd_kernel(const bf16_t* __rest
             float f[8];
             unpack8(*reinterpret_cast<const u32x4_t*>(row + ch * 8), f);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) f[j] = (__expf(f[j] - lse) - ((ch * 8 + j) == tgt ? 1.f : 0.f)) * sc;
+            for (int j = 0; j < 8; ++j) f[j] = (ch * 8 + j < V) ? (__expf(f[j] - lse) - ((ch * 8 + j) == tgt ? 1.f : 0.f)) * sc : 0.f;      // pad columns stay zero
             *reinterpret_cast<u32x4_t*>(drow + ch * 8) = pack8(f);
         }
     }
@@ -446,7 +452,7 @@ __global__ void __launch_bounds__(256) masked_ce_bwd_kernel(const bf16_t* __rest
 extern "C" int genie_masked_ce_fwd(const void* logits_bf16, int64_t pitch, int64_t nrow, int V, const int64_t* target,
                                    const unsigned char* mask, float* row_lse, float* loss_sum, void* stream) {
     GENIE_CHECK_ARG(logits_bf16 && target && row_lse && loss_sum, "genie_masked_ce_fwd: null pointer");
-    GENIE_CHECK_ARG(V >= 8 && V % 8 == 0 && pitch >= V && pitch % 8 == 0, "genie_masked_ce_fwd: V=%d / pitch must be multiples of 8", V);
+    GENIE_CHECK_ARG(V >= 1 && pitch >= ((V + 7) & ~7) && pitch % 8 == 0, "genie_masked_ce_fwd: V=%d needs a row pitch that is a multiple of 8 and >= V rounded up to 8 (got %lld)", V, (long long)pitch);
     if (nrow == 0) return GENIE_OK;
     const unsigned grid = (unsigned)(nrow < 4096 ? nrow : 4096);
     masked_ce_fwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((const bf16_t*)logits_bf16, pitch, nrow, V, (const long long*)target, mask, row_lse, loss_sum);
@@ -458,7 +464,7 @@ extern "C" int genie_masked_ce_bwd(const void* logits_bf16, int64_t pitch, int64
                                    const unsigned char* mask, const float* row_lse, const float* scale, void* dlogits_bf16,
                                    int64_t dpitch, void* stream) {
     GENIE_CHECK_ARG(logits_bf16 && target && row_lse && scale && dlogits_bf16, "genie_masked_ce_bwd: null pointer");
-    GENIE_CHECK_ARG(V >= 8 && V % 8 == 0 && pitch >= V && dpitch >= V && pitch % 8 == 0 && dpitch % 8 == 0, "genie_masked_ce_bwd: bad V / pitch");
+    GENIE_CHECK_ARG(V >= 1 && pitch >= ((V + 7) & ~7) && dpitch >= ((V + 7) & ~7) && pitch % 8 == 0 && dpitch % 8 == 0, "genie_masked_ce_bwd: bad V / pitch");
     if (nrow == 0) return GENIE_OK;
     const unsigned grid = (unsigned)(nrow < 4096 ? nrow : 4096);
     masked_ce_bwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((const bf16_t*)logits_bf16, pitch, nrow, V, (const long long*)target, mask, row_lse, scale, (bf16_t*)dlogits_bf16, dpitch);

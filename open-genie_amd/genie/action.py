@@ -56,6 +56,12 @@ class LatentAction(nn.Module):
     def sample(self, idxs: Tensor) -> Tensor:
         return self.quant.codebook[idxs]
 
+    def forward_order(self):
+        """Sub-modules in execution order (trainer.execution_order lays the parameter arena out this way): the action head and
+        its quantiser run after the encoder; their gradients are complete once the decoder's backward has delivered the condition
+        gradients, i.e. before the encoder's backward starts."""
+        return [self.proj_in, self.enc_layers, self.to_act, self.quant, self.dec_layers, self.proj_out]
+
     def _project_to_action(self, video: Tensor) -> Tensor:
         """Linear over 'b c t h w -> b t (c h w)' features.  The CL memory order of a frame is (h, w, c), so the weight's
         columns are permuted instead of the activation (a (d, C*H*W) tensor vs. B*T*C*H*W elements)."""

@@ -39,6 +39,10 @@ class DynamicsModel(nn.Module):
         self.tok_vocab, self.act_vocab, self.embed_dim = tok_vocab, act_vocab, embed_dim
         self._head_op = GF.ConvOp(ConvSpec(embed_dim, tok_vocab, (1, 1, 1)))
 
+    def forward_order(self):
+        """Sub-modules in execution order (trainer.execution_order lays the parameter arena out this way)."""
+        return [self.tok_emb, self.act_emb, self.dec_layers, self.head]
+
     def _trunk(self, tokens: Tensor, act_id: Tensor) -> Tensor:
         x = self.tok_emb(tokens) + self.act_emb(act_id)                 # (B, T, H, W, D)
         for dec in self.dec_layers:

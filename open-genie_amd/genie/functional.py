@@ -3,11 +3,16 @@
 Every Function takes/returns CL tensors (genie/cl.py) and enqueues kernels on the current stream;
 nothing here synchronises, so a whole training step can be captured in one hipGraph.
 
-Weight gradients: by default (``DIRECT_PARAM_GRADS = True``) the wgrad kernels accumulate straight
-into ``param.grad`` with fp32 atomics and the Function returns ``None`` for the parameter -- no
-per-step allocation/memset/add per weight, and ``param.grad`` can be a view into one flat arena that
-the optimiser and the RCCL all-reduce work on (genie/trainer.py).  Set it to ``False`` to get the
-classic "return the gradient" behaviour (needed for torch.autograd.grad / hooks on parameters).
+Weight gradients, two modes (``DIRECT_PARAM_GRADS``, env ``GENIE_DIRECT_PARAM_GRADS``):
+
+* ``'arena'`` (default): parameters that a ``genie.trainer.ParamArena`` manages get their gradients accumulated straight into
+  ``param.grad`` (a view of the flat gradient arena) by the wgrad kernels, with fp32 atomics, and the Function returns ``None`` for
+  them -- no per-step allocation / memset / add per weight, one fused optimiser kernel, contiguous all-reduce ranges.  Every other
+  parameter gets the classic behaviour: the gradient is RETURNED to autograd, so ``torch.autograd.grad`` w.r.t. parameters,
+  parameter hooks, torch DDP's reducer and Lightning's ``strategy=ddp`` (the reference's entry point, config/tokenize.yaml:77)
+  see it like any other gradient.
+* ``'all'``: direct accumulation for every fp32 leaf parameter (what round 1 did unconditionally; bypasses AccumulateGrad).
+* ``'off'``: never.
 """
 from __future__ import annotations
 
@@ -20,7 +25,18 @@ from . import _hip
 from .cl import empty_like_cl, is_cl, pitch_of, to_cl
 from .conv import ConvSpec, conv_dgrad, conv_forward, conv_wgrad, pack_weight_bwd, pack_weight_fwd
 
-DIRECT_PARAM_GRADS = True
+DIRECT_PARAM_GRADS = __import__('os').environ.get('GENIE_DIRECT_PARAM_GRADS', 'arena')
+
+
+def _direct(p: Optional[Tensor]) -> bool:
+    """May the kernels accumulate this parameter's gradient straight into ``p.grad``?"""
+    mode = DIRECT_PARAM_GRADS
+    if mode is True or mode == 'all':
+        return True
+    if mode is False or mode == 'off' or p is None:
+        return False
+    return getattr(p, '_genie_arena', False)
+
 FUSED_RESBLOCK = __import__('os').environ.get('GENIE_FUSED_RESBLOCK', '1') != '0'    # VideoResidualBlock as one autograd node
 
 _ws_cache = {}
@@ -91,7 +107,7 @@ class _Conv3dFn(torch.autograd.Function):
             wleaf = weight if weight.is_leaf else getattr(weight, '_base', None)
             linear_view = (wleaf is not weight and wleaf is not None and wleaf.dim() == 2 and wleaf.is_contiguous()
                            and tuple(weight.shape) == (*wleaf.shape, 1, 1, 1))
-            if DIRECT_PARAM_GRADS and wleaf is not None and wleaf.is_leaf and (wleaf is weight or linear_view) and (bias is None or bias.is_leaf):
+            if wleaf is not None and _direct(wleaf) and wleaf.is_leaf and (wleaf is weight or linear_view) and (bias is None or (bias.is_leaf and _direct(bias))):
                 gw = _grad_buffer(wleaf).view(weight.shape) if wleaf is not weight else _grad_buffer(weight)
                 gb = _grad_buffer(bias) if need_b else None
                 conv_wgrad(x, dy, op.spec, gw, gb)
@@ -150,12 +166,12 @@ class _GroupNormFn(torch.autograd.Function):
         dgamma = dbeta = None
         ret_g = ret_b = None
         if need_g:
-            if DIRECT_PARAM_GRADS and gamma.is_leaf and gamma.dtype == torch.float32 and gamma.is_contiguous():
+            if _direct(gamma) and gamma.is_leaf and gamma.dtype == torch.float32 and gamma.is_contiguous():
                 dgamma = _grad_buffer(gamma)
             else:
                 dgamma = ret_g = torch.zeros(c, dtype=torch.float32, device=x.device)
         if need_b:
-            if DIRECT_PARAM_GRADS and beta.is_leaf and beta.dtype == torch.float32 and beta.is_contiguous():
+            if _direct(beta) and beta.is_leaf and beta.dtype == torch.float32 and beta.is_contiguous():
                 dbeta = _grad_buffer(beta)
             else:
                 dbeta = ret_b = torch.zeros(c, dtype=torch.float32, device=x.device)
@@ -299,6 +315,7 @@ class _LfqFn(torch.autograd.Function):
                                           dzl.data_ptr(), _hip.stream_ptr()), 'genie_lfq_loss')
             ctx.save_for_backward(dzl)
         ctx.meta = (dt, ntok, width, pitch, z2d.dtype, z2d.shape[1])
+        ctx.training = bool(training)
         ctx.mark_non_differentiable(idx)
         return quant, idx, loss4
 
@@ -309,7 +326,9 @@ class _LfqFn(torch.autograd.Function):
         dzl = ctx.saved_tensors[0] if ctx.saved_tensors else None
         out = torch.empty((ntok, pitch), dtype=dtype, device=dquant.device if dquant is not None else dloss4.device)
         dq = None
-        if dquant is not None:
+        # the straight-through term exists only in training mode: in eval the reference returns `quant` itself
+        # (quantization.py:104-113, no `inp + (quant - inp).detach()`), so nothing flows back to the encoder
+        if dquant is not None and ctx.training:
             dq = dquant
             if dq.dtype != dtype or dq.stride(0) != pitch or dq.stride(1) != 1:
                 tmp = torch.zeros((ntok, pitch), dtype=dtype, device=dq.device)
@@ -331,16 +350,29 @@ def lfq_rows(z2d: Tensor, ncb: int, d: int, training: bool, beta: float, commit_
 # Masked token cross-entropy over bf16 logits (DynamicsModel.compute_loss)
 # ------------------------------------------------------------------------------------------------
 class _MaskedCEFn(torch.autograd.Function):
-    """logits: (..., V) bf16 whose rows are contiguous (row pitch = stride of the last-but-one dim); target / mask: (...)."""
+    """logits: (..., V) bf16 whose rows are evenly pitched (the (B, T, H, W, V) permutation of a CL tensor, or any dense tensor);
+    target / mask: (...).  Any V >= 1: rows are addressed with the channel pitch (a multiple of 8), pad columns are masked."""
 
     @staticmethod
     def forward(ctx, logits: Tensor, target: Tensor, mask: Optional[Tensor]):
         lib = _hip.load_library()
         v = logits.shape[-1]
         rows = logits.numel() // v
-        lg = logits.reshape(rows, v)                       # a view for the (B, T, H, W, V) permutation of a CL tensor
-        if lg.stride(1) != 1 or lg.dtype != torch.bfloat16:
-            raise ValueError('masked_cross_entropy: logits rows must be contiguous bf16')
+        vp = (v + 7) & ~7
+        lg = None
+        if logits.dtype == torch.bfloat16 and (v == 1 or logits.stride(-1) == 1):
+            # rows evenly pitched? (contiguous over the leading dims with a last-dim pitch >= vp)
+            pitch = logits.stride(-2) if logits.dim() >= 2 else vp
+            expect, ok = pitch, pitch >= vp and pitch % 8 == 0 and logits.storage_offset() % 8 == 0
+            for sz, st in zip(reversed(logits.shape[:-1]), reversed(logits.stride()[:-1])):
+                ok = ok and (sz == 1 or st == expect)
+                expect *= sz
+            if ok:
+                lg = logits.as_strided((rows, v), (pitch, 1))
+        if lg is None:                                     # dense copy into a padded buffer (pad columns are never read as logits)
+            buf = torch.zeros((rows, vp), dtype=torch.bfloat16, device=logits.device)
+            buf[:, :v] = logits.reshape(rows, v)
+            lg = buf[:, :v]
         tgt = target.reshape(rows).to(torch.int64).contiguous()
         mk = None if mask is None else mask.reshape(rows).to(torch.uint8).contiguous()
         lse = torch.empty(rows, dtype=torch.float32, device=logits.device)
@@ -356,11 +388,12 @@ class _MaskedCEFn(torch.autograd.Function):
     def backward(ctx, g: Tensor):
         lg, tgt, mk, lse, count = ctx.saved_tensors
         rows, v = lg.shape
+        vp = (v + 7) & ~7
         scale = (g.float().reshape(1) / count).contiguous()
-        dl = torch.empty((rows, v), dtype=torch.bfloat16, device=lg.device)
+        dl = torch.empty((rows, vp), dtype=torch.bfloat16, device=lg.device)          # the kernel zeroes the pad columns
         _hip.check(_hip.load_library().genie_masked_ce_bwd(lg.data_ptr(), lg.stride(0), rows, v, tgt.data_ptr(), _hip.ptr(mk), lse.data_ptr(),
-                                                           scale.data_ptr(), dl.data_ptr(), v, _hip.stream_ptr()), 'genie_masked_ce_bwd')
-        return dl.reshape(ctx.shape), None, None
+                                                           scale.data_ptr(), dl.data_ptr(), vp, _hip.stream_ptr()), 'genie_masked_ce_bwd')
+        return dl[:, :v].view(*ctx.shape[:-1], v), None, None
 
 
 def masked_cross_entropy(logits: Tensor, target: Tensor, mask: Optional[Tensor] = None) -> Tensor:
@@ -487,10 +520,10 @@ def residual_block(x: Tensor, norm1, conv_a, norm2, conv_b, conv_r) -> Optional[
     """Fused VideoResidualBlock when every piece is in the standard form (fp32 leaf parameters, direct gradient accumulation);
     returns None when the caller must fall back to the module-by-module composition."""
     params = [norm1.weight, norm1.bias, conv_a.weight, conv_a.bias, norm2.weight, norm2.bias, conv_b.weight, conv_b.bias, conv_r.weight, conv_r.bias]
-    if not FUSED_RESBLOCK or not DIRECT_PARAM_GRADS or not torch.is_grad_enabled():
+    if not FUSED_RESBLOCK or not torch.is_grad_enabled():
         return None
     for p in params:
-        if p is not None and not (p.is_leaf and p.requires_grad and p.dtype == torch.float32):
+        if p is not None and not (p.is_leaf and p.requires_grad and p.dtype == torch.float32 and _direct(p)):
             return None
     if any(p is None for p in (norm1.weight, norm1.bias, norm2.weight, norm2.bias)) or norm1.num_groups != norm2.num_groups:
         return None

@@ -156,7 +156,7 @@ class _AttnFn(torch.autograd.Function):
                                            1 if causal else 0, c, ntok, _hip.stream_ptr()), 'genie_attention_bwd')
         dx = empty_like_cl(x)
         need_g, need_b = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
-        direct = GF.DIRECT_PARAM_GRADS and gamma.is_leaf and beta.is_leaf and gamma.dtype == torch.float32
+        direct = GF._direct(gamma) and GF._direct(beta) and gamma.is_leaf and beta.is_leaf and gamma.dtype == torch.float32
         dgamma = (GF._grad_buffer(gamma) if direct else torch.zeros(c, dtype=torch.float32, device=x.device)) if need_g else None
         dbeta = (GF._grad_buffer(beta) if direct else torch.zeros(c, dtype=torch.float32, device=x.device)) if need_b else None
         _hip.check(lib.genie_rotary_layernorm_bwd(P(x), P(du), P(dout) if add_resid else None, P(dx), ntok, c, c, P(table), pos_div, pos_mod,
@@ -202,6 +202,10 @@ class Attention(nn.Module):
         x = to_cl(x)
         b, c, t, h, w = x.shape
         if c != hid:
+            if isinstance(self.embed, RotaryEmbedding) and c < 2 * self.embed.freq.numel():
+                # what the reference's rotary embedding says first (attention.py:87) -- e.g. the shipped config/tokenize.yaml, whose
+                # channels-first 64-feature stem meets channels-last 512-wide blocks
+                raise AssertionError(f'feature dimension {c} is not of sufficient size to rotate in all the positions {2 * self.embed.freq.numel()}')
             raise RuntimeError(f'Attention: input has {c} features, expected n_head * d_head = {hid}')
         npos = h * w if self._mode == 'space' else t
         table = self.embed.table(npos, c) if isinstance(self.embed, RotaryEmbedding) else None

@@ -146,6 +146,10 @@ class VideoTokenizer(LightningModule):
         self.gan_loss_weight, self.perc_loss_weight, self.quant_loss_weight = gan_loss_weight, perc_loss_weight, quant_loss_weight
         self.save_hyperparameters()
 
+    def forward_order(self):
+        """Sub-modules in execution order (trainer.execution_order lays the parameter arena out this way)."""
+        return [self.enc_layers, self.quant, self.dec_layers]
+
     def encode(self, video: Tensor, cond: Tensor | None = None) -> Tensor:
         return run_layers(self.enc_layers, self.enc_ext, video, cond)
 

@@ -1,21 +1,28 @@
-"""The N > 1 path on CPU: world_size-2 gloo run of the data-parallel bookkeeping (bucket cuts, bucket readiness
-order, mean reduction, batched scalar reduction).  The arithmetic kernels are not involved."""
+"""The N > 1 path on CPU: world_size-2 gloo runs of (a) the data-parallel bookkeeping (bucket cuts, readiness order, mean reduction,
+batched scalar reduction, bf16 compression) and (b) the real thing minus the kernels -- an nn.Module re-homed into a ParamArena laid
+out in execution order, overlap hooks installed, forward/backward on different data per rank -- checked against an unbucketed
+all-reduce.  The arithmetic kernels are not involved (torch CPU ops stand in for them)."""
 import os
 import sys
 
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
+import torch.nn as nn
 
 from util import ROOT
 
 
-def _worker(rank: int, world: int, port: int, q):
+def _setup(rank: int, world: int, port: int):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     for p in (ROOT, os.path.join(ROOT, 'open-genie_amd')):
         if p not in sys.path:
             sys.path.insert(0, p)
     dist.init_process_group('gloo', rank=rank, world_size=world)
+
+
+def _worker(rank: int, world: int, port: int, q):
+    _setup(rank, world, port)
     try:
         from genie.trainer import DataParallel, shard_clips
         grads = torch.arange(1000, dtype=torch.float32) * (rank + 1)
@@ -26,27 +33,137 @@ def _worker(rank: int, world: int, port: int, q):
         assert torch.equal(grads[:640], torch.arange(640, dtype=torch.float32) * (rank + 1))      # not yet reduced
         dp.bucket_ready(1)
         dp.finish()                              # reduces what is left exactly once
+        assert dp.last_fired == [2, 1, 0]
         assert torch.equal(grads, torch.arange(1000, dtype=torch.float32) * 1.5)
         dp.finish()                              # a second step starts clean
         assert torch.allclose(grads, torch.arange(1000, dtype=torch.float32) * 1.5)
         s = dp.reduce_scalars([torch.tensor(float(rank)), 2.0 * (rank + 1)])
         assert torch.allclose(s, torch.tensor([0.5, 3.0]))
         clips = list(shard_clips(7, rank, world))
+        # bf16 gradient compression: half the bytes, bf16-rounded mean
+        g2 = (torch.arange(1000, dtype=torch.float32) * 0.37 + 1.0) * (rank + 1)
+        dpc = DataParallel(g2, boundaries=[500], compress='bf16')
+        dpc.finish()
+        want = ((torch.arange(1000, dtype=torch.float32) * 0.37 + 1.0).to(torch.bfloat16).float() * 1
+                + ((torch.arange(1000, dtype=torch.float32) * 0.37 + 1.0) * 2).to(torch.bfloat16).float()).to(torch.bfloat16).float() / 2
+        assert torch.allclose(g2, want, rtol=2 ** -7), (g2 - want).abs().max()
+        assert dpc.bytes_reduced == 1000 * 2
         q.put((rank, clips, dp.bytes_reduced))
     finally:
         dist.destroy_process_group()
 
 
-def test_world_size_2_gloo():
+class _Block(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.fc = nn.Linear(d, d)
+
+    def forward(self, x):
+        return x + torch.tanh(self.fc(x))
+
+
+class _Toy(nn.Module):
+    """Registration order != execution order, as in VideoTokenizer (quant after dec_layers) and DynamicsModel (embeddings after
+    dec_layers): `late` is registered first but runs last, `quant` is registered last but runs in the middle."""
+
+    def __init__(self, d=16):
+        super().__init__()
+        self.late = nn.Linear(d, 1)
+        self.enc = nn.ModuleList([_Block(d) for _ in range(3)])
+        self.dec = nn.ModuleList([_Block(d) for _ in range(3)])
+        self.quant = nn.Linear(d, d)
+        self.stray = nn.Parameter(torch.ones(d))          # used everywhere, listed nowhere -> goes first in the arena
+
+    def forward_order(self):
+        return [self.enc, self.quant, self.dec, self.late]
+
+    def forward(self, x):
+        for m in self.enc:
+            x = m(x)
+        x = self.quant(x) * self.stray
+        for m in self.dec:
+            x = m(x)
+        return self.late(x * self.stray).pow(2).mean()
+
+
+def _model_worker(rank: int, world: int, port: int, q, compress):
+    _setup(rank, world, port)
+    try:
+        from genie.trainer import DataParallel, ParamArena
+        torch.manual_seed(0)
+        model = _Toy()
+        ref = _Toy()
+        ref.load_state_dict(model.state_dict())
+        arena = ParamArena(model)
+        names = arena.order_names
+        assert names[0] == 'stray' and names.index('quant.weight') < names.index('dec.0.fc.weight') < names.index('late.weight'), names
+        assert names.index('enc.2.fc.bias') < names.index('quant.weight')
+        dp = DataParallel(arena.grads, compress=compress)
+        cuts = [model.enc[1], model.quant, model.dec[1], model.late]
+        dp.install_overlap_hooks(arena, model, cuts)
+        assert len(dp.buckets) == 5
+        fired_during_backward = []
+        for step in range(2):
+            torch.manual_seed(100 + rank + 10 * step)              # different data on every rank
+            x = torch.randn(8, 16)
+            loss = model(x)
+            loss.backward()
+            fired_during_backward.append(list(dp.fired))           # buckets whose reduction was issued by hooks, before finish()
+            dp.finish()
+            # unbucketed reference: plain autograd on a copy, one all-reduce over every gradient
+            ref.zero_grad()
+            ref(x).backward()
+            for (n, p) in ref.named_parameters():
+                g = p.grad.clone()
+                dist.all_reduce(g)
+                g /= world
+                got = dict(model.named_parameters())[n].grad
+                tol = dict(rtol=2 ** -6, atol=1e-3) if compress else dict(rtol=1e-6, atol=1e-7)
+                assert torch.allclose(got, g, **tol), (n, (got - g).abs().max().item())
+            arena.zero_grad()
+        # buckets fire in reverse arena order while backward is still running: late -> dec[1:] -> quant+dec[0] -> enc[1:]
+        assert fired_during_backward[0] == [4, 3, 2, 1], fired_during_backward
+        assert dp.last_fired == [4, 3, 2, 1, 0]
+        # an arena in registration order must refuse early reduction
+        m2 = _Toy()
+        del _Toy.forward_order
+        try:
+            a2 = ParamArena(m2)
+            try:
+                DataParallel(a2.grads).install_overlap_hooks(a2, m2, [m2.enc[1]])
+                raise AssertionError('registration-order arena accepted overlap hooks')
+            except ValueError:
+                pass
+        finally:
+            pass
+        q.put((rank, dp.bytes_reduced))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(target, extra=()):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    port = 29500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29500 + (os.getpid() * 7 + len(extra) * 131 + hash(str(extra)) % 997) % 2000
+    procs = [ctx.Process(target=target, args=(r, 2, port, q, *extra)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
-        p.join(120)
+        p.join(180)
         assert p.exitcode == 0
-    res = sorted(q.get(timeout=5) for _ in range(2))
+    return sorted(q.get(timeout=5) for _ in range(2))
+
+
+def test_world_size_2_gloo():
+    res = _run(_worker)
     assert res[0][1] == [0, 2, 4, 6] and res[1][1] == [1, 3, 5]
     assert res[0][2] == 2 * 1000 * 4
+
+
+def test_world_size_2_module_arena_hooks():
+    res = _run(_model_worker, (None,))
+    assert res[0][1] == res[1][1] > 0
+
+
+def test_world_size_2_module_arena_hooks_bf16_compress():
+    _run(_model_worker, ('bf16',))

@@ -248,7 +248,8 @@ def test_attention_core_kernels(nseq, nhead, dh, sq, sk, causal, cross):
         assert rel_rms(dq, qr.grad) < 2e-2, rel_rms(dq, qr.grad)
 
 
-@pytest.mark.parametrize('rows,v,masked', [(37, 256, True), (16, 1000, True), (9, 1 << 14, False), (64, 8, True)])
+@pytest.mark.parametrize('rows,v,masked', [(37, 256, True), (16, 1000, True), (9, 1 << 14, False), (64, 8, True), (20, 250, True), (33, 3, False), (12, 1, True),
+                                           (11, 77, False)])     # any vocabulary size: ragged last chunk, pad columns masked
 def test_masked_cross_entropy_kernel(rows, v, masked):
     """genie_masked_ce_fwd / _bwd == F.cross_entropy(logits[mask].float(), target[mask]) and its autograd (dynamics.py:92-97)."""
     from genie import functional as GF
@@ -269,3 +270,52 @@ def test_masked_cross_entropy_kernel(rows, v, masked):
     got, want = ld.grad.float().cpu(), lr.grad
     assert (got[~sel] == 0).all()
     assert (got - want).abs().max().item() <= 2 ** -8 * want.abs().max().item() + 1e-8      # one bf16 rounding of the gradient
+
+
+def test_masked_cross_entropy_bad_target_poisons_the_loss():
+    """A target outside [0, V) raises in F.cross_entropy; the kernel cannot raise, so it must not read out of bounds and the loss is NaN."""
+    from genie import functional as GF
+    logits = torch.randn(4, 16).to(torch.bfloat16).cuda()
+    target = torch.tensor([1, 2, 16, 3]).cuda()
+    assert torch.isnan(GF.masked_cross_entropy(logits, target, None)).item()
+    assert torch.isfinite(GF.masked_cross_entropy(logits, target, torch.tensor([1, 1, 0, 1], dtype=torch.bool).cuda())).item()
+
+
+def test_dynamics_full_vocabulary_parity():
+    """BASELINE configs[3] head shape: V = 2^18 tokens, D = 512 (8 heads x 64) -- the persistent 256x256 GEMM behind Linear(D -> V),
+    the masked cross-entropy over 2^18-wide rows and the gradient of the 134 M-element head weight, against the oracle (fp32 CPU,
+    logits materialised once: 512 rows x 2^18 x 4 B = 0.5 GB).  Tolerances: logits 2 % relative RMS, loss 1 %, gradients 6 %."""
+    from genie.dynamics import DynamicsModel
+    from genie.trainer import ParamArena
+    from oracle import genie_oracle as O
+    desc = (('space-time_attn', {'n_rep': 2, 'n_head': 8, 'd_head': 64}),)
+    V = 1 << 18
+    torch.manual_seed(7)
+    m = DynamicsModel(desc, tok_vocab=V, act_vocab=8, embed_dim=512)
+    with torch.no_grad():
+        for p in m.parameters():
+            if p.dim() >= 2:
+                p.copy_(bf16_round(p))
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    m = m.cuda().train()
+    arena = ParamArena(m)
+    arena.attach_weight_packs(m)
+    tok, act = torch.randint(0, V, (2, 4, 8, 8)), torch.randint(0, 8, (2, 4))
+    mask = torch.rand(2, 4, 8, 8) < 0.75
+    logits, last = m(tok.cuda(), act.cuda())
+    assert tuple(logits.shape) == (2, 4, 8, 8, V) and tuple(last.shape) == (2, 8, 8, V)
+    sd_req = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and 'freq' not in k else v) for k, v in sd.items()}
+    ref, _ = O.dynamics_forward(tok, act, sd_req, desc)
+    assert rel_rms(logits, ref) < 2e-2, rel_rms(logits, ref)
+    del logits, last
+    loss = m.compute_loss(tok.cuda(), act.cuda(), mask=mask.cuda())
+    loss.backward()
+    tokf = torch.masked_fill(tok, mask, 0)
+    ref_m, _ = O.dynamics_forward(tokf, act, sd_req, desc)
+    loss_ref = torch.nn.functional.cross_entropy(ref_m[mask].reshape(-1, V), tokf[mask].reshape(-1))
+    assert abs(loss.item() - loss_ref.item()) < 1e-2 * abs(loss_ref.item()), (loss.item(), loss_ref.item())
+    loss_ref.backward()
+    for name in ('head.weight', 'head.bias', 'dec_layers.1.ffn.1.net.1.0.weight', 'dec_layers.0.space_attn.norm.weight', 'act_emb.0.weight'):
+        p = dict(m.named_parameters())[name]
+        r = rel_rms(p.grad, sd_req[name].grad)
+        assert r < 6e-2, (name, r)

@@ -85,3 +85,77 @@ def test_weight_packs_follow_the_optimiser():
     for a, b in zip(*losses):
         assert abs(a - b) <= 1e-3 * abs(a), losses
     assert losses[0][0] == losses[1][0] and abs(losses[0][1] - losses[1][1]) <= 1e-5 * abs(losses[0][1]), losses
+
+
+PROJ_ENC = ENC[:-1] + (('causal-conv3d', {'in_channels': 128, 'out_channels': 16, 'kernel_size': 1}),)
+PROJ_DEC = (('causal-conv3d', {'in_channels': 16, 'out_channels': 128, 'kernel_size': 3}),) + DEC[1:2] + \
+           (('adaptive_group_norm', {'dim_cond': 16, 'num_groups': 8, 'num_channels': 128, 'has_ext': True}),) + DEC[3:]
+
+
+def _step_grads(build, run, dp_cuts, loopback):
+    """One forward/backward of a freshly built model; returns (gradient arena copy, DataParallel or None, arena)."""
+    from genie.trainer import DataParallel, ParamArena
+    m = build()
+    arena = ParamArena(m)
+    dp = None
+    if loopback:
+        dp = DataParallel(arena.grads, compress='bf16', loopback=True)
+        dp.install_overlap_hooks(arena, m, dp_cuts(m))
+    loss = run(m)
+    loss.backward()
+    if dp is not None:
+        fired_in_backward = list(dp.fired)
+        dp.finish()
+        dp.fired_in_backward = fired_in_backward
+    torch.cuda.synchronize()
+    return arena.grads.clone(), dp, arena
+
+
+def test_data_parallel_loopback_on_real_models():
+    """The RCCL side-stream path on ONE GPU (a single-rank nccl group, loopback=True): arena laid out in execution order, overlap
+    hooks on real models whose registration order differs from execution order (a PROJECTING LFQ -- quant.proj_inp / proj_out --
+    and a DynamicsModel with embeddings + head), buckets reduced on the comm stream during backward.  With bf16 compression a
+    reduced bucket is rounded to bf16 in place, so a gradient contribution that arrived AFTER its bucket had been reduced (the
+    failure ADVICE.md round 1 describes) would leave values that are not bf16-representable: every gradient must be, and must
+    match the run without data parallelism."""
+    import torch.distributed as dist
+    from genie import VideoTokenizer
+    from genie.dynamics import DynamicsModel
+    if not dist.is_initialized():
+        dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29611', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        x = torch.randn(2, 3, 4, 16, 16, device='cuda')
+
+        def build_tok():
+            torch.manual_seed(0)
+            m = VideoTokenizer(PROJ_ENC, PROJ_DEC, d_codebook=10, gan_loss_weight=0., perc_loss_weight=0.).cuda().train()
+            assert isinstance(m.quant.proj_inp, torch.nn.Linear)
+            return m
+
+        desc = (('space-time_attn', {'n_rep': 3, 'n_head': 2, 'd_head': 32}),)
+        tok, act = torch.randint(0, 256, (2, 4, 4, 4), device='cuda'), torch.randint(0, 5, (2, 4), device='cuda')
+        mask = (torch.rand(2, 4, 4, 4, device='cuda') < 0.7)
+
+        def build_dyn():
+            torch.manual_seed(1)
+            return DynamicsModel(desc, tok_vocab=256, act_vocab=5, embed_dim=64).cuda().train()
+
+        cases = [
+            (build_tok, lambda m: m(x)[0], lambda m: [m.enc_layers[2], m.quant, m.dec_layers[1], m.dec_layers[4]]),
+            (build_dyn, lambda m: m.compute_loss(tok, act, mask=mask), lambda m: [m.dec_layers[1], m.dec_layers[2], m.head]),
+        ]
+        for build, run, cuts in cases:
+            g_ref, _, _ = _step_grads(build, run, cuts, loopback=False)
+            g_dp, dp, arena = _step_grads(build, run, cuts, loopback=True)
+            nb = len(dp.buckets)
+            assert dp.last_fired == list(range(nb - 1, -1, -1)), dp.last_fired
+            assert len(dp.fired_in_backward) >= nb - 1, (dp.fired_in_backward, nb)        # all but the first bucket start during backward
+            assert dp.bytes_reduced == arena.numel * 2
+            assert torch.equal(g_dp, g_dp.to(torch.bfloat16).float()), 'a gradient was written after its bucket had been reduced'
+            for name, (off, n) in arena.slots.items():
+                a, b = g_dp[off:off + n], g_ref[off:off + n]
+                assert b.abs().max() > 0 or 'bias' in name or 'freq' in name, f'{name}: no gradient'
+                err = (a - b).abs().max().item()
+                assert err <= 2 ** -7 * b.abs().max().item() + 1e-6, (name, err, b.abs().max().item())
+    finally:
+        dist.destroy_process_group()
