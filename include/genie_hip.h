@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GENIE_ABI_VERSION 3
+#define GENIE_ABI_VERSION 4
 
 #define GENIE_F32 0
 #define GENIE_BF16 1
@@ -206,6 +206,10 @@ int genie_blur_pool3d_bwd(const void* dy_cl, int out_channels, int out_pitch, co
 
 int genie_silu_fwd(const void* x, void* y, int64_t numel, void* stream);
 int genie_silu_bwd(const void* x, const void* dy, void* dx, int64_t numel, void* stream);
+/* LeakyReLU over a CL buffer.  replaces: nn.LeakyReLU in ImageResidualBlock (image.py:118-131) and FrameDiscriminator.to_logits
+ * (discriminator.py:91), forward and backward.  (GroupNorm fuses it as act = 2, slope 0.01: genie_groupnorm_fwd / _bwd.) */
+int genie_leaky_relu_fwd(const void* x, void* y, int64_t numel, float slope, void* stream);
+int genie_leaky_relu_bwd(const void* x, const void* dy, void* dx, int64_t numel, float slope, void* stream);
 int genie_add(const void* a, const void* b, void* y, int64_t numel, void* stream);
 
 /* ---------------------------------------------------------------------------------------------

@@ -156,6 +156,27 @@ __global__ void __launch_bounds__(256) add_kernel(const u32x4_t* __restrict__ a,
     }
 }
 
+__global__ void __launch_bounds__(256) leaky_fwd_kernel(const u32x4_t* __restrict__ x, u32x4_t* __restrict__ y, long long n16, float slope) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long long)gridDim.x * 256) {
+        float f[8];
+        unpack8(x[i], f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = f[j] > 0.f ? f[j] : slope * f[j];
+        y[i] = pack8(f);
+    }
+}
+__global__ void __launch_bounds__(256) leaky_bwd_kernel(const u32x4_t* __restrict__ x, const u32x4_t* __restrict__ dy, u32x4_t* __restrict__ dx, long long n16,
+                                                        float slope) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long long)gridDim.x * 256) {
+        float f[8], g[8];
+        unpack8(x[i], f);
+        unpack8(dy[i], g);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g[j] = f[j] > 0.f ? g[j] : slope * g[j];
+        dx[i] = pack8(g);
+    }
+}
+
 extern "C" int genie_silu_fwd(const void* x, void* y, int64_t numel, void* stream) {
     GENIE_CHECK_ARG(numel % 8 == 0, "genie_silu_fwd: numel %lld not a multiple of 8", (long long)numel);
     if (numel == 0) return GENIE_OK;
@@ -629,6 +650,22 @@ extern "C" int genie_blur_pool3d_bwd(const void* dy_cl, int out_channels, int ou
     GENIE_CHECK_LAUNCH();
     const long long total = (long long)g.N * g.T * g.H * g.W * (cpitch >> 3);
     blur_stencil_bwd_kernel<<<ew_grid(total), 256, 0, s>>>(ws, taps, g, (bf16_t*)dx_cl, C, cpitch);
+    GENIE_CHECK_LAUNCH();
+    return GENIE_OK;
+}
+
+// LeakyReLU over a CL buffer (reference: nn.LeakyReLU in ImageResidualBlock image.py:118-131 and FrameDiscriminator.to_logits discriminator.py:91)
+extern "C" int genie_leaky_relu_fwd(const void* x, void* y, int64_t numel, float slope, void* stream) {
+    GENIE_CHECK_ARG(x && y && numel % 8 == 0, "genie_leaky_relu_fwd: null pointer or numel %lld not a multiple of 8", (long long)numel);
+    if (numel == 0) return GENIE_OK;
+    leaky_fwd_kernel<<<ew_grid(numel / 8), 256, 0, (hipStream_t)stream>>>((const u32x4_t*)x, (u32x4_t*)y, numel / 8, slope);
+    GENIE_CHECK_LAUNCH();
+    return GENIE_OK;
+}
+extern "C" int genie_leaky_relu_bwd(const void* x, const void* dy, void* dx, int64_t numel, float slope, void* stream) {
+    GENIE_CHECK_ARG(x && dy && dx && numel % 8 == 0, "genie_leaky_relu_bwd: null pointer or numel %lld not a multiple of 8", (long long)numel);
+    if (numel == 0) return GENIE_OK;
+    leaky_bwd_kernel<<<ew_grid(numel / 8), 256, 0, (hipStream_t)stream>>>((const u32x4_t*)x, (const u32x4_t*)dy, (u32x4_t*)dx, numel / 8, slope);
     GENIE_CHECK_LAUNCH();
     return GENIE_OK;
 }

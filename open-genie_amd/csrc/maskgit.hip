@@ -92,20 +92,22 @@ __global__ void __launch_bounds__(SAMPLE_THREADS) maskgit_sample_kernel(const T*
     m = fmaxf(fmaxf(s_f[0], s_f[1]), fmaxf(s_f[2], s_f[3]));
     __syncthreads();
 
-    // pass 2: softmax denominator in fp32 (torch's softmax is fp32 throughout)
-    float tot = 0.f;
+    // pass 2: softmax denominator.  torch's CPU softmax sums the fp32 exponentials with a vectorised cascade that is accurate to an
+    // ulp or two; a plain fp32 running sum per thread over up to 2^18 / 256 terms is not (measured 2e-5 relative), so the partial sums
+    // are kept in double and the total is rounded to fp32 once -- the nearest fp32 to the true sum, which is what torch's also is.
+    double tot_d = 0.0;
     for (long long g = tid; g < ngroups; g += SAMPLE_THREADS) {
         float x[8];
         group_x<T>(row, g << 3, V, temp, x, vec);
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) s += expf(x[i] - m);          // exp(-inf) = 0 for the tail of a ragged last group
-        tot += s;
+        tot_d += (double)s;
     }
-    tot = wave_sum(tot);
-    if (lane == 0) s_f[wave] = tot;
+    tot_d = wave_sum_f64(tot_d);
+    if (lane == 0) s_d[wave] = tot_d;
     __syncthreads();
-    tot = (s_f[0] + s_f[1]) + (s_f[2] + s_f[3]);
+    const float tot = (float)((s_d[0] + s_d[1]) + (s_d[2] + s_d[3]));
     __syncthreads();
 
     // pass 3: each wave owns a contiguous quarter of the row; sum of the fp32 probabilities of that range, in double

@@ -172,7 +172,7 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const bf16_t* __restrict_
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 float z = f[j] * a[j] + b[j];
-                f[j] = act == 1 ? silu_f(z) : z;
+                f[j] = act == 1 ? silu_f(z) : (act == 2 ? (z > 0.f ? z : 0.01f * z) : z);
             }
             *reinterpret_cast<u32x4_t*>(ys + p * g.Cp + cc * 8) = pack8(f);
         }
@@ -232,7 +232,7 @@ __global__ void __launch_bounds__(256) gn_bwd_reduce_kernel(const bf16_t* __rest
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const float z = f[j] * a[j] + b[j];
-                    const float dz = act == 1 ? d[j] * silu_grad_f(z) : d[j];
+                    const float dz = act == 1 ? d[j] * silu_grad_f(z) : (act == 2 ? (z > 0.f ? d[j] : 0.01f * d[j]) : d[j]);
                     s1[j] += dz;
                     s2[j] += dz * (f[j] - mu[j]) * rs[j];
                 }
@@ -352,7 +352,7 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const bf16_t* __restr
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float z = f[j] * a[j] + b[j];
-                const float dz = act == 1 ? d[j] * silu_grad_f(z) : d[j];
+                const float dz = act == 1 ? d[j] * silu_grad_f(z) : (act == 2 ? (z > 0.f ? d[j] : 0.01f * d[j]) : d[j]);
                 d[j] = k1[j] * dz + k2[j] * f[j] + k3[j];
             }
             *reinterpret_cast<u32x4_t*>(os + p * g.Cp + cc * 8) = pack8(d);

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('GENIE_HIP_LIB', os.path.join(os.path.dirname(_HERE), 'lib', 'libgenie_hip.so'))
 
 GENIE_F32, GENIE_BF16 = 0, 1
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class GenieTap(C.Structure):
@@ -79,6 +79,8 @@ SIGNATURES = {
     'genie_blur_pool3d_bwd': (C.c_int, [_P, _I, _I, _PL, _P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), _P, _I, _P, _P]),
     'genie_silu_fwd': (C.c_int, [_P, _P, _L, _P]),
     'genie_silu_bwd': (C.c_int, [_P, _P, _P, _L, _P]),
+    'genie_leaky_relu_fwd': (C.c_int, [_P, _P, _L, _F, _P]),
+    'genie_leaky_relu_bwd': (C.c_int, [_P, _P, _P, _L, _F, _P]),
     'genie_add': (C.c_int, [_P, _P, _P, _L, _P]),
     'genie_lfq_quantize': (C.c_int, [_P, _I, _L, _I, _I, _L, _P, _P, _P]),
     'genie_lfq_loss_ws_floats': (C.c_int64, [_L, _I, _I]),

@@ -185,11 +185,12 @@ class _GroupNormFn(torch.autograd.Function):
 
 
 def group_norm(x: Tensor, groups: int, gamma: Optional[Tensor], beta: Optional[Tensor], eps: float = 1e-5,
-               ada_scale: Optional[Tensor] = None, ada_shift: Optional[Tensor] = None, act: bool = False) -> Tensor:
+               ada_scale: Optional[Tensor] = None, ada_shift: Optional[Tensor] = None, act=False) -> Tensor:
+    """`act`: False / 0 none, True / 1 SiLU, 2 LeakyReLU(0.01) -- applied in the same pass."""
     x = to_cl(x)
     if x.shape[1] % groups != 0:
         raise ValueError(f'num_channels {x.shape[1]} must be divisible by num_groups {groups}')
-    return _GroupNormFn.apply(x, gamma, beta, ada_scale, ada_shift, groups, eps, 1 if act else 0)
+    return _GroupNormFn.apply(x, gamma, beta, ada_scale, ada_shift, groups, eps, int(act))
 
 
 class _SiluFn(torch.autograd.Function):
@@ -213,6 +214,31 @@ class _SiluFn(torch.autograd.Function):
 
 def silu(x: Tensor) -> Tensor:
     return _SiluFn.apply(to_cl(x))
+
+
+class _LeakyFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x: Tensor, slope: float):
+        y = empty_like_cl(x)
+        numel = x.shape[0] * x.shape[2] * x.shape[3] * x.shape[4] * pitch_of(x)
+        _hip.check(_hip.load_library().genie_leaky_relu_fwd(x.data_ptr(), y.data_ptr(), numel, slope, _hip.stream_ptr()), 'genie_leaky_relu_fwd')
+        ctx.slope = slope
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        (x,) = ctx.saved_tensors
+        dy = to_cl(dy)
+        dx = empty_like_cl(x)
+        numel = x.shape[0] * x.shape[2] * x.shape[3] * x.shape[4] * pitch_of(x)
+        _hip.check(_hip.load_library().genie_leaky_relu_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), numel, ctx.slope, _hip.stream_ptr()),
+                   'genie_leaky_relu_bwd')
+        return dx, None
+
+
+def leaky_relu(x: Tensor, slope: float = 0.01) -> Tensor:
+    return _LeakyFn.apply(to_cl(x), float(slope))
 
 
 # ------------------------------------------------------------------------------------------------

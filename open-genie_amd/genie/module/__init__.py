@@ -9,17 +9,8 @@ import torch.nn as nn
 
 from ..utils import Blueprint, default, exists
 from .norm import AdaptiveGroupNorm, GroupNorm, SiLU
-from .video import (BlurPooling3d, CausalConv3d, CausalConvTranspose3d, DepthToSpaceTimeUpsample, DepthToSpaceUpsample,
+from .video import (CausalConv3d, CausalConvTranspose3d, DepthToSpaceTimeUpsample, DepthToSpaceUpsample,
                     DepthToTimeUpsample, SpaceTimeDownsample, VideoResidualBlock)
-
-
-def _out_of_scope(name: str):
-    class _Missing(nn.Module):
-        def __init__(self, *a, **k):
-            raise NotImplementedError(f"module '{name}' belongs to the GAN/discriminator path, which is outside the "
-                                      f"implemented hot path (SURVEY.md section 8f-2)")
-    _Missing.__name__ = f'Missing_{name}'
-    return _Missing
 
 
 def get_module(name: str):
@@ -34,9 +25,14 @@ def get_module(name: str):
             from .attention import SpaceTimeAttention
             return SpaceTimeAttention
         case 'blur_pool':
-            return BlurPooling3d
-        case 'space_downsample' | 'image-residual':
-            return _out_of_scope(name)
+            from .image import BlurPooling2d                  # the 2-D form, as in the reference's registry (__init__.py:33-34)
+            return BlurPooling2d
+        case 'space_downsample':
+            from .image import SpaceDownsample
+            return SpaceDownsample
+        case 'image-residual':
+            from .image import ImageResidualBlock
+            return ImageResidualBlock
         case 'video-residual':
             return VideoResidualBlock
         case 'causal-conv3d':

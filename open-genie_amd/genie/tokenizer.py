@@ -18,6 +18,7 @@ from torch.optim import AdamW, Optimizer
 from . import functional as GF
 from ._lightning import LightningModule
 from .module import parse_blueprint
+from .module.loss import GANLoss
 from .module.norm import GroupNorm, SiLU
 from .module.quantization import LookupFreeQuantization
 from .utils import Blueprint, default, exists
@@ -141,14 +142,15 @@ class VideoTokenizer(LightningModule):
         self.quant = LookupFreeQuantization(codebook_dim=d_codebook, num_codebook=n_codebook, input_dim=last_enc_dim,
                                             use_bias=lfq_bias, frac_sample=lfq_frac_sample, commit_weight=lfq_commit_weight,
                                             entropy_weight=lfq_entropy_weight, diversity_weight=lfq_diversity_weight)
-        self.perc_crit = _OutOfScopeCritic('PerceptualLoss (frozen VGG16)') if perc_loss_weight > 0 else nn.Identity()
-        self.gan_crit = _OutOfScopeCritic('GANLoss / FrameDiscriminator') if gan_loss_weight > 0 else nn.Identity()
+        self.perc_crit = _OutOfScopeCritic('PerceptualLoss (frozen VGG16 with downloaded weights)') if perc_loss_weight > 0 else nn.Identity()
+        # hinge GAN critic on a few frames per clip (reference tokenizer.py:294-299)
+        self.gan_crit = GANLoss(discriminate=gan_discriminate, num_frames=gan_frames_per_batch, **disc_kwargs) if gan_loss_weight > 0 else nn.Identity()
         self.gan_loss_weight, self.perc_loss_weight, self.quant_loss_weight = gan_loss_weight, perc_loss_weight, quant_loss_weight
         self.save_hyperparameters()
 
     def forward_order(self):
         """Sub-modules in execution order (trainer.execution_order lays the parameter arena out this way)."""
-        return [self.enc_layers, self.quant, self.dec_layers]
+        return [self.enc_layers, self.quant, self.dec_layers, self.gan_crit]
 
     def encode(self, video: Tensor, cond: Tensor | None = None) -> Tensor:
         return run_layers(self.enc_layers, self.enc_ext, video, cond)

@@ -621,3 +621,71 @@ def latent_action_forward(video: Tensor, sd: SD, enc_desc, dec_desc, d_codebook:
     rec_loss = F.mse_loss(recon, video)
     loss = rec_loss + (q_loss * quant_loss_weight if q_loss is not None else 0)
     return idxs, loss, (rec_loss, q_loss), recon
+
+
+# ----------------------------------------------------------------------------------------------
+# f2  GAN critic      genie/module/image.py:105-163, discriminator.py:17-114, loss.py:109-164, utils.py:30-56
+# ----------------------------------------------------------------------------------------------
+def image_residual_block(x: Tensor, sd: SD, prefix: str, inp_channel: int, out_channel: Optional[int] = None, kernel_size=3,
+                         padding=1, num_groups: int = 1, downsample: Optional[int] = None) -> Tensor:
+    """image.py:105-163.  main = GN, LeakyReLU, Conv2d, GN, LeakyReLU, Conv2d[, SpaceDownsample]; res = Conv2d(1x1, stride = downsample)
+    when out_channel is given, else identity.  SpaceDownsample (image.py:86-103): 'b c (h p) (w q) -> b (c p q) h w' then Conv2d 1x1."""
+    res = x
+    if out_channel is not None:
+        res = F.conv2d(x, sd[prefix + 'res.weight'], _get(sd, prefix + 'res.bias'), stride=downsample or 1)
+    h = F.leaky_relu(F.group_norm(x, num_groups, sd[prefix + 'main.0.weight'], sd[prefix + 'main.0.bias']))
+    h = F.conv2d(h, sd[prefix + 'main.2.weight'], _get(sd, prefix + 'main.2.bias'), padding=padding)
+    h = F.leaky_relu(F.group_norm(h, num_groups, sd[prefix + 'main.3.weight'], sd[prefix + 'main.3.bias']))
+    h = F.conv2d(h, sd[prefix + 'main.5.weight'], _get(sd, prefix + 'main.5.bias'), padding=padding)
+    if downsample:
+        b, c, hh, ww = h.shape
+        f = downsample
+        h = h.reshape(b, c, hh // f, f, ww // f, f).permute(0, 1, 3, 5, 2, 4).reshape(b, c * f * f, hh // f, ww // f)
+        h = F.conv2d(h, sd[prefix + 'main.6.go_up.1.weight'], _get(sd, prefix + 'main.6.go_up.1.bias'))
+    return h + res
+
+
+def frame_discriminator(image: Tensor, sd: SD, prefix: str = '', model_dim: int = 64, dim_mults=(1, 2, 4), down_step=(None, 2, 2),
+                        kernel_size=3, num_groups: int = 1, **_) -> Tensor:
+    """discriminator.py:99-114 with use_attn=False (the attention variants cannot run in the reference, SURVEY.md 4): Conv2d stem;
+    per stage a residual block, then `attn(out) + out` and `ff(out) + out` with attn = ff = Identity, i.e. the features are
+    doubled twice; Conv2d + LeakyReLU + flatten + Linear -> one logit per image."""
+    dims = [model_dim * m for m in dim_mults]
+    out = F.conv2d(image, sd[prefix + 'proj_in.weight'], _get(sd, prefix + 'proj_in.bias'), padding=1)
+    for i, ((ci, co), down) in enumerate(zip(zip(dims[:-1], dims[1:]), down_step)):
+        out = image_residual_block(out, sd, f'{prefix}core.{i}.0.', ci, co, kernel_size=kernel_size, num_groups=num_groups, downsample=down)
+        out = out + out
+        out = out + out
+    out = F.leaky_relu(F.conv2d(out, sd[prefix + 'to_logits.0.weight'], _get(sd, prefix + 'to_logits.0.bias'), padding=1))
+    return F.linear(out.flatten(1), sd[prefix + 'to_logits.3.weight'], sd[prefix + 'to_logits.3.bias'])[:, 0]
+
+
+def pick_frames(video: Tensor, frame_idxs: Tensor) -> Tensor:
+    """utils.py:30-56 with explicit indices: frame_idxs (b * k,) -> (b * k, c, h, w), k consecutive entries per clip."""
+    b = video.shape[0]
+    batch_idxs = torch.repeat_interleave(torch.arange(b), frame_idxs.numel() // b)
+    return video[batch_idxs, :, frame_idxs]
+
+
+def gan_loss(rec_video: Tensor, inp_video: Tensor, train_gen: bool, frame_idxs: Tensor, sd: SD, prefix: str = 'gan_crit.disc.', **disc_kw) -> Tensor:
+    """loss.py:147-164 (frames critic): hinge loss; the fakes are detached when the critic is being trained."""
+    fake, real = pick_frames(rec_video, frame_idxs), pick_frames(inp_video, frame_idxs)
+    if train_gen:
+        return -frame_discriminator(fake, sd, prefix, **disc_kw).mean()
+    fs = frame_discriminator(fake.detach(), sd, prefix, **disc_kw)
+    rs = frame_discriminator(real, sd, prefix, **disc_kw)
+    return (F.relu(1 + fs) + F.relu(1 - rs)).mean()
+
+
+def tokenizer_forward_gan(video: Tensor, sd: SD, enc_desc, dec_desc, d_codebook: int, idx_gen: Tensor, idx_dis: Tensor, disc_kw: dict,
+                          gan_loss_weight: float = 1., quant_loss_weight: float = 1., beta: float = 100., **lfq_kw):
+    """tokenizer.py:352-387 with the GAN critic on and the perceptual term omitted (VGG16 weights do not exist offline):
+    loss = mse + gen * w + dis * w + quant * w_q; idx_gen / idx_dis are the frame choices of the two gan_crit calls."""
+    enc = tokenizer_encode(video, sd, enc_desc)
+    (q, idx), q_loss = lfq_forward(enc, sd, 'quant.', d_codebook, 1, training=True, beta=beta, transpose=True, **lfq_kw)
+    rec = tokenizer_decode(q, sd, dec_desc)
+    rec_loss = F.mse_loss(rec, video)
+    gen = gan_loss(rec, video, True, idx_gen, sd, **disc_kw)
+    dis = gan_loss(rec, video, False, idx_dis, sd, **disc_kw)
+    loss = rec_loss + gen * gan_loss_weight + dis * gan_loss_weight + q_loss * quant_loss_weight
+    return loss, (rec_loss, gen, dis, q_loss), rec

@@ -98,3 +98,16 @@ def test_dynamics_generate_token_ids():
         gen = O.dynamics_generate(e['tokens'], e['act'], e['sd'], e['desc'], e['uniforms'], steps=e['steps'], which=e['which'], temp=e['temp'])
         assert gen.dtype == e['gen'].dtype and torch.equal(gen, e['gen']), name
         assert torch.equal(gen[:, :-1], e['tokens'])
+
+
+def test_gan_critic_path():
+    g = load('gan.pt')
+    for i in range(3):
+        e = g[f'image_residual_{i}']
+        close(O.image_residual_block(e['x'], e['sd'], '', **e['kw']), e['out'], 1e-4)
+    e = g['frame_discriminator']
+    close(O.frame_discriminator(e['x'], e['sd'], '', **e['kw']), e['out'], 1e-4)
+    e = g['gan_loss']
+    sd = {'gan_crit.' + k: v for k, v in e['sd'].items()}
+    close(O.gan_loss(e['rec'], e['video'], True, e['gen']['frame_idxs'], sd, **e['kw']), e['gen']['loss'], 1e-4)
+    close(O.gan_loss(e['rec'], e['video'], False, e['dis']['frame_idxs'], sd, **e['kw']), e['dis']['loss'], 1e-4)

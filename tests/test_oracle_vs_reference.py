@@ -211,3 +211,35 @@ def test_dynamics_generate_injected_noise():
         gen, _ = reference_generate(m, tok, act, u, steps, which=which, temp=temp)
         mine = O.dynamics_generate(tok, act, sd_of(m), DYN_DESC, u, steps=steps, which=which, temp=temp)
         assert torch.equal(gen, mine), (seed, (gen != mine).sum().item())
+
+
+def test_gan_critic_path():
+    """f2: ImageResidualBlock, FrameDiscriminator and the hinge GANLoss of the live reference == the oracle's restatement
+    (frame choice injected through a stubbed torch.randperm)."""
+    I, Dm, L = ref_module('module.image'), ref_module('module.discriminator'), ref_module('module.loss')
+    for kw in [dict(inp_channel=8, out_channel=16, num_groups=2, downsample=2), dict(inp_channel=8, out_channel=8, downsample=None),
+               dict(inp_channel=8, out_channel=None, num_groups=4)]:
+        torch.manual_seed(0)
+        m = I.ImageResidualBlock(**kw)
+        x = torch.randn(3, 8, 12, 12)
+        close(O.image_residual_block(x, sd_of(m), '', **kw), m(x), 1e-4)
+    disc_kw = dict(inp_size=(16, 16), model_dim=8, dim_mults=(1, 2, 4), down_step=(None, 2, 2), num_groups=2)
+    torch.manual_seed(1)
+    d = Dm.FrameDiscriminator(**disc_kw)
+    img = torch.randn(5, 3, 16, 16)
+    close(O.frame_discriminator(img, sd_of(d), '', **disc_kw), d(img), 1e-4)
+    g = L.GANLoss(discriminate='frames', num_frames=2, **disc_kw)
+    sd = {'gan_crit.' + k: v for k, v in sd_of(g).items()}
+    rec, vid = torch.randn(2, 3, 6, 16, 16), torch.randn(2, 3, 6, 16, 16)
+    perms = [torch.randperm(6) for _ in range(4)]
+    real_randperm = torch.randperm
+    for train_gen, ps in ((True, perms[:2]), (False, perms[2:])):
+        # (pick_frames evaluates its default frame choice eagerly -- utils.py:45-49 -- so more permutations are drawn than used)
+        it = iter(list(ps) + [real_randperm(6) for _ in range(8)])
+        torch.randperm = lambda n, **k: next(it)
+        try:
+            want = g(rec, vid, train_gen=train_gen)
+        finally:
+            torch.randperm = real_randperm
+        idx = torch.cat([p[:2] for p in ps])
+        close(O.gan_loss(rec, vid, train_gen, idx, sd, **disc_kw), want.detach(), 1e-4)
