@@ -22,3 +22,6 @@ except Exception:                                      # lightning absent (this 
     class LightningDataModule:
         def __init__(self, *args, **kwargs) -> None:
             pass
+
+        def save_hyperparameters(self, *args, **kwargs) -> None:
+            pass

@@ -308,3 +308,98 @@ def shard_clips(num_clips: int, rank: int, world: int) -> range:
     """Rank r takes clips r::world -- what Lightning's DistributedSampler does for the reference's DataLoader
     (reference genie/module/data.py:97)."""
     return range(rank, num_clips, world)
+
+
+# ----------------------------------------------------------------------------------------------------------------------------------
+# fit loop: what ``Trainer.fit`` does for the reference's LightningCLI entry points (tokenizer.py:6-19, config/tokenize.yaml:74-92),
+# on this runtime: parameter arena + fused AdamW, clip-sharded data parallel, pinned prefetch, one scalar all-reduce per log line
+# ----------------------------------------------------------------------------------------------------------------------------------
+class Trainer:
+    """Minimal stand-in for ``lightning.Trainer`` with the keys of the reference's ``trainer:`` config section that matter here:
+    ``max_epochs``, ``max_steps``, ``log_every_n_steps``, ``val_check_interval``, ``limit_val_batches``, ``default_root_dir``;
+    ``accelerator`` / ``devices`` / ``strategy`` / ``precision`` / ``callbacks`` / ``logger`` are accepted and recorded (one process
+    per GPU is launched by ``torch.distributed.run``; arithmetic is bf16 with fp32 masters; ``save_last`` is always on)."""
+
+    def __init__(self, max_epochs: int = 1, max_steps: int = -1, log_every_n_steps: int = 16, val_check_interval: int | None = None,
+                 limit_val_batches: int | None = None, default_root_dir: str = 'runs', grad_compress: Optional[str] = None, **ignored) -> None:
+        self.max_epochs, self.max_steps = max_epochs, (max_steps if max_steps and max_steps > 0 else None)
+        self.log_every_n_steps, self.val_check_interval, self.limit_val_batches = max(1, log_every_n_steps), val_check_interval, limit_val_batches
+        self.default_root_dir, self.grad_compress, self.ignored = default_root_dir, grad_compress, dict(ignored)
+        self.global_step = 0
+        self.history: List[dict] = []
+
+    @staticmethod
+    def _adamw_hparams(model) -> dict:
+        opt = model.configure_optimizers()
+        if type(opt).__name__ != 'AdamW':
+            raise NotImplementedError(f'Trainer: the fused optimiser kernel implements AdamW (the reference default, tokenizer.py:22,437-442); got {type(opt).__name__}')
+        d = opt.defaults
+        return dict(lr=d['lr'], betas=tuple(d['betas']), eps=d['eps'], weight_decay=d['weight_decay'])
+
+    def _log(self, model, dp: 'DataParallel', tag: str) -> dict:
+        logged = getattr(model, '_last_logged', {})
+        keys = sorted(logged)
+        vals = dp.reduce_scalars([logged[k] for k in keys]) if keys else torch.zeros(0)
+        rec = {'step': self.global_step, 'split': tag, **{k: round(v, 6) for k, v in zip(keys, vals.tolist())}}
+        self.history.append(rec)
+        if not dist.is_initialized() or dist.get_rank() == 0:
+            import json
+            print(json.dumps(rec), flush=True)
+        return rec
+
+    def validate(self, model, loader, dp) -> None:
+        from .module.data import DevicePrefetcher
+        model.eval()
+        with torch.no_grad():
+            for i, batch in enumerate(DevicePrefetcher(loader)):
+                if self.limit_val_batches is not None and i >= self.limit_val_batches:
+                    break
+                model.validation_step(batch, i)
+        model.train()
+        self._log(model, dp, 'val')
+
+    def save_last(self, model) -> str:
+        import os
+        path = os.path.join(self.default_root_dir, 'last.ckpt')
+        if not dist.is_initialized() or dist.get_rank() == 0:
+            os.makedirs(self.default_root_dir, exist_ok=True)
+            torch.save({'state_dict': {k: v.detach().cpu() for k, v in model.state_dict().items()}, 'global_step': self.global_step}, path)
+        return path
+
+    def fit(self, model, datamodule) -> 'Trainer':
+        from .module.data import DevicePrefetcher
+        dev = torch.device('cuda', torch.cuda.current_device())
+        model.to(dev).train()
+        datamodule.setup('fit')
+        hp = self._adamw_hparams(model)
+        arena = ParamArena(model)
+        arena.attach_weight_packs(model)
+        dp = DataParallel(arena.grads, compress=self.grad_compress)
+        if dp.active and hasattr(model, 'forward_order'):
+            # one bucket per top-level stage that owns parameters; the first stage's bucket is reduced by finish()
+            stages = [m for m in model.forward_order() if any(p.requires_grad for p in m.parameters())]
+            if len(stages) > 1:
+                dp.install_overlap_hooks(arena, model, stages[1:])
+        done = False
+        for epoch in range(self.max_epochs):
+            loader = datamodule.train_dataloader()
+            if hasattr(getattr(loader, 'sampler', None), 'set_epoch'):
+                loader.sampler.set_epoch(epoch)
+            for i, batch in enumerate(DevicePrefetcher(loader)):
+                loss = model.training_step(batch, i)
+                loss.backward()
+                dp.finish()
+                arena.adamw_step(**hp)
+                self.global_step += 1
+                if self.global_step % self.log_every_n_steps == 0:
+                    self._log(model, dp, 'train')
+                if self.val_check_interval and self.global_step % self.val_check_interval == 0:
+                    self.validate(model, datamodule.val_dataloader(), dp)
+                if self.max_steps is not None and self.global_step >= self.max_steps:
+                    done = True
+                    break
+            if done:
+                break
+        self._log(model, dp, 'train')
+        self.save_last(model)
+        return self

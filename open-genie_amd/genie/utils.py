@@ -38,3 +38,18 @@ def pick_frames(video: Tensor, frames_idxs: Tensor | None = None, frames_per_bat
 
 def enc2dec_name(name: str) -> str:
     return name.replace('downsample', 'upsample')
+
+
+def default_iterdata_worker_init(worker_id: int) -> None:
+    """Give every DataLoader worker of an IterableDataset its own seed and its own [_start, _end) slice of the stream
+    (reference utils.py:61-75)."""
+    from torch.utils.data import get_worker_info
+    torch.manual_seed(torch.initial_seed() + worker_id)
+    info = get_worker_info()
+    if info is None:
+        return
+    ds = info.dataset
+    lo, hi = ds._start, ds._end
+    per_worker = int((hi - lo) / info.num_workers)
+    ds._start = lo + info.id * per_worker
+    ds._end = min(ds._start + per_worker, hi)

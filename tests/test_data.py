@@ -1,0 +1,107 @@
+"""Data path on CPU: Platformer2D clip slicing / padding / axis order on raw frame arrays, the data modules'
+loaders, rank sharding, and the prefetcher's pass-through form."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from util import ROOT  # noqa: F401
+
+
+@pytest.fixture()
+def clips(tmp_path):
+    rng = np.random.default_rng(0)
+    for split, n in (('train', 5), ('val', 2), ('test', 2)):
+        d = tmp_path / 'Coinrun' / split
+        d.mkdir(parents=True)
+        for i in range(n):
+            frames = rng.integers(0, 256, size=(10 + 3 * i, 8, 12, 3), dtype=np.uint8)
+            if i % 2:
+                np.savez(d / f'ep{i}.npz', frames=frames)
+            else:
+                np.save(d / f'ep{i}.npy', frames)
+    (tmp_path / 'Coinrun' / 'train' / 'notes.txt').write_text('not a clip')
+    return str(tmp_path)
+
+
+def test_platformer2d_slicing_padding_and_format(clips):
+    from genie.module.data import Platformer2D
+    ds = Platformer2D(clips, split='train', num_frames=6, output_format='c t h w')
+    assert len(ds) == 5
+    v = ds[0]
+    raw = np.load(os.path.join(clips, 'Coinrun', 'train', 'ep0.npy'))
+    assert tuple(v.shape) == (3, 6, 8, 12) and v.dtype == torch.float32
+    assert torch.equal(v, torch.from_numpy(raw[:6].copy()).float().div(255.).permute(3, 0, 1, 2))
+    assert tuple(Platformer2D(clips, num_frames=6)[1].shape) == (6, 3, 8, 12)                  # default 't c h w'
+    # a clip shorter than the request comes back whole (reference data.py:190-192) ...
+    assert tuple(Platformer2D(clips, num_frames=64, padding='repeat')[0].shape) == (10, 3, 8, 12)
+    # ... random starts stay inside the clip
+    ds = Platformer2D(clips, num_frames=9, randomize=True)
+    for _ in range(10):
+        assert tuple(ds[0].shape) == (9, 3, 8, 12)
+    with pytest.raises(ValueError):
+        Platformer2D(clips, padding='mirror')
+    with pytest.raises(ValueError):
+        Platformer2D(clips, output_format='t c h')
+
+
+def test_padding_modes_fill_truncated_reads(clips, monkeypatch):
+    """A reader that delivers fewer frames than its header promises (what a damaged mp4 does) triggers the padding modes."""
+    from genie.module import data as D
+
+    class Short(D._ArrayReader):
+        def read(self, start, count):
+            return super().read(start, count)[: max(1, count - 3)]
+
+    monkeypatch.setattr(D, 'open_video', lambda p: Short(p))
+    base = D.Platformer2D(clips, num_frames=8, padding='none')[0]
+    assert base.shape[0] == 5
+    rep = D.Platformer2D(clips, num_frames=8, padding='repeat')[0]
+    assert rep.shape[0] == 8 and torch.equal(rep[:5], base) and all(torch.equal(rep[i], base[-1]) for i in range(5, 8))
+    zero = D.Platformer2D(clips, num_frames=8, padding='zero')[0]
+    assert zero.shape[0] == 8 and zero[5:].abs().sum() == 0
+    rnd = D.Platformer2D(clips, num_frames=8, padding='random')[0]
+    assert rnd.shape[0] == 8 and torch.equal(rnd[5], rnd[7]) and 0 <= rnd[5:].min() and rnd[5:].max() <= 1
+
+
+def test_video_container_needs_opencv(tmp_path):
+    from genie.module.data import open_video
+    p = tmp_path / 'clip.mp4'
+    p.write_bytes(b'')
+    try:
+        import cv2  # noqa: F401
+    except ImportError:
+        with pytest.raises(ImportError, match='OpenCV'):
+            open_video(str(p))
+    with pytest.raises(ValueError):
+        open_video(str(tmp_path / 'clip.gif'))
+
+
+def test_data_modules_and_prefetcher(clips):
+    from genie.dataset import LightningKinetics, LightningPlatformer2D, LightningSynthetic
+    from genie.module.data import DevicePrefetcher, LightningDataset
+    dm = LightningPlatformer2D(clips, num_frames=8, output_format='c t h w', batch_size=2, train_shuffle=False)
+    with pytest.raises(RuntimeError):
+        dm.train_dataloader()
+    dm.setup('fit')
+    batches = list(DevicePrefetcher(dm.train_dataloader(), device=None if not torch.cuda.is_available() else 'cuda'))
+    assert len(batches) == 3 and tuple(batches[0].shape) == (2, 3, 8, 8, 12) and tuple(batches[-1].shape) == (1, 3, 8, 8, 12)
+    assert len(list(dm.val_dataloader())) == 1
+    dm.setup('test')
+    assert len(dm.test_dataloader().dataset) == 2
+    with pytest.raises(ValueError):
+        dm.setup('predict')
+    syn = LightningSynthetic(num_clips=10, shape=(3, 4, 8, 8), batch_size=4)
+    syn.setup('fit')
+    a, b = next(iter(syn.train_dataloader())), next(iter(syn.train_dataloader()))
+    assert tuple(a.shape) == (4, 3, 4, 8, 8) and torch.equal(a, b) and 0 <= a.min() and a.max() <= 1
+    with pytest.raises(NotImplementedError):
+        LightningDataset().setup('fit')
+    with pytest.raises(ImportError):
+        LightningKinetics('x', 16)
+    import yaml
+    cfg = os.path.join(clips, 'data.yaml')
+    yaml.safe_dump({'dataset': {'root': clips, 'num_frames': 4, 'batch_size': 3}}, open(cfg, 'w'))
+    dm2 = LightningPlatformer2D.from_config(cfg)
+    assert dm2.batch_size == 3 and dm2.num_frames == 4
