@@ -73,12 +73,19 @@ def test_product_path_fails_loudly_without_gpu():
         m.quant(torch.randn(2, 6, 2, 4, 4), transpose=True)
 
 
-def test_default_tokenizer_critics_are_out_of_scope():
+def test_tokenizer_critics():
+    """GAN critic: built from disc_kwargs like the reference (tokenizer.py:294-299; with the default empty disc_kwargs the reference's
+    FrameDiscriminator() call fails for want of inp_size, and so does this one).  Perceptual critic: needs VGG16 weights that do not
+    exist offline -> calling it raises with a pointer to perc_loss_weight=0."""
     from genie import VideoTokenizer
+    from genie.module.loss import GANLoss
     g = torch.load(os.path.join(GOLD, 'tokenizer_small.pt'), weights_only=False)
-    m = VideoTokenizer(g['enc_desc'], g['dec_desc'], d_codebook=6)        # default gan/perc weights = 1
+    with pytest.raises(TypeError, match='inp_size'):
+        VideoTokenizer(g['enc_desc'], g['dec_desc'], d_codebook=6)        # default gan/perc weights = 1, disc_kwargs = {}
+    m = VideoTokenizer(g['enc_desc'], g['dec_desc'], d_codebook=6, disc_kwargs={'inp_size': 16, 'model_dim': 8})
+    assert isinstance(m.gan_crit, GANLoss) and sum(p.numel() for p in m.gan_crit.parameters()) > 0
     with pytest.raises(NotImplementedError, match='outside the implemented hot path'):
-        m.gan_crit(None, None, train_gen=True)
+        m.perc_crit(None, None)
 
 
 def test_param_arena_views_and_offsets():
