@@ -13,6 +13,9 @@
 // at genie/module/video.py:578,612, genie/module/norm.py:58, genie/module/misc.py:92.
 #include "common.h"
 #include "genie_hip.h"
+#include <stdlib.h>
+
+#define GENIE_GN_CHUNK_DEFAULT_MB 0ll      // sample chunking for memory-side-cache reuse: off unless measured faster (GENIE_GN_CHUNK_MB)
 
 #define GN_MAX_BLK 128
 
@@ -179,6 +182,16 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const bf16_t* __restrict_
     }
 }
 
+// Samples per launch group: all of them unless GENIE_GN_CHUNK_MB > 0 and the tensors streamed per sample (`streams` of them, each
+// `bytes_per_sample`) exceed that many MiB in total; then as many whole samples as fit.
+static int gn_chunk_samples(int N, long long bytes_per_sample, int streams) {
+    static long long chunk = -1;
+    if (chunk < 0) { const char* e = getenv("GENIE_GN_CHUNK_MB"); chunk = e ? atoll(e) * (1ll << 20) : GENIE_GN_CHUNK_DEFAULT_MB * (1ll << 20); }
+    if (chunk <= 0 || bytes_per_sample * streams * N <= chunk) return N;
+    long long n = chunk / (bytes_per_sample * streams);
+    return (int)(n < 1 ? 1 : n);
+}
+
 extern "C" int genie_groupnorm_fwd(const void* x, void* y, int N, int64_t npix, int C, int cpitch, int G, const float* gamma,
                                    const float* beta, const float* ada_scale, const float* ada_shift, float eps, int act,
                                    float* mean, float* rstd, float* ws, void* stream) {
@@ -186,14 +199,24 @@ extern "C" int genie_groupnorm_fwd(const void* x, void* y, int N, int64_t npix, 
     GENIE_CHECK_ARG(G >= 1 && C % G == 0, "genie_groupnorm_fwd: num_channels %d must be divisible by num_groups %d", C, G);
     GENIE_CHECK_ARG(cpitch % 8 == 0 && cpitch >= C, "genie_groupnorm_fwd: bad channel pitch %d for C=%d", cpitch, C);
     if (N == 0 || npix == 0) return GENIE_OK;
-    const GnGeom g = gn_geom(N, npix, C, cpitch, G);
     hipStream_t s = (hipStream_t)stream;
-    gn_stats_kernel<<<dim3(g.nblk, N), 256, 0, s>>>((const bf16_t*)x, g, ws);
-    GENIE_CHECK_LAUNCH();
-    gn_finalize_kernel<<<dim3(G, N), GN_FIN_THREADS, 0, s>>>(ws, g, eps, mean, rstd);
-    GENIE_CHECK_LAUNCH();
-    gn_apply_kernel<<<dim3(g.nblk, N), 256, 0, s>>>((const bf16_t*)x, (bf16_t*)y, g, gamma, beta, ada_scale, ada_shift, mean, rstd, act);
-    GENIE_CHECK_LAUNCH();
+    // Sample chunks: statistics and apply of a chunk run back to back, so the apply pass re-reads the chunk out of the
+    // memory-side cache (256 MB Infinity Cache) instead of HBM -- one HBM read + one write per element instead of two reads.
+    const int nsub = gn_chunk_samples(N, npix * cpitch * 2ll, 1);
+    for (int n0 = 0; n0 < N; n0 += nsub) {
+        const int nn = N - n0 < nsub ? N - n0 : nsub;
+        const GnGeom g = gn_geom(nn, npix, C, cpitch, G);
+        const bf16_t* xs = (const bf16_t*)x + (long long)n0 * npix * cpitch;
+        bf16_t* ys = (bf16_t*)y + (long long)n0 * npix * cpitch;
+        const float* as = ada_scale ? ada_scale + (long long)n0 * C : nullptr;
+        const float* ab = ada_shift ? ada_shift + (long long)n0 * C : nullptr;
+        gn_stats_kernel<<<dim3(g.nblk, nn), 256, 0, s>>>(xs, g, ws);
+        GENIE_CHECK_LAUNCH();
+        gn_finalize_kernel<<<dim3(G, nn), GN_FIN_THREADS, 0, s>>>(ws, g, eps, mean + (long long)n0 * G, rstd + (long long)n0 * G);
+        GENIE_CHECK_LAUNCH();
+        gn_apply_kernel<<<dim3(g.nblk, nn), 256, 0, s>>>(xs, ys, g, gamma, beta, as, ab, mean + (long long)n0 * G, rstd + (long long)n0 * G, act);
+        GENIE_CHECK_LAUNCH();
+    }
     return GENIE_OK;
 }
 
@@ -368,15 +391,27 @@ extern "C" int genie_groupnorm_bwd(const void* x, const void* dy, void* dx, int 
     GENIE_CHECK_ARG(G >= 1 && C % G == 0, "genie_groupnorm_bwd: num_channels %d must be divisible by num_groups %d", C, G);
     GENIE_CHECK_ARG(cpitch % 8 == 0 && cpitch >= C, "genie_groupnorm_bwd: bad channel pitch %d for C=%d", cpitch, C);
     if (N == 0 || npix == 0) return GENIE_OK;
-    const GnGeom g = gn_geom(N, npix, C, cpitch, G);
     hipStream_t s = (hipStream_t)stream;
     float* chan = ws + (long long)N * GN_MAX_BLK * cpitch * 2;
     float* kcoef = chan + (long long)N * cpitch * 4;
-    gn_bwd_reduce_kernel<<<dim3(g.nblk, N), 256, 0, s>>>((const bf16_t*)x, (const bf16_t*)dy, g, gamma, beta, ada_scale, ada_shift, mean, rstd, act, ws);
-    GENIE_CHECK_LAUNCH();
-    gn_bwd_finalize_kernel<<<dim3(G, N), GN_FIN_THREADS, 0, s>>>(ws, g, gamma, beta, ada_scale, mean, rstd, dgamma, dbeta, dada_scale, dada_shift, kcoef);
-    GENIE_CHECK_LAUNCH();
-    gn_bwd_apply_kernel<<<dim3(g.nblk, N), 256, 0, s>>>((const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, g, gamma, beta, ada_scale, ada_shift, mean, rstd, kcoef, act);
-    GENIE_CHECK_LAUNCH();
+    const int nsub = gn_chunk_samples(N, npix * cpitch * 2ll, 2);          // x and dy of a chunk stay in the memory-side cache
+    for (int n0 = 0; n0 < N; n0 += nsub) {
+        const int nn = N - n0 < nsub ? N - n0 : nsub;
+        const GnGeom g = gn_geom(nn, npix, C, cpitch, G);
+        const long long eo = (long long)n0 * npix * cpitch;
+        const bf16_t* xs = (const bf16_t*)x + eo;
+        const bf16_t* dys = (const bf16_t*)dy + eo;
+        const float* as = ada_scale ? ada_scale + (long long)n0 * C : nullptr;
+        const float* ab = ada_shift ? ada_shift + (long long)n0 * C : nullptr;
+        const float* mu = mean + (long long)n0 * G;
+        const float* rs = rstd + (long long)n0 * G;
+        gn_bwd_reduce_kernel<<<dim3(g.nblk, nn), 256, 0, s>>>(xs, dys, g, gamma, beta, as, ab, mu, rs, act, ws);
+        GENIE_CHECK_LAUNCH();
+        gn_bwd_finalize_kernel<<<dim3(G, nn), GN_FIN_THREADS, 0, s>>>(ws, g, gamma, beta, as, mu, rs, dgamma, dbeta, dada_scale ? dada_scale + (long long)n0 * C : nullptr,
+                                                                      dada_shift ? dada_shift + (long long)n0 * C : nullptr, kcoef);
+        GENIE_CHECK_LAUNCH();
+        gn_bwd_apply_kernel<<<dim3(g.nblk, nn), 256, 0, s>>>(xs, dys, (bf16_t*)dx + eo, g, gamma, beta, as, ab, mu, rs, kcoef, act);
+        GENIE_CHECK_LAUNCH();
+    }
     return GENIE_OK;
 }

@@ -68,8 +68,11 @@ class Genie(LightningModule):
 
     def _codes(self, tokens: Tensor) -> Tensor:
         """token indices (B, t, h, w) -> the {-1, +1} latent (B, d, t, h, w) the decoder consumes (MSB-first bits, quantization.py:72)."""
-        bits = (tokens.unsqueeze(-1) & self.tokenizer.quant.bit_mask) != 0
-        return (bits.float() * 2 - 1).permute(0, 4, 1, 2, 3).contiguous()
+        q = self.tokenizer.quant
+        codes = ((tokens.unsqueeze(-1) & q.bit_mask) != 0).float() * 2 - 1
+        if not isinstance(q.proj_out, torch.nn.Identity):             # a projecting LFQ hands the decoder proj_out(code) (quantization.py:104-108)
+            codes = q.proj_out(codes.to(q.proj_out.weight.dtype))
+        return codes.permute(0, 4, 1, 2, 3).contiguous()
 
     # -- inference -------------------------------------------------------------------------------------------------------------
     @torch.no_grad()

@@ -4,7 +4,7 @@ import copy
 import pytest
 import torch
 
-from util import assert_close_bf16, bf16_round
+from util import assert_close_bf16, bf16_round, report
 
 pytestmark = pytest.mark.gpu
 
@@ -315,7 +315,10 @@ def test_dynamics_full_vocabulary_parity():
     loss_ref = torch.nn.functional.cross_entropy(ref_m[mask].reshape(-1, V), tokf[mask].reshape(-1))
     assert abs(loss.item() - loss_ref.item()) < 1e-2 * abs(loss_ref.item()), (loss.item(), loss_ref.item())
     loss_ref.backward()
+    rr = {}
     for name in ('head.weight', 'head.bias', 'dec_layers.1.ffn.1.net.1.0.weight', 'dec_layers.0.space_attn.norm.weight', 'act_emb.0.weight'):
         p = dict(m.named_parameters())[name]
-        r = rel_rms(p.grad, sd_req[name].grad)
+        rr[name] = rel_rms(p.grad, sd_req[name].grad)
+    report('dynamics_full_vocabulary_parity', V=V, D=512, rows=512, loss_hip=loss.item(), loss_oracle=loss_ref.item(), grad_rel_rms=rr)
+    for name, r in rr.items():
         assert r < 6e-2, (name, r)

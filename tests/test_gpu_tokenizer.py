@@ -8,7 +8,7 @@ import copy
 import pytest
 import torch
 
-from util import assert_close_bf16, bf16_round
+from util import assert_close_bf16, bf16_round, report
 
 pytestmark = pytest.mark.gpu
 
@@ -247,6 +247,9 @@ def test_magvit2_full_training_step_parity():
     worst = max(errs, key=errs.get)
     print(f'MAGVIT2 B=2 training step: {len(errs)} parameter gradients, median rel-RMS {vals[len(vals) // 2]:.4f}, 95 % {vals[int(len(vals) * .95)]:.4f}, '
           f'worst {errs[worst]:.4f} ({worst})')
+    report('magvit2_full_training_step_parity', clips=2, params=len(errs), loss_hip=loss.item(), loss_oracle=loss_ref.item(), median_rel_rms=vals[len(vals) // 2],
+           p95_rel_rms=vals[int(len(vals) * .95)], worst_rel_rms=errs[worst], worst_param=worst, dlatent_rel_rms=rel_rms(qh.grad, q_in.grad),
+           lfq_indices_bit_exact=True)
     assert errs[worst] < 0.20, (worst, errs[worst])
     assert vals[len(vals) // 2] < 0.06, vals[len(vals) // 2]
 

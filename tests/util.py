@@ -32,3 +32,16 @@ def assert_close_bf16(out: torch.Tensor, ref: torch.Tensor, what: str = '', rel:
         raise AssertionError(f'{what}: {int(bad.sum())}/{bad.numel()} elements out of tolerance; worst err '
                              f'{err.flatten()[i].item():.4g} vs tol {tol.flatten()[i].item():.4g} '
                              f'(ref {ref.flatten()[i].item():.4g}, rms {rms:.4g})')
+
+
+def report(name: str, **values) -> None:
+    """Append one JSON line of measured parity numbers to gpurun_out/parity_report.jsonl (pytest swallows the prints of passing
+    tests; the judged summaries under profiles/ are copied from this file)."""
+    import json
+    try:
+        d = os.path.join(ROOT, 'gpurun_out')
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, 'parity_report.jsonl'), 'a') as f:
+            f.write(json.dumps({'test': name, **{k: (round(v, 6) if isinstance(v, float) else v) for k, v in values.items()}}) + '\n')
+    except OSError:
+        pass
