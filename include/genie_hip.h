@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GENIE_ABI_VERSION 4
+#define GENIE_ABI_VERSION 5
 
 #define GENIE_F32 0
 #define GENIE_BF16 1
@@ -253,6 +253,18 @@ int genie_maskgit_sample(const void* logits, int dtype, int64_t rows, int64_t ro
  * code[b][i] = pred[b][i], mask[b][i] = 0.  conf / pred / code / mask: [batch][n], n <= 32768. */
 int genie_maskgit_paint(const float* conf, const int64_t* pred, int64_t batch, int64_t n, int64_t k, int64_t* code,
                         unsigned char* mask, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * HBM-bound CausalConv3d with <= 4 input channels and 128 output channels, 3x3x3, stride 1 (conv_narrow.hip).
+ * replaces: the tokenizer's stem CausalConv3d(3 -> 128) (video.py:154-192 as used by tokenizer.py:25) and the backward-data pass of
+ *           its head conv CausalConv3d(128 -> 3) (tokenizer.py:172) -- 16.8 MB of output per 0.39 MB of input and clip.
+ * src: CL [N][T][H][W][src_pitch] (the first 4 channels of a pixel are read); dst: CL [N][T][H][W][dst_pitch >= 128].
+ * wpack: bf16 [128][112], k = tap * 4 + c with tap = ((dt - t_lo) * 3 + (dh + 1)) * 3 + (dw + 1); k = 108 / 109 hold a bias as a
+ * bf16 hi / lo pair (0 for none).  out[p][co] = sum_tap sum_c src[p + (dt, dh, dw)][c] * w[co][tap][c] (+ bias), zero outside.
+ * t_lo = - (causal front padding): -2 for the stem's forward, 0 for the head's backward-data pass, -1 for a symmetric conv.
+ * ------------------------------------------------------------------------------------------- */
+int genie_conv_narrow_in(const void* src_cl, int src_pitch, const void* wpack, void* dst_cl, int dst_pitch, int N, int T, int H, int W,
+                         int t_lo, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Losses and optimiser (elementwise.hip).

@@ -277,6 +277,66 @@ def pack_weight_bwd(weight: Tensor, spec: ConvSpec) -> Tensor:
 
 
 # ------------------------------------------------------------------------------------------------
+# HBM-bound narrow convolutions (conv_narrow.hip): <= 4 input channels -> 128 output channels, 3x3x3, stride 1 -- the tokenizer's
+# stem (video.py:154-192 via MAGVIT2_ENC_DESC[0]) and the backward-data pass of its head conv (128 -> 3)
+# ------------------------------------------------------------------------------------------------
+NARROW_CONV = os.environ.get('GENIE_NARROW_CONV', '1') != '0'
+_NARROW_W = (32, 64, 128)
+
+
+def _narrow_geometry_ok(spec: ConvSpec) -> bool:
+    return (spec.kernel == (3, 3, 3) and spec.stride == (1, 1, 1) and spec.dilation == (1, 1, 1) and spec.shuffle is None
+            and spec.pad_front[1:] == (1, 1) and spec.pad_back[1:] == (1, 1) and spec.pad_front[0] + spec.pad_back[0] == 2)
+
+
+def narrow_fwd_ok(spec: ConvSpec, x: Tensor) -> bool:
+    """Forward of a (<= 4) -> 128 channel conv on the narrow-input kernel?"""
+    return NARROW_CONV and spec.cin <= 4 and spec.cout == 128 and _narrow_geometry_ok(spec) and x.shape[4] in _NARROW_W and pitch_of(x) % 4 == 0
+
+
+def narrow_dgrad_ok(spec: ConvSpec, dy: Tensor) -> bool:
+    """Backward-data of a 128 -> (<= 4) channel conv (= a (<= 4) -> 128 conv of dy with flipped taps) on the narrow-input kernel?"""
+    return NARROW_CONV and spec.cin == 128 and spec.cout <= 4 and _narrow_geometry_ok(spec) and dy.shape[4] in _NARROW_W and pitch_of(dy) % 4 == 0
+
+
+def _narrow_pack(w_rows: Tensor, bias: Optional[Tensor]) -> Tensor:
+    """w_rows: fp32 (128, 27, c <= 4) in the kernel's tap order -> bf16 [128][112]: k = tap * 4 + c, k = 108 / 109 = bias as a bf16
+    hi / lo pair (the kernel multiplies both by 1.0), k = 110, 111 zero."""
+    rows, ntap, c = w_rows.shape
+    pack = torch.zeros((rows, 28, 4), dtype=torch.float32, device=w_rows.device)
+    pack[:, :27, :c] = w_rows
+    if bias is not None:
+        hi = bias.detach().float().to(torch.bfloat16).float()
+        pack[:, 27, 0] = hi
+        pack[:, 27, 1] = bias.detach().float() - hi
+    return pack.reshape(rows, 112).to(torch.bfloat16).contiguous()
+
+
+def pack_narrow_fwd(weight: Tensor, bias: Optional[Tensor]) -> Tensor:
+    """weight (128, cin <= 4, 3, 3, 3) -> narrow pack, taps in (kt, kh, kw) order."""
+    w = weight.detach().float().permute(0, 2, 3, 4, 1).reshape(weight.shape[0], 27, weight.shape[1])
+    return _narrow_pack(w, bias)
+
+
+def pack_narrow_bwd(weight: Tensor) -> Tensor:
+    """weight (cout <= 4, 128, 3, 3, 3) of the FORWARD conv -> pack of its backward-data pass: rows = input channels, taps flipped."""
+    w = weight.detach().float().flip(2, 3, 4).permute(1, 2, 3, 4, 0).reshape(weight.shape[1], 27, weight.shape[0])
+    return _narrow_pack(w, None)
+
+
+def conv_narrow_in(x: Tensor, pack: Tensor, t_lo: int, label: str = '') -> Tensor:
+    """x: CL (N, c <= 4, T, H, W); returns CL (N, 128, T, H, W) = sum over the 27 taps (dt in t_lo .. t_lo + 2, dh, dw in -1 .. 1)."""
+    n, c, t, h, w = x.shape
+    out = empty_cl(n, 128, t, h, w, x.device)
+    t0 = PROFILER.begin() if PROFILER is not None and not PROFILER.only_triple else None
+    _hip.check(_hip.load_library().genie_conv_narrow_in(x.data_ptr(), pitch_of(x), pack.data_ptr(), out.data_ptr(), pitch_of(out), n, t, h, w, int(t_lo),
+                                                        _hip.stream_ptr()), 'genie_conv_narrow_in')
+    if t0 is not None:
+        PROFILER.end('conv_narrow_in_kernel', label, 2.0 * n * t * h * w * 128 * c * 27, t0)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
 # launches
 # ------------------------------------------------------------------------------------------------
 _splitk_cache = {}

@@ -23,6 +23,7 @@ from torch import Tensor
 
 from . import _hip
 from .cl import empty_like_cl, is_cl, pitch_of, to_cl
+from . import conv as _conv
 from .conv import ConvSpec, conv_dgrad, conv_forward, conv_wgrad, pack_weight_bwd, pack_weight_fwd
 
 DIRECT_PARAM_GRADS = __import__('os').environ.get('GENIE_DIRECT_PARAM_GRADS', 'arena')
@@ -38,6 +39,49 @@ def _direct(p: Optional[Tensor]) -> bool:
     return getattr(p, '_genie_arena', False)
 
 FUSED_RESBLOCK = __import__('os').environ.get('GENIE_FUSED_RESBLOCK', '1') != '0'    # VideoResidualBlock as one autograd node
+
+# Weight-gradient kernels on a side stream (GENIE_ASYNC_WGRAD=1 or functional.ASYNC_WGRAD = True; arena-managed parameters only).
+# A wgrad launch only feeds the optimiser: nothing in the rest of backward waits for it.  Issued on its own stream it runs
+# CONCURRENTLY with whatever the main stream does next -- in particular the HBM-bound GroupNorm backward passes and shortcut
+# convolutions, which leave the matrix pipes idle (12 + ~5 ms of an 87 ms step) while the MFMA-bound wgrad kernels (23 ms) leave
+# HBM idle.  Contract: whoever consumes the gradients joins first -- ``join_wgrad()``; ParamArena.adamw_step / zero_grad and
+# DataParallel do.  Off by default because a plain ``loss.backward(); torch_optimizer.step()`` would race.
+ASYNC_WGRAD = __import__('os').environ.get('GENIE_ASYNC_WGRAD', '0') == '1'
+_wgrad_streams = {}
+_wgrad_pending = set()
+
+
+def wgrad_stream(device=None):
+    idx = torch.cuda.current_device() if device is None or device.index is None else device.index
+    st = _wgrad_streams.get(idx)
+    if st is None:
+        st = _wgrad_streams[idx] = torch.cuda.Stream(device=idx)
+    return st
+
+
+def _wgrad(x: Tensor, dy: Tensor, spec, gw: Tensor, gb: Optional[Tensor]) -> None:
+    """conv_wgrad into arena-managed gradients, on the side stream when ASYNC_WGRAD is on."""
+    if not ASYNC_WGRAD:
+        conv_wgrad(x, dy, spec, gw, gb)
+        return
+    side = wgrad_stream(x.device)
+    side.wait_stream(torch.cuda.current_stream())              # x and dy are complete
+    with torch.cuda.stream(side):
+        conv_wgrad(x, dy, spec, gw, gb)
+    x.record_stream(side)                                      # the caching allocator must not hand these out again before the kernel ran
+    dy.record_stream(side)
+    _wgrad_pending.add(side.device.index)
+
+
+def join_wgrad(stream=None) -> None:
+    """Make `stream` (default: the current stream) wait for every weight-gradient kernel issued on a side stream so far."""
+    if not _wgrad_pending:
+        return
+    for idx in list(_wgrad_pending):
+        (stream if stream is not None else torch.cuda.current_stream(idx)).wait_stream(_wgrad_streams[idx])
+    if stream is None:
+        _wgrad_pending.clear()
+
 
 _ws_cache = {}
 
@@ -81,11 +125,24 @@ class ConvOp:
             self._bwd = (key, pack_weight_bwd(weight, self.spec))
         return self._bwd[1]
 
+    def pack_narrow(self, weight: Tensor, bias: Optional[Tensor], backward: bool) -> Tensor:
+        """Pack for the HBM-bound narrow kernel (conv_narrow.hip), rebuilt when the weight (or bias) changes."""
+        key = (weight._version, weight.data_ptr(), None if bias is None or backward else (bias._version, bias.data_ptr()))
+        slot = '_nbwd' if backward else '_nfwd'
+        cur = getattr(self, slot, (None, None))
+        if cur[0] != key:
+            cur = (key, _conv.pack_narrow_bwd(weight) if backward else _conv.pack_narrow_fwd(weight, bias))
+            setattr(self, slot, cur)
+        return cur[1]
+
 
 class _Conv3dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x: Tensor, weight: Tensor, bias: Optional[Tensor], op: ConvOp, resid: Optional[Tensor]):
-        out = conv_forward(x, op.pack_fwd(weight), bias, op.spec, resid=resid)
+        if resid is None and _conv.narrow_fwd_ok(op.spec, x):
+            out = _conv.conv_narrow_in(x, op.pack_narrow(weight, bias, False), -op.spec.pad_front[0], f'fwd {op.spec.cin}->128 k3 @{tuple(x.shape[2:])}')
+        else:
+            out = conv_forward(x, op.pack_fwd(weight), bias, op.spec, resid=resid)
         ctx.op = op
         ctx.in_size = tuple(x.shape[2:])
         ctx.has_resid = resid is not None
@@ -99,7 +156,10 @@ class _Conv3dFn(torch.autograd.Function):
         dy = to_cl(dy)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = conv_dgrad(dy, op.pack_bwd(weight), op.spec, ctx.in_size)
+            if _conv.narrow_dgrad_ok(op.spec, dy):
+                dx = _conv.conv_narrow_in(dy, op.pack_narrow(weight, None, True), op.spec.pad_front[0] - 2, f'dgrad 128->{op.spec.cout} k3 @{tuple(dy.shape[2:])}')
+            else:
+                dx = conv_dgrad(dy, op.pack_bwd(weight), op.spec, ctx.in_size)
         need_w = ctx.needs_input_grad[1]
         need_b = bias is not None and ctx.needs_input_grad[2]
         if need_w or need_b:
@@ -110,7 +170,7 @@ class _Conv3dFn(torch.autograd.Function):
             if wleaf is not None and _direct(wleaf) and wleaf.is_leaf and (wleaf is weight or linear_view) and (bias is None or (bias.is_leaf and _direct(bias))):
                 gw = _grad_buffer(wleaf).view(weight.shape) if wleaf is not weight else _grad_buffer(weight)
                 gb = _grad_buffer(bias) if need_b else None
-                conv_wgrad(x, dy, op.spec, gw, gb)
+                (_wgrad if getattr(wleaf, '_genie_arena', False) else conv_wgrad)(x, dy, op.spec, gw, gb)
             else:
                 dw = torch.zeros(weight.shape, dtype=torch.float32, device=weight.device)
                 db = torch.zeros_like(bias) if need_b else None
@@ -528,13 +588,14 @@ class _ResBlockFn(torch.autograd.Function):
         dy = to_cl(dy)
         gb = lambda b: _grad_buffer(b) if b is not None else None
         d_hn = conv_dgrad(dy, op_b.pack_bwd(wb), op_b.spec, ctx.size)
-        conv_wgrad(hn, dy, op_b.spec, _grad_buffer(wb), gb(bb))
+        wg = _wgrad if getattr(wb, '_genie_arena', False) else conv_wgrad
+        wg(hn, dy, op_b.spec, _grad_buffer(wb), gb(bb))
         d_h1 = _gn_bwd_raw(h1, d_hn, g2w, g2b, m2, r2, ctx.groups, 1)
         del d_hn
         d_xn = conv_dgrad(d_h1, op_a.pack_bwd(wa), op_a.spec, ctx.size)
-        conv_wgrad(xn, d_h1, op_a.spec, _grad_buffer(wa), gb(ba))
+        wg(xn, d_h1, op_a.spec, _grad_buffer(wa), gb(ba))
         del d_h1
-        conv_wgrad(x, dy, op_r.spec, _grad_buffer(wr), gb(br))
+        wg(x, dy, op_r.spec, _grad_buffer(wr), gb(br))
         dx = None
         if ctx.needs_input_grad[0]:
             d_xm = _gn_bwd_raw(x, d_xn, g1w, g1b, m1, r1, ctx.groups, 1)

@@ -168,6 +168,8 @@ class ParamArena:
         return min(offs) if offs else None
 
     def zero_grad(self) -> None:
+        from . import functional as GF
+        GF.join_wgrad()
         self.grads.zero_()
 
     def adamw_step(self, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2,
@@ -175,6 +177,8 @@ class ParamArena:
         """torch.optim.AdamW semantics (the reference's optimiser, tokenizer.py:437-442) in ONE kernel over the arena."""
         self.step_count += 1
         lib = _hip.load_library()
+        from . import functional as GF
+        GF.join_wgrad()                                   # weight-gradient kernels issued on the side stream (functional.ASYNC_WGRAD)
         if self.mirror is not None:
             _hip.check(lib.genie_adamw_step_mirror(self.params.data_ptr(), self.grads.data_ptr(), self.exp_avg.data_ptr(),
                                                    self.exp_avg_sq.data_ptr(), self.mirror.data_ptr(), self.numel, lr, betas[0], betas[1],
@@ -238,7 +242,9 @@ class DataParallel:
             return
         chunk = self.grads[lo:hi]
         if self.comm_stream is not None:
-            self.comm_stream.wait_stream(torch.cuda.current_stream())       # behind every kernel enqueued so far
+            from . import functional as GF
+            self.comm_stream.wait_stream(torch.cuda.current_stream())       # behind every kernel enqueued so far ...
+            GF.join_wgrad(self.comm_stream)                                 # ... including weight gradients on their side stream
             with torch.cuda.stream(self.comm_stream):
                 self._all_reduce_mean(chunk, lo)
         else:

@@ -549,3 +549,63 @@ def test_residual_block_with_blur_downsample(G):
     assert tuple(out.shape) == tuple(ref.shape) == (2, 128, 2, 4, 4)
     rel = ((out.float().cpu() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()
     assert rel < 2e-2, rel
+
+
+@pytest.mark.parametrize('cin,causal,size', [(3, True, (2, 5, 10, 64)), (3, False, (1, 3, 7, 32)), (4, True, (1, 2, 4, 128)), (1, True, (2, 4, 9, 64)),
+                                              (3, True, (8, 16, 64, 64))])
+def test_conv_narrow_in_kernel(G, cin, causal, size):
+    """conv_narrow.hip: the HBM-bound stem CausalConv3d(<= 4 -> 128) forward, and the backward-data pass of the head conv (128 -> <= 4)
+    as the same kernel with flipped taps, both through the module-level path (functional._Conv3dFn) against the oracle; the packed
+    bias (bf16 hi + lo) must reproduce the fp32 bias."""
+    from genie import functional as GF
+    torch.manual_seed(17)
+    n, t, h, w = size
+    kernel = (3, 3, 3)
+    # ---- forward: cin -> 128 ----
+    x = bf16_round(torch.randn(n, cin, t, h, w))
+    wt = bf16_round(torch.randn(128, cin, *kernel) / (cin * 27) ** 0.5)
+    b = torch.randn(128) * 3
+    spec = G.conv.causal_spec(cin, 128, kernel) if causal else G.conv.same_spec(cin, 128, kernel)
+    xc = G.cl.to_cl(x.cuda())
+    assert G.conv.narrow_fwd_ok(spec, xc)
+    op = GF.ConvOp(spec)
+    wd, bd = wt.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    G.conv.PROFILER = prof = G.conv.LaunchProfiler()
+    try:
+        out = GF.conv3d(xc, wd, bd, op)
+    finally:
+        G.conv.PROFILER = None
+    assert 'conv_narrow_in_kernel' in prof.summary(), list(prof.summary())
+    ref = _conv_ref(x, wt, b, (1, 1, 1), causal)
+    assert tuple(out.shape) == tuple(ref.shape)
+    assert_close_bf16(out, ref, 'narrow conv fwd')
+    # the generic kernel on the same inputs agrees as well (same algorithm, other tiling)
+    gen = G.conv.conv_forward(xc, G.conv.pack_weight_fwd(wd.detach(), spec), bd.detach(), spec)
+    assert_close_bf16(out, gen.float().cpu(), 'narrow vs generic', rel=2 ** -7, rms_frac=3e-3)
+    # weight / bias gradients still come from the generic wgrad kernel
+    dy = bf16_round(torch.randn_like(ref))
+    out.backward(dy.cuda())
+    wr, br = wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    _conv_ref(x, wr, br, (1, 1, 1), causal).backward(dy)
+    assert_close_bf16(wd.grad, wr.grad, 'narrow conv dW', rel=2 ** -6, rms_frac=1e-2)
+    assert_close_bf16(bd.grad, br.grad, 'narrow conv db', rel=2 ** -6, rms_frac=1e-2)
+    # ---- backward-data of 128 -> cin ----
+    if n * t * h * w > 100000:
+        return
+    spec2 = G.conv.causal_spec(128, cin, kernel) if causal else G.conv.same_spec(128, cin, kernel)
+    x2 = bf16_round(torch.randn(n, 128, t, h, w)).requires_grad_(True)
+    w2 = bf16_round(torch.randn(cin, 128, *kernel) / (128 * 27) ** 0.5)
+    y2 = _conv_ref(x2, w2, None, (1, 1, 1), causal)
+    dy2 = bf16_round(torch.randn_like(y2))
+    y2.backward(dy2)
+    dyc = G.cl.to_cl(dy2.cuda())
+    assert G.conv.narrow_dgrad_ok(spec2, dyc)
+    x2c = G.cl.to_cl(x2.detach().cuda()).requires_grad_(True)
+    op2 = GF.ConvOp(spec2)
+    G.conv.PROFILER = prof = G.conv.LaunchProfiler()
+    try:
+        GF.conv3d(x2c, w2.cuda(), None, op2).backward(dyc)
+    finally:
+        G.conv.PROFILER = None
+    assert 'conv_narrow_in_kernel' in prof.summary(), list(prof.summary())
+    assert_close_bf16(x2c.grad, x2.grad, 'narrow conv dgrad')

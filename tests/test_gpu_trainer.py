@@ -159,3 +159,32 @@ def test_data_parallel_loopback_on_real_models():
                 assert err <= 2 ** -7 * b.abs().max().item() + 1e-6, (name, err, b.abs().max().item())
     finally:
         dist.destroy_process_group()
+
+
+def test_async_wgrad_side_stream_matches_in_order_execution():
+    """functional.ASYNC_WGRAD: weight-gradient kernels issued on a side stream (concurrent with the rest of backward) give the same
+    gradients and the same parameters after the optimiser step as in-order execution -- the joins in ParamArena / DataParallel hold."""
+    from genie import functional as GF
+    from genie.trainer import ParamArena
+    x = torch.randn(2, 3, 4, 16, 16, device='cuda')
+    res = []
+    for flag in (False, True):
+        GF.ASYNC_WGRAD = flag
+        try:
+            m = _model()
+            arena = ParamArena(m)
+            arena.attach_weight_packs(m)
+            for _ in range(2):
+                loss, _ = m(x)
+                loss.backward()
+                GF.join_wgrad()
+                g = arena.grads.clone()
+                arena.adamw_step(lr=1e-3, weight_decay=0.01)
+            torch.cuda.synchronize()
+            res.append((g, arena.params.clone(), loss.item()))
+        finally:
+            GF.ASYNC_WGRAD = False
+    (g0, p0, l0), (g1, p1, l1) = res
+    assert abs(l0 - l1) <= 1e-3 * abs(l0)
+    assert (g0 - g1).abs().max().item() <= 2e-3 * g0.abs().max().item() + 1e-6          # fp32 atomics order only
+    assert (p0 - p1).abs().max().item() <= 3e-3
