@@ -136,8 +136,8 @@ def main():
     ap.add_argument('--dump', type=str, default='')
     ap.add_argument('--grad-compress', choices=['none', 'bf16'], default=os.environ.get('GENIE_GRAD_COMPRESS', 'none'),
                     help='gradient all-reduce payload: fp32 (exact, default) or bf16 (half the xGMI bytes)')
-    ap.add_argument('--async-wgrad', type=int, default=int(os.environ.get('GENIE_ASYNC_WGRAD', 1)),
-                    help='1: weight-gradient kernels on a side stream, concurrent with the HBM-bound GroupNorm / shortcut passes of backward')
+    ap.add_argument('--async-wgrad', type=int, default=int(os.environ.get('GENIE_ASYNC_WGRAD', 2)),
+                    help='1: weight-gradient kernels on a side stream, overlapping the HBM-bound GroupNorm / element-wise passes of backward (conv launches wait for it); 2: unordered; 0: off')
     ap.add_argument('--dp-loopback', action='store_true', help='N = 1 only: run the RCCL bucket all-reduces on a single-rank group (side-stream path on one GPU)')
     args = ap.parse_args()
 
@@ -172,7 +172,7 @@ def main():
     from genie import MAGVIT2_DEC_DESC, MAGVIT2_ENC_DESC, VideoTokenizer, conv as gconv
     from genie import functional as GF
     from genie.trainer import DataParallel, ParamArena
-    GF.ASYNC_WGRAD = bool(args.async_wgrad)
+    GF.ASYNC_WGRAD = int(args.async_wgrad)
 
     torch.manual_seed(0)                                   # identical initial weights on every rank
     model = VideoTokenizer(MAGVIT2_ENC_DESC, MAGVIT2_DEC_DESC, d_codebook=18, gan_loss_weight=0., perc_loss_weight=0.).to(dev).train()
@@ -232,7 +232,7 @@ def main():
         'config': {'workload': 'configs[1]: VideoTokenizer (MAGVIT2_ENC/DEC_DESC, d_codebook=18) training, 16x64x64 random clips, bf16 activations / fp32 master weights; '
                                'step = encode + LFQ(train) + decode + MSE + quant loss + backward + AdamW (R-fwd loss)',
                    'clips_per_gpu': B, 'global_batch': B * world, 'clip': list(CLIP), 'params': 375554837, 'parallelism': f'dp{world}',
-                   'wgrad_side_stream': bool(args.async_wgrad),
+                   'wgrad_side_stream': {0: 'off', 1: 'on (conv launches wait for it: overlaps GroupNorm / element-wise passes only)', 2: 'on (unordered)'}.get(int(args.async_wgrad)),
                    'grad_allreduce': {'payload': 'fp32' if args.grad_compress == 'none' else 'bf16', 'buckets': len(dp.buckets),
                                       'bytes_per_step': dp.bytes_reduced // max(1, args.steps + args.warmup), 'overlapped_with_backward': dp.active,
                                       'loopback': bool(args.dp_loopback and world == 1)},

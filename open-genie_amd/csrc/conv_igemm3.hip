@@ -28,6 +28,7 @@ struct Igemm3Args {
     IgemmArgs g;                   // tensors, row grid (To/Ho/Wo == Ts/Hs/Ws), destination mapping, weight permutation, tiles
     int nsteps;                    // entries of the step table, one per (dt, dh, channel block)
     int WP, img_rows;              // W + 2, (BM / W) * WP
+    int xcdcol;                    // 1: every XCD works on ONE column tile (its weight slice stays L2-resident); grid is rounded up
     int dbg;                       // timing ablations (results are WRONG when non-zero): 4 no glds in the loop, 8 no ds_read,
                                    // 16 no MFMA, 32 no barrier
 };
@@ -288,7 +289,14 @@ __global__ void __launch_bounds__(64 * NWAVE) igemm3d_kernel(const Igemm3Args p,
     const int W = a.Wo, H = a.Ho, T = a.To, WP = p.WP;
 
     int tile_m, tile_n;
-    {
+    if (p.xcdcol) {
+        // blocks are dealt round-robin to the 8 XCDs: XCD x takes column tile x % tiles_n and every (8 / tiles_n)-th row tile, so the
+        // weight rows an XCD streams (1.75 MB for 256 -> 256 x 27 taps) stay in its 4 MB L2 while the activations stream through
+        const int per = 8 / a.tiles_n, x = blockIdx.x & 7;
+        tile_n = x % a.tiles_n;
+        tile_m = (int)(blockIdx.x >> 3) * per + x / a.tiles_n;
+        if (tile_m >= a.tiles_m) return;
+    } else {
         const int id = xcd_tile_id(a.tiles_m * a.tiles_n, blockIdx.x);
         tile_n = id % a.tiles_n;
         tile_m = id / a.tiles_n;
@@ -759,7 +767,8 @@ static int launch_igemm3d_t(const Igemm3Args& p, const GenieTriStep* steps, hipS
         }
         configured = true;
     }
-    hipLaunchKernelGGL((igemm3d_kernel<PRE, SPLITK, NWAVE>), dim3(p.g.tiles_m * p.g.tiles_n, SPLITK ? p.g.split_k : 1), dim3(64 * NWAVE), lds, s, p, steps);
+    const int nblk = p.xcdcol ? cdiv(p.g.tiles_m, 8 / p.g.tiles_n) * 8 : p.g.tiles_m * p.g.tiles_n;
+    hipLaunchKernelGGL((igemm3d_kernel<PRE, SPLITK, NWAVE>), dim3(nblk, SPLITK ? p.g.split_k : 1), dim3(64 * NWAVE), lds, s, p, steps);
     GENIE_CHECK_LAUNCH();
     if (SPLITK) return genie_igemm_splitk_finish(p.g, s);
     return GENIE_OK;
@@ -843,6 +852,8 @@ int genie_conv_igemm3_try(const GenieConvDesc* d, IgemmArgs a, hipStream_t s) {
     p.WP = W + 2;
     p.img_rows = (bm / W) * (W + 2);
     p.dbg = d->tri_flags & 60;                          // bits 2-5: timing ablations
+    static const int xcdcol_env = getenv("GENIE_TRI_XCDCOL") ? atoi(getenv("GENIE_TRI_XCDCOL")) : 0;
+    p.xcdcol = (((d->tri_flags & 512) || xcdcol_env) && bm == 256 && (tiles_n == 2 || tiles_n == 4 || tiles_n == 8)) ? 1 : 0;
     const bool pipe = (d->tri_flags & 1) == 0;
     genie_note_variant(split > 1 ? GENIE_VARIANT_IGEMM3_256_SPLITK : (bm == 256 ? GENIE_VARIANT_IGEMM3_256 : GENIE_VARIANT_IGEMM3_128));
     if (bm == 256 && (d->tri_flags & 2) == 0) {                                                // deep-prefetch schedules

@@ -46,7 +46,12 @@ FUSED_RESBLOCK = __import__('os').environ.get('GENIE_FUSED_RESBLOCK', '1') != '0
 # convolutions, which leave the matrix pipes idle (12 + ~5 ms of an 87 ms step) while the MFMA-bound wgrad kernels (23 ms) leave
 # HBM idle.  Contract: whoever consumes the gradients joins first -- ``join_wgrad()``; ParamArena.adamw_step / zero_grad and
 # DataParallel do.  Off by default because a plain ``loss.backward(); torch_optimizer.step()`` would race.
-ASYNC_WGRAD = __import__('os').environ.get('GENIE_ASYNC_WGRAD', '0') == '1'
+# Mode 1 (what bench.py uses): every conv forward / backward-data launch on the main stream first waits for the side stream, so the
+# MFMA-bound gather-GEMMs never share the chip with a wgrad kernel -- the wgrad kernels overlap the NON-conv work that follows them
+# (GroupNorm backward, LFQ, element-wise passes) and nothing else; per-kernel timings of the gather-GEMMs stay clean.  Mode 2: no
+# such waits (wgrad runs whenever the hardware finds room; measured equally fast end to end, but it inflates the wall time of the
+# conv kernels it shares CUs with).
+ASYNC_WGRAD = int(__import__('os').environ.get('GENIE_ASYNC_WGRAD', '0'))
 _wgrad_streams = {}
 _wgrad_pending = set()
 
@@ -71,6 +76,31 @@ def _wgrad(x: Tensor, dy: Tensor, spec, gw: Tensor, gb: Optional[Tensor]) -> Non
     x.record_stream(side)                                      # the caching allocator must not hand these out again before the kernel ran
     dy.record_stream(side)
     _wgrad_pending.add(side.device.index)
+
+
+_LFQ_DEFER = False
+
+
+class deferred_lfq_loss:
+    """Context: LFQ training losses computed inside it are issued on the side stream (when ASYNC_WGRAD == 2) -- the caller must call
+    ``join_wgrad()`` before reading the loss or running backward."""
+
+    def __enter__(self):
+        global _LFQ_DEFER
+        self._old = _LFQ_DEFER
+        _LFQ_DEFER = ASYNC_WGRAD == 2
+        return self
+
+    def __exit__(self, *exc):
+        global _LFQ_DEFER
+        _LFQ_DEFER = self._old
+        return False
+
+
+def _conv_gate() -> None:
+    """Called before a conv forward / backward-data launch: in mode 1 the main stream waits for outstanding wgrad kernels."""
+    if ASYNC_WGRAD == 1 and _wgrad_pending:
+        join_wgrad()
 
 
 def join_wgrad(stream=None) -> None:
@@ -139,6 +169,7 @@ class ConvOp:
 class _Conv3dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x: Tensor, weight: Tensor, bias: Optional[Tensor], op: ConvOp, resid: Optional[Tensor]):
+        _conv_gate()
         if resid is None and _conv.narrow_fwd_ok(op.spec, x):
             out = _conv.conv_narrow_in(x, op.pack_narrow(weight, bias, False), -op.spec.pad_front[0], f'fwd {op.spec.cin}->128 k3 @{tuple(x.shape[2:])}')
         else:
@@ -156,6 +187,7 @@ class _Conv3dFn(torch.autograd.Function):
         dy = to_cl(dy)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
+            _conv_gate()
             if _conv.narrow_dgrad_ok(op.spec, dy):
                 dx = _conv.conv_narrow_in(dy, op.pack_narrow(weight, None, True), op.spec.pad_front[0] - 2, f'dgrad 128->{op.spec.cout} k3 @{tuple(dy.shape[2:])}')
             else:
@@ -397,8 +429,21 @@ class _LfqFn(torch.autograd.Function):
             loss4 = torch.empty(4, dtype=torch.float32, device=z2d.device)
             dzl = torch.empty((ntok, ncb * d), dtype=torch.float32, device=z2d.device)
             ws = workspace(lib.genie_lfq_loss_ws_floats(ntok, ncb, d), z2d.device, 'lfq')
-            _hip.check(lib.genie_lfq_loss(z2d.data_ptr(), dt, ntok, ncb, d, pitch, beta, commit_w, ent_w, div_w, ws.data_ptr(), loss4.data_ptr(),
-                                          dzl.data_ptr(), _hip.stream_ptr()), 'genie_lfq_loss')
+            if _LFQ_DEFER:
+                # inside `deferred_lfq_loss()`: the loss kernels (VALU-bound: 2^18 codes per token enumerated on chip, 5 ms at 8192 tokens)
+                # go to the side stream and run under whatever the caller launches next (the decoder); the caller joins before it
+                # touches the loss (VideoTokenizer.forward does)
+                side = wgrad_stream(z2d.device)
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    _hip.check(lib.genie_lfq_loss(z2d.data_ptr(), dt, ntok, ncb, d, pitch, beta, commit_w, ent_w, div_w, ws.data_ptr(), loss4.data_ptr(),
+                                                  dzl.data_ptr(), _hip.stream_ptr()), 'genie_lfq_loss')
+                for t_ in (z2d, loss4, dzl):
+                    t_.record_stream(side)
+                _wgrad_pending.add(side.device.index)
+            else:
+                _hip.check(lib.genie_lfq_loss(z2d.data_ptr(), dt, ntok, ncb, d, pitch, beta, commit_w, ent_w, div_w, ws.data_ptr(), loss4.data_ptr(),
+                                              dzl.data_ptr(), _hip.stream_ptr()), 'genie_lfq_loss')
             ctx.save_for_backward(dzl)
         ctx.meta = (dt, ntok, width, pitch, z2d.dtype, z2d.shape[1])
         ctx.training = bool(training)
@@ -571,6 +616,7 @@ class _ResBlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, g1w, g1b, wa, ba, g2w, g2b, wb, bb, wr, br, ops, groups: int, eps1: float, eps2: float):
         op_a, op_b, op_r = ops
+        _conv_gate()
         xn, m1, r1 = _gn_fwd_raw(x, g1w, g1b, groups, eps1, 1)
         h1 = conv_forward(xn, op_a.pack_fwd(wa), ba, op_a.spec)
         hn, m2, r2 = _gn_fwd_raw(h1, g2w, g2b, groups, eps2, 1)
@@ -587,11 +633,13 @@ class _ResBlockFn(torch.autograd.Function):
         op_a, op_b, op_r = ctx.ops
         dy = to_cl(dy)
         gb = lambda b: _grad_buffer(b) if b is not None else None
+        _conv_gate()
         d_hn = conv_dgrad(dy, op_b.pack_bwd(wb), op_b.spec, ctx.size)
         wg = _wgrad if getattr(wb, '_genie_arena', False) else conv_wgrad
         wg(hn, dy, op_b.spec, _grad_buffer(wb), gb(bb))
         d_h1 = _gn_bwd_raw(h1, d_hn, g2w, g2b, m2, r2, ctx.groups, 1)
         del d_hn
+        _conv_gate()                                           # wgrad of conv_b ran under the GroupNorm backward above
         d_xn = conv_dgrad(d_h1, op_a.pack_bwd(wa), op_a.spec, ctx.size)
         wg(xn, d_h1, op_a.spec, _grad_buffer(wa), gb(ba))
         del d_h1

@@ -169,9 +169,11 @@ class VideoTokenizer(LightningModule):
 
     def forward(self, video: Tensor, beta: float = 100., transpose: bool = True) -> Tuple[Tensor, Tuple[Tensor, ...]]:
         enc_video = self.encode(video)
-        (quant_video, idxs), quant_loss = self.quant(enc_video, beta=beta, transpose=transpose)
+        with GF.deferred_lfq_loss():                       # (side stream, when enabled: the entropy loss runs under the decoder)
+            (quant_video, idxs), quant_loss = self.quant(enc_video, beta=beta, transpose=transpose)
         rec_video = self.decode(quant_video)
         rec_loss = GF.mse_loss(rec_video, video)
+        GF.join_wgrad()
         gen_loss = self.gan_crit(rec_video, video, train_gen=True) if self.gan_loss_weight > 0 else 0
         dis_loss = self.gan_crit(rec_video, video, train_gen=False) if self.gan_loss_weight > 0 else 0
         perc_loss = self.perc_crit(rec_video, video) if self.perc_loss_weight > 0 else 0
