@@ -129,6 +129,7 @@ int genie_conv_igemm(const GenieConvDesc* desc, void* stream);
 #define GENIE_VARIANT_WGRAD_128x32 9
 #define GENIE_VARIANT_WGRAD_32x128 10
 #define GENIE_VARIANT_WGRAD3 11
+#define GENIE_VARIANT_IGEMM3_WIDE 12     /* igemm3w_kernel: 256 x 256 tile, layers with >= 256 output channels */
 int genie_last_conv_variant(void);
 
 /* Weight gradient: dW[row(n)][tap][c] += sum_m DY[dpix(m)][n'] * SRC[pix(m)*step + off_tap][c]

@@ -22,6 +22,10 @@
 //             waits are counted (s_waitcnt vmcnt(N)) so that image rounds stay in flight across the workgroup barrier
 #include "igemm_common.h"
 
+#ifndef GENIE_TRI_WIDE_DEFAULT
+#define GENIE_TRI_WIDE_DEFAULT 1          // 256 x 256 kw-triple tiles where Cout >= 256 (measured +5...9 % per layer; GENIE_TRI_WIDE=0 switches them off)
+#endif
+
 static __device__ __attribute__((aligned(256))) uint32_t g_zero_page3[64];
 
 struct Igemm3Args {
@@ -526,6 +530,233 @@ __global__ void __launch_bounds__(64 * NWAVE) igemm3d_kernel(const Igemm3Args p,
 int genie_igemm_splitk_finish(const IgemmArgs& a, hipStream_t s);      // conv_igemm.hip
 
 // ------------------------------------------------------------------------------------------------------------------------------
+// 256 x 256 tile for layers with >= 256 output channels (GENIE_TRI_WIDE=1 / tri_flags bit 10).  Per 64-deep K-tile the 256 x 128 kernel
+// above moves 13.3 KB of image + 16 KB of weights through L2 -> LDS and reads 16 fragments per 16 MFMAs; with 256 columns per block the
+// image is shared by twice the MFMAs: 13.3 + 32 KB per 2x the work (-23 % L2 -> LDS bytes per MFMA) and a 64 x 128 wave tile needs 6
+// fragment reads per 8 MFMAs instead of 4 per 4 (-25 % LDS reads).  LDS stays at 144 KB by cutting the weight tiles in half along K:
+// 256 rows x 64 B (32 channels), ring of FOUR 16-KB slots issued THREE half-tiles ahead, 64-B rows with the 4-slot XOR swizzle of
+// gemm_pw256_kernel.  Schedule (pre-read form): half-tile k = 6 i + 2 s + h uses k-steps 2h, 2h + 1 of image i at shift s;
+//   during half-tile k: read k-step 2h+1, MFMAs of k-step 2h (pre-read), issue group g(k) = image rounds of step i+1 ([2,1,1,1,0,0]
+//   over the six half-tiles) + weight half-tile k+3 (2 glds), pre-read k-step 0 of half-tile k+1, MFMAs of k-step 2h+1,
+//   s_waitcnt vmcnt(|g(k)|) -> everything issued before half-tile k has landed -> barrier publishes it.
+//   RAW: half-tile k+1's weights were issued in k-2 and published at barrier k-1, before its pre-read in k; the image of step i+1 is
+//   complete in group 6i+3, published at barrier 6i+4, pre-read in 6i+5.  WAR: slot (k+3)&3 was last read in half-tile k-1; the
+//   spare image was last read in half-tile 6i-1.
+// ------------------------------------------------------------------------------------------------------------------------------
+template <bool SPLITK>
+__global__ void __launch_bounds__(512) igemm3w_kernel(const Igemm3Args p, const GenieTriStep* __restrict__ steps) {
+    constexpr int BM = 256, BN = 256, NWAVE = 8, WN = 2, TM = 2, TN = 4;
+    constexpr int RPR = 64, A_ROUNDS = 5;
+    constexpr int A_BYTES = A_ROUNDS * RPR * 128, B_BYTES = BN * 64;        // 40 KB images, 16 KB weight half-tiles
+    constexpr int B_LOADS = 2;                                               // 16 rows x 64 B per wave instruction, 256 rows / 8 waves
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const IgemmArgs& a = p.g;
+    int nsteps = p.nsteps;
+    if (SPLITK) {
+        const int s0 = (int)blockIdx.y * a.chunks_per_split;
+        steps += s0;
+        nsteps = nsteps - s0 < a.chunks_per_split ? nsteps - s0 : a.chunks_per_split;
+    }
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int W = a.Wo, H = a.Ho, T = a.To, WP = p.WP;
+    int tile_m, tile_n;
+    {
+        const int id = xcd_tile_id(a.tiles_m * a.tiles_n, blockIdx.x);
+        tile_n = id % a.tiles_n;
+        tile_m = id / a.tiles_n;
+    }
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page3);
+
+    unsigned a_base[A_ROUNDS];
+    int a_th[A_ROUNDS];
+    const int row0_id = m0 / W;
+#pragma unroll
+    for (int i = 0; i < A_ROUNDS; ++i) {
+        const int r = i * RPR + (tid >> 3);
+        const int lc = (tid & 7) ^ ((r >> 1) & 7);
+        const int hl = r / WP, w = r - hl * WP - 1;
+        const int rowid = row0_id + hl;
+        const long long m = (long long)rowid * W + w;
+        const bool valid = r < p.img_rows && w >= 0 && w < W && m < a.M;
+        a_base[i] = valid ? (unsigned)m * (unsigned)a.Cs + lc * 8 : 0u;
+        a_th[i] = valid ? ((((rowid / H) % T) << 16) | (rowid % H)) : (int)0x80000000;
+    }
+    const bf16_t* b_ptr[B_LOADS];
+#pragma unroll
+    for (int j = 0; j < B_LOADS; ++j) {
+        const int row = (j * NWAVE + wave) * 16 + (lane >> 2);
+        const int lc = (lane & 3) ^ ((row >> 2) & 3);
+        const int n = n0 + row;
+        const int wr = n < a.Ncols ? (a.perm_f > 1 ? (n % a.perm_c) * a.perm_f + n / a.perm_c : n) : -1;
+        b_ptr[j] = wr >= 0 ? a.wgt + (size_t)wr * a.w_row_stride + lc * 8 : nullptr;
+    }
+    auto stage_a = [&](const GenieTriStep& e, bool live, int i, char* abuf) {
+        const int t = (a_th[i] >> 16) + e.dt, h = (a_th[i] & 0xffff) + e.dh;
+        const bool ok = live & ((unsigned)t < (unsigned)T) & ((unsigned)h < (unsigned)H);
+        const bf16_t* q = a.src + (int)(a_base[i] + (unsigned)e.a_delta);
+        q = ok ? q : zero;
+        __builtin_amdgcn_global_load_lds(GLB_PTR(q), LDS_PTR(abuf + (i * NWAVE + wave) * 1024), 16, 0, 0);
+    };
+    auto stage_b = [&](int wofs, bool live, char* bbuf) {                      // one 32-channel half of a weight tile
+#pragma unroll
+        for (int j = 0; j < B_LOADS; ++j) {
+            const bf16_t* q = (live && b_ptr[j]) ? b_ptr[j] + wofs : zero;
+            __builtin_amdgcn_global_load_lds(GLB_PTR(q), LDS_PTR(bbuf + (j * NWAVE + wave) * 1024), 16, 0, 0);
+        }
+    };
+
+    unsigned a_off[3][4][TM], b_off[2][TN];
+    const int khalf = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int pl = wm * (TM * 32) + i * 32 + (lane & 31);
+        const int hl = pl / W;
+        const int row0 = hl * WP + (pl - hl * W);
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int row = row0 + s;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) a_off[s][ks][i] = (unsigned)(row * 128 + (((ks * 2 + khalf) ^ ((row >> 1) & 7)) << 4));
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int row = wn * (TN * 32) + j * 32 + (lane & 31);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) b_off[ks][j] = (unsigned)(row * 64 + (((ks * 2 + khalf) ^ ((row >> 2) & 3)) << 4));
+    }
+
+    f32x16_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    char* const A0 = smem;
+    char* const B0 = smem + 2 * A_BYTES;                                      // four weight half-tile slots
+
+    auto read_frag = [&](const char* abuf, int s, int ksa, const char* bbuf, int ksb, bf16x8_t (&fa)[TM], bf16x8_t (&fb)[TN]) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8_t*>(abuf + a_off[s][ksa][i]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const bf16x8_t*>(bbuf + b_off[ksb][j]);
+    };
+    auto mfma8 = [&](const bf16x8_t (&fa)[TM], const bf16x8_t (&fb)[TN]) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    };
+    auto raw_barrier = [&]() {
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+
+    // ---- prologue: image 0, weight half-tiles 0, 1, 2 ----
+    {
+        const GenieTriStep e = steps[0];
+#pragma unroll
+        for (int i = 0; i < A_ROUNDS; ++i) stage_a(e, true, i, A0);
+        stage_b(e.wofs0, true, B0);
+        stage_b(e.wofs0 + 32, true, B0 + B_BYTES);
+        stage_b(e.wofs1, true, B0 + 2 * B_BYTES);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    raw_barrier();
+
+    bf16x8_t fa0[TM], fb0[TN];
+    read_frag(A0, 0, 0, B0, 0, fa0, fb0);
+    int k = 0;                                                                // half-tile counter; weight half-tile k sits in slot k & 3
+    for (int i = 0; i < nsteps; ++i, k += 6) {
+        const GenieTriStep cur = steps[i];
+        const bool has_next = i + 1 < nsteps;
+        const GenieTriStep nxt = steps[has_next ? i + 1 : i];
+        char* const acur = A0 + (i & 1) * A_BYTES;
+        char* const anxt = A0 + ((i + 1) & 1) * A_BYTES;
+        // half-tile R (0..5) of this step: shift S = R / 2, channel half HH = R % 2.  NEXT_* = where half-tile R + 1 reads its first k-step.
+        // ISSUE = the DMA group of this half-tile (image rounds of step i + 1, then weight half-tile k + R + 3); WAITN = its size.
+#define GENIE_HTILE(R, S, HH, ISSUE, NEXT_A, NEXT_S, NEXT_KS, WAITN)                                              \
+        {                                                                                                        \
+            const char* bcur = B0 + ((k + R) & 3) * B_BYTES;                                                     \
+            const char* bnext = B0 + ((k + R + 1) & 3) * B_BYTES;                                                \
+            bf16x8_t fa1[TM], fb1[TN];                                                                           \
+            read_frag(acur, S, 2 * HH + 1, bcur, 1, fa1, fb1);                                                   \
+            mfma8(fa0, fb0);                                                                                     \
+            __builtin_amdgcn_sched_barrier(0);                                                                   \
+            ISSUE                                                                                                \
+            __builtin_amdgcn_sched_barrier(0);                                                                   \
+            read_frag(NEXT_A, NEXT_S, NEXT_KS, bnext, 0, fa0, fb0);                                              \
+            mfma8(fa1, fb1);                                                                                     \
+            __builtin_amdgcn_sched_barrier(0);                                                                   \
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WAITN) : "memory");                                        \
+            raw_barrier();                                                                                       \
+        }
+        // weight half-tile k + R + 3: (step, shift, half) of half-tile index R + 3 -> R = 0: (cur, s1, h1); 1: (cur, s2, h0); 2: (cur, s2, h1);
+        //                                                                      3: (nxt, s0, h0); 4: (nxt, s0, h1); 5: (nxt, s1, h0)
+        GENIE_HTILE(0, 0, 0,
+                    stage_a(nxt, has_next, 0, anxt); stage_a(nxt, has_next, 1, anxt);
+                    __builtin_amdgcn_sched_barrier(0);
+                    stage_b(cur.wofs1 + 32, true, B0 + ((k + 3) & 3) * B_BYTES);,
+                    acur, 0, 2, 4)
+        GENIE_HTILE(1, 0, 1,
+                    stage_a(nxt, has_next, 2, anxt);
+                    __builtin_amdgcn_sched_barrier(0);
+                    stage_b(cur.wofs2, true, B0 + ((k + 4) & 3) * B_BYTES);,
+                    acur, 1, 0, 3)
+        GENIE_HTILE(2, 1, 0,
+                    stage_a(nxt, has_next, 3, anxt);
+                    __builtin_amdgcn_sched_barrier(0);
+                    stage_b(cur.wofs2 + 32, true, B0 + ((k + 5) & 3) * B_BYTES);,
+                    acur, 1, 2, 3)
+        GENIE_HTILE(3, 1, 1,
+                    stage_a(nxt, has_next, 4, anxt);
+                    __builtin_amdgcn_sched_barrier(0);
+                    stage_b(nxt.wofs0, has_next, B0 + ((k + 6) & 3) * B_BYTES);,
+                    acur, 2, 0, 3)
+        GENIE_HTILE(4, 2, 0,
+                    stage_b(nxt.wofs0 + 32, has_next, B0 + ((k + 7) & 3) * B_BYTES);,
+                    acur, 2, 2, 2)
+        GENIE_HTILE(5, 2, 1,
+                    stage_b(nxt.wofs1, has_next, B0 + ((k + 8) & 3) * B_BYTES);,
+                    anxt, 0, 0, 2)
+#undef GENIE_HTILE
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    raw_barrier();
+
+    if (SPLITK) {
+        igemm_store_partials<TM, TN>(a, acc, blockIdx.y, m0, n0, wm, wn, lane);
+        return;
+    }
+    igemm_epilogue<BM, TM, TN>(a, acc, smem, m0, n0, wm, wn, tid, lane);
+}
+
+template <bool SPLITK>
+static int launch_igemm3w(const Igemm3Args& p, const GenieTriStep* steps, hipStream_t s) {
+    constexpr int lds = 2 * (5 * 64 * 128) + 4 * 256 * 64;
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute((const void*)igemm3w_kernel<SPLITK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) {
+            genie_set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return GENIE_ERR_HIP;
+        }
+        configured = true;
+    }
+    hipLaunchKernelGGL((igemm3w_kernel<SPLITK>), dim3(p.g.tiles_m * p.g.tiles_n, SPLITK ? p.g.split_k : 1), dim3(512), lds, s, p, steps);
+    GENIE_CHECK_LAUNCH();
+    if (SPLITK) return genie_igemm_splitk_finish(p.g, s);
+    return GENIE_OK;
+}
+
+
+
+// ------------------------------------------------------------------------------------------------------------------------------
 // Persistent form of igemm3d_kernel<true, false>: one block per CU walks its tiles and the K-tile stream of the schedule above
 // runs straight through tile boundaries -- during the LAST step of a tile the image and the three weight tiles of the next
 // tile's first step are issued (loader state = row addresses / coordinates / weight rows of the tile being LOADED, switched at
@@ -855,6 +1086,14 @@ int genie_conv_igemm3_try(const GenieConvDesc* d, IgemmArgs a, hipStream_t s) {
     static const int xcdcol_env = getenv("GENIE_TRI_XCDCOL") ? atoi(getenv("GENIE_TRI_XCDCOL")) : 0;
     p.xcdcol = (((d->tri_flags & 512) || xcdcol_env) && bm == 256 && (tiles_n == 2 || tiles_n == 4 || tiles_n == 8)) ? 1 : 0;
     const bool pipe = (d->tri_flags & 1) == 0;
+    // bit 10 / GENIE_TRI_WIDE=1: 256 x 256 tiles where the layer has >= 256 output channels and still >= one block per CU
+    static const int wide_env = getenv("GENIE_TRI_WIDE") ? atoi(getenv("GENIE_TRI_WIDE")) : GENIE_TRI_WIDE_DEFAULT;
+    if (((d->tri_flags & 1024) || wide_env) && bm == 256 && split == 1 && a.Nstore >= 256 && p.dbg == 0 && (d->tri_flags & (1 | 2 | 64 | 128 | 256)) == 0 &&
+        ((long long)p.g.tiles_m * cdiv(a.Nstore, 256) >= 256 || (d->tri_flags & 2048))) {      // bit 11: even with few tiles (tests)
+        p.g.tiles_n = cdiv(a.Nstore, 256);
+        genie_note_variant(GENIE_VARIANT_IGEMM3_WIDE);
+        return launch_igemm3w<false>(p, d->tri_steps, s);
+    }
     genie_note_variant(split > 1 ? GENIE_VARIANT_IGEMM3_256_SPLITK : (bm == 256 ? GENIE_VARIANT_IGEMM3_256 : GENIE_VARIANT_IGEMM3_128));
     if (bm == 256 && (d->tri_flags & 2) == 0) {                                                // deep-prefetch schedules
         // bit 7: the persistent form.  Measured A/B on one box (B = 8 step): the kernel itself +1 % (1117 -> 1128 TFLOP/s averaged over

@@ -609,3 +609,47 @@ def test_conv_narrow_in_kernel(G, cin, causal, size):
         G.conv.PROFILER = None
     assert 'conv_narrow_in_kernel' in prof.summary(), list(prof.summary())
     assert_close_bf16(x2c.grad, x2.grad, 'narrow conv dgrad')
+
+
+WIDE_CASES = [
+    # cin, cout, kernel, causal, size, residual epilogue
+    (64, 256, (3, 3, 3), False, (2, 4, 8, 8), False),
+    (128, 512, (3, 3, 3), True, (1, 3, 16, 16), True),
+    (64, 320, (3, 3, 3), False, (1, 2, 32, 32), False),       # two column tiles, the second 64 wide
+    (192, 256, (3, 1, 3), True, (2, 3, 4, 16), False),        # three channel blocks
+    (128, 256, (3, 3, 3), False, (3, 1, 5, 8), True),         # M = 120: partial row tile
+    (256, 256, (3, 3, 3), False, (2, 8, 16, 16), False),      # 16 row tiles, 4 channel blocks
+]
+
+
+@pytest.mark.parametrize('cin,cout,kernel,causal,size,resid', WIDE_CASES)
+def test_conv_triple_wide_kernel(G, cin, cout, kernel, causal, size, resid, monkeypatch):
+    """igemm3w_kernel (256 x 256 tile, 32-channel weight half-tiles): forward (with and without the residual epilogue) and
+    backward-data against the oracle; the library must report that the wide kernel ran (variant 12)."""
+    monkeypatch.setattr(G.conv, 'TRI_BM', 256)
+    monkeypatch.setattr(G.conv, 'TRI_FLAGS', 1024 | 2048)
+    torch.manual_seed(13)
+    n, t, h, w = size
+    x = bf16_round(torch.randn(n, cin, t, h, w))
+    wt = bf16_round(torch.randn(cout, cin, *kernel) / (cin * kernel[0] * kernel[1] * kernel[2]) ** 0.5)
+    b = torch.randn(cout)
+    xr = x.clone().requires_grad_(True)
+    if causal:
+        from oracle import genie_oracle as O
+        ref = O.causal_conv3d(xr, wt, b, stride=(1, 1, 1))
+        spec = G.conv.causal_spec(cin, cout, kernel)
+    else:
+        ref = F.conv3d(xr, wt, b, padding=tuple((k - 1) // 2 for k in kernel))
+        spec = G.conv.same_spec(cin, cout, kernel)
+    dy = bf16_round(torch.randn_like(ref))
+    ref.backward(dy)
+    wd = wt.cuda()
+    lib = G.hip.load_library()
+    r = bf16_round(torch.randn_like(ref)) if resid else None
+    out = G.conv.conv_forward(G.cl.to_cl(x.cuda()), G.conv.pack_weight_fwd(wd, spec), b.cuda(), spec, resid=None if r is None else G.cl.to_cl(r.cuda()))
+    assert lib.genie_last_conv_variant() == 12, lib.genie_last_conv_variant()
+    assert_close_bf16(out, ref.detach() + (r if resid else 0), 'wide triple fwd')
+    if cin >= 256:                                            # backward-data = the same kernel over dy with cin output columns
+        dx = G.conv.conv_dgrad(G.cl.to_cl(dy.cuda()), G.conv.pack_weight_bwd(wd, spec), spec, (t, h, w))
+        assert lib.genie_last_conv_variant() == 12, lib.genie_last_conv_variant()
+        assert_close_bf16(dx, xr.grad, 'wide triple dgrad')
