@@ -49,7 +49,7 @@ for sub, counter in (('fetch', 'FETCH_SIZE'), ('write', 'WRITE_SIZE')):
 # /opt/skills/guides/MI355X_MICROARCH.md (HBM section) prescribes for gfx950: the counters are in KB; FETCH_SIZE reports half of
 # the bytes of 16-B/lane streaming reads (x2); WRITE_SIZE is used as reported (calibrated here on the AdamW kernel: 16 B/param
 # read, 16 B/param written incl. the gradient clear -> FETCH x 2 = 6.0 GB, WRITE = 6.0 GB for 375.6 M parameters).
-NAMES = {'igemm3d_kernel<true, false>': 'igemm3_kernel<256>', 'igemm3d_kernel<true, true>': 'igemm3_kernel<256,splitk>', 'igemm3_kernel<128': 'igemm3_kernel<128>', 'wgrad3_kernel': 'wgrad3_kernel',
+NAMES = {'igemm3w_kernel<false>': 'igemm3_kernel<256x256>', 'igemm3d_kernel<true, false': 'igemm3_kernel<256>', 'igemm3d_kernel<true, true': 'igemm3_kernel<256,splitk>', 'igemm3_kernel<128': 'igemm3_kernel<128>', 'wgrad3_kernel': 'wgrad3_kernel',
          'igemm_kernel<128, 2, 2, false>': 'igemm_kernel<128,generic>', 'wgrad_kernel<128, 128': 'wgrad_kernel<128,128>',
          'adamw_kernel': 'adamw_kernel'}
 traffic = {}
@@ -60,7 +60,7 @@ for rk, bk in NAMES.items():
         traffic[bk] = {'bytes_per_launch': round(f['per_dispatch'] * 1024 * 2 + w['per_dispatch'] * 1024),
                        'fetch_bytes': round(f['per_dispatch'] * 1024 * 2), 'write_bytes': round(w['per_dispatch'] * 1024),
                        'dispatches': f['dispatches'],
-                       'source': f'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of bench.py --batch 8, profiles/{tag}_summary.json; '
+                       'source': f'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of bench.py (same batch), profiles/{tag}_summary.json; '
                                  'FETCH_SIZE x 2 (gfx950 correction), KB -> bytes'}
 summary['traffic'] = traffic
 
