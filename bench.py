@@ -134,6 +134,7 @@ def main():
     ap.add_argument('--no-kernel-events', action='store_true')
     ap.add_argument('--all-kernel-events', action='store_true', help='HIP events around EVERY conv launch (full conv_kernels table; costs ~4 %% of the step)')
     ap.add_argument('--dump', type=str, default='')
+    ap.add_argument('--no-in-order-pass', action='store_true', help='skip the three extra in-order steps behind roofline_in_order (rocprofv3 runs: keeps every launch of the trace in the timed regime)')
     ap.add_argument('--grad-compress', choices=['none', 'bf16'], default=os.environ.get('GENIE_GRAD_COMPRESS', 'none'),
                     help='gradient all-reduce payload: fp32 (exact, default) or bf16 (half the xGMI bytes)')
     ap.add_argument('--async-wgrad', type=int, default=int(os.environ.get('GENIE_ASYNC_WGRAD', 2)),
@@ -215,7 +216,7 @@ def main():
     # concurrent weight-gradient kernel took.  Three more steps, OUTSIDE the timed region, with everything in order give the same
     # kernels' own rate next to it (`roofline_in_order`); `value` and `roofline` come from the timed region only.
     prof_inorder = None
-    if prof is not None and GF.ASYNC_WGRAD and world == 1:
+    if prof is not None and GF.ASYNC_WGRAD and world == 1 and not args.no_in_order_pass:
         GF.join_wgrad()
         GF.ASYNC_WGRAD = 0
         step(args.warmup + args.steps)
