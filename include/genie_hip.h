@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GENIE_ABI_VERSION 5
+#define GENIE_ABI_VERSION 6
 
 #define GENIE_F32 0
 #define GENIE_BF16 1
@@ -266,6 +266,12 @@ int genie_maskgit_paint(const float* conf, const int64_t* pred, int64_t batch, i
  * ------------------------------------------------------------------------------------------- */
 int genie_conv_narrow_in(const void* src_cl, int src_pitch, const void* wpack, void* dst_cl, int dst_pitch, int N, int T, int H, int W,
                          int t_lo, void* stream);
+/* The other direction: 128 input channels -> cout <= 3 output channels (the head conv CausalConv3d(128 -> 3) forward, tokenizer.py:172).
+ * src: CL [N][T][H][W][128]; dst: CL [N][T][H][W][8] (whole 16-byte pixels are written, channels >= cout zero); bias fp32 [cout] or NULL.
+ * wpack: bf16 [16][1152], row = 4 * (dt - t_lo) + co (every other row zero), k = ((dh + 1) * 3 + (dw + 1)) * 128 + ci.  t_lo in [-2, 0];
+ * W a multiple of 32, H * W * 256 < 2^32. */
+int genie_conv_narrow_out(const void* src_cl, const void* wpack, const float* bias, void* dst_cl, int N, int T, int H, int W, int cout,
+                          int t_lo, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Losses and optimiser (elementwise.hip).

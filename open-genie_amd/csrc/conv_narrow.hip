@@ -20,6 +20,8 @@
 
 namespace {
 
+__device__ __attribute__((aligned(256))) uint32_t g_zero_page_n[64];
+
 constexpr int NIN_HB = 4;                  // image rows per workgroup (one per wave)
 constexpr int NIN_KSTEPS = 7;              // 112 = 27 taps x 4 channels + bias hi/lo + 2 zero slots
 constexpr int NIN_KP = 16 * NIN_KSTEPS;    // row pitch of the weight pack [128][112]
@@ -131,6 +133,218 @@ __global__ void __launch_bounds__(256, 2) conv_narrow_in_kernel(const NarrowInAr
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// The other direction: 128 input channels -> <= 3 output channels, 3x3x3, stride 1 -- the forward of the decoder's head conv
+// CausalConv3d(128 -> 3) (tokenizer.py:172).  16.8 MB in, 0.39 MB out per clip: the roofline is the INPUT stream.
+//
+// A 3-column GEMM wastes a 32-wide MFMA tile ten times over.  Here the product is transposed and only the frame taps stay apart:
+//     C[(dt, co)][q] = sum_{dh, dw, ci} W[co][(dt, dh, dw)][ci] * X[tin][q + (dh - 1, dw - 1)][ci]      (K = 9 * 128 = 1152, 36 k-steps of 32)
+// is formed with v_mfma_f32_16x16x32_bf16 for 16 output pixels q of one image row and ONE input frame tin: 9 of the 16 rows are
+// used (row = 4 dt + co), the weights are the A operand and live in registers for the whole launch (36 x 4 VGPRs).  out[t] is the
+// sum of C_{t + t_lo + dt}[dt] over three consecutive input frames.  In the 16x16 C layout row block dt is lane group dt (lanes
+// 16 dt .. 16 dt + 15, registers = co), so that sum is carried in the accumulator itself: after each input frame lane group 2
+// holds a finished output frame (converted, bias added and stored as whole 16-byte pixels straight from registers), and the
+// partial sums move one lane group up (ds_bpermute, 8 per frame) to be the C input of the next frame's MFMAs.  No scatter, no
+// atomics (an earlier input-stationary version spent 3/4 of its time in ds_add_f32), no fp32 staging.
+// One workgroup = 4 waves = 4 image rows x 32 columns of one sample, marching over the frames of its segment; the input tile of a
+// frame (6 rows x 34 pixels x 256 B, 16-byte chunks XOR-swizzled by pixel so the 256-B-strided fragment reads are conflict-free)
+// is shared by the waves and arrives by LDS-DMA two frames ahead (3 buffers, counted waits, one s_barrier per frame); pixels
+// outside the image or the clip are fetched from a zero page, so there are no masks in the inner loop.
+// ------------------------------------------------------------------------------------------------------------------------------
+constexpr int NOUT_KSTEPS = 36;
+constexpr int NOUT_ROWPIX = 34;                         // 32 columns + 2 halo
+constexpr int NOUT_PIECES = 13;                         // DMA pieces (4 pixels x 256 B) per wave and frame: 4 x 13 x 4 = 208 >= 6 x 34 pixels
+constexpr int NOUT_BUF_BYTES = 4 * NOUT_PIECES * 1024;  // 53248
+constexpr int NOUT_NBUF = 3;
+constexpr int NOUT_WROW = 1152;                         // weight pack [16][1152]
+
+__device__ __forceinline__ unsigned nout_lds_offset(const void* p) {
+    return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+__device__ __forceinline__ bf16x8_t nout_read128(unsigned lds_addr) {
+    bf16x8_t v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(lds_addr));
+    return v;
+}
+__device__ __forceinline__ bf16x8_t nout_read128_hi(unsigned lds_addr) {      // the second 16-column half: + 16 pixels
+    bf16x8_t v;
+    asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(v) : "v"(lds_addr));
+    return v;
+}
+
+struct NarrowOutArgs {
+    const bf16_t* src;      // CL [N][T][H][W][128]
+    const bf16_t* wpack;    // [16][1152]: row = 4 dt + co (other rows zero), k = (dh * 3 + dw) * 128 + ci
+    const float* bias;      // [3] or null
+    bf16_t* dst;            // CL [N][T][H][W][8]
+    int N, T, H, W, cout;
+    int t_lo;               // out[t] reads input frames t + t_lo .. t + t_lo + 2
+    int hblocks, wblocks, tsegs, tseg_len;
+};
+
+__global__ void __launch_bounds__(256) conv_narrow_out_kernel(const NarrowOutArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 15, kg = lane >> 4;
+    const int W = a.W, H = a.H;
+    const unsigned lds0 = nout_lds_offset(smem);
+
+    int b = blockIdx.x;
+    const int seg = b % a.tsegs; b /= a.tsegs;
+    const int wb = b % a.wblocks; b /= a.wblocks;
+    const int hb = b % a.hblocks;
+    const int n = b / a.hblocks;
+    const int h0 = hb * 4, w0 = wb * 32;
+    const int h = h0 + wave;
+    const bool row_ok = h < H;                                                 // wave-uniform
+    const int ts0 = seg * a.tseg_len, ts1 = (ts0 + a.tseg_len < a.T) ? ts0 + a.tseg_len : a.T;      // output frames of this workgroup
+    const int nf = ts1 - ts0 + 2;                                              // input frames tin = ts0 + t_lo + f, f = 0 .. nf - 1
+    const int tin_first = ts0 + a.t_lo;
+
+    // weights: A fragments, row = lane & 15, k = 32 ks + 8 kg .. + 7
+    bf16x8_t wf[NOUT_KSTEPS];
+#pragma unroll
+    for (int ks = 0; ks < NOUT_KSTEPS; ++ks) wf[ks] = *reinterpret_cast<const bf16x8_t*>(a.wpack + col * NOUT_WROW + 32 * ks + 8 * kg);
+    float bias_r[3] = {0.f, 0.f, 0.f};
+    if (a.bias) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) if (c < a.cout) bias_r[c] = a.bias[c];
+    }
+    // pin the completion of these loads HERE: hipcc would otherwise wait for them at their first uses inside the frame loop with
+    // counted vmcnt(N) that also count (and drain) the inline-asm DMA stream
+#pragma unroll
+    for (int c = 0; c < 3; ++c) asm volatile("" : "+v"(bias_r[c]));
+#pragma unroll
+    for (int ks = 0; ks < NOUT_KSTEPS; ++ks) asm volatile("" : "+v"(wf[ks]));
+
+    // ---- lane constants ----
+    // DMA piece P = wave + 4 i covers tile pixels 4 P .. 4 P + 3 (pixel q = row * 34 + column, 6 rows: image rows h0 - 1 .. h0 + 4,
+    // columns w0 - 1 .. w0 + 32); lane -> pixel q = 4 P + kg, LDS slot col holds the source chunk col ^ (q & 15)
+    unsigned dma_off[NOUT_PIECES];                                             // byte offset inside the input frame, or ~0u: zero page
+#pragma unroll
+    for (int i = 0; i < NOUT_PIECES; ++i) {
+        const int q = 4 * (wave + 4 * i) + kg;
+        const int rr = q / NOUT_ROWPIX, cc = q - rr * NOUT_ROWPIX;
+        const int hin = h0 - 1 + rr, w = w0 - 1 + cc;
+        const bool ok = rr < 6 && hin >= 0 && hin < H && w >= 0 && w < W;
+        dma_off[i] = ok ? (unsigned)((hin * W + w) * 256 + ((col ^ (q & 15)) << 4)) : 0xffffffffu;
+    }
+    const char* const zero_ptr = reinterpret_cast<const char*>(g_zero_page_n) + col * 16;
+    // fragment reads: B operand column = output pixel col (+ 16 for the second half), k-group kg; tap (dh, dw) reads tile pixel
+    // q = (wave + dh) * 34 + col + dw, chunk (4 j + kg) ^ (q & 15) for the k-step j = 0..3 inside the tap
+    unsigned rd_base[9];
+#pragma unroll
+    for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+        for (int dw = 0; dw < 3; ++dw) {
+            const int q = (wave + dh) * NOUT_ROWPIX + col + dw;
+            rd_base[dh * 3 + dw] = (unsigned)(q * 256 + ((kg ^ (q & 15)) << 4));
+        }
+    const unsigned perm_addr = (unsigned)(((lane - 16) & 63) * 4);
+
+    auto issue_frame = [&](int f) {
+        const int tin = tin_first + f;
+        const bool fv = f < nf && tin >= 0 && tin < a.T;                       // wave-uniform
+        const char* base = reinterpret_cast<const char*>(a.src) + (((long long)n * a.T + (fv ? tin : 0)) * H * W) * 256;
+        const unsigned buf = lds0 + (unsigned)(f % NOUT_NBUF) * NOUT_BUF_BYTES + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < NOUT_PIECES; ++i) {
+            const char* p = (fv && dma_off[i] != 0xffffffffu) ? base + dma_off[i] : zero_ptr;
+            const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(buf + i * 4096));
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(p), "s"(dst) : "memory", "m0");
+        }
+    };
+
+    issue_frame(0);
+    issue_frame(1);
+    f32x4_t acc[2];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) acc[hf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    u32x4_t pend[2] = {u32x4_t{0u, 0u, 0u, 0u}, u32x4_t{0u, 0u, 0u, 0u}};
+    int pend_t = -1;
+    auto flush = [&]() {
+        if (pend_t >= 0 && kg == 2) {
+            bf16_t* o = a.dst + ((((long long)n * a.T + pend_t) * H + h) * W + w0 + col) * 8;
+            *reinterpret_cast<u32x4_t*>(o) = pend[0];
+            *reinterpret_cast<u32x4_t*>(o + 128) = pend[1];
+        }
+        pend_t = -1;
+    };
+
+    for (int f = 0; f < nf; ++f) {
+        asm volatile("s_waitcnt vmcnt(13)" ::: "memory");                     // this wave's pieces of frame f landed (frame f + 1 stays in flight)
+        __builtin_amdgcn_s_barrier();                                          // ... and everyone's; everyone is done with frame f - 1
+        asm volatile("" ::: "memory");
+        flush();                                                               // stores go out BEFORE the next DMA batch: the counted wait above
+        issue_frame(f + 2);                                                    // then covers exactly one batch (into the buffer frame f - 1 left)
+        const int tin = tin_first + f;
+        if (row_ok && tin >= 0 && tin < a.T) {
+            const unsigned buf = lds0 + (unsigned)(f % NOUT_NBUF) * NOUT_BUF_BYTES;
+            // Fragment reads are inline asm: hipcc orders a compiler-visible LDS access behind EVERY outstanding LDS-DMA (vmcnt(0)),
+            // which would drain the prefetch once per frame.  Groups of four reads (two k-steps x two halves), one group ahead.
+            bf16x8_t xg[2][4];
+            auto read_group = [&](int g, bf16x8_t* x) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int ks = 2 * g + q;
+                    const unsigned ad = buf + (rd_base[ks >> 2] ^ (unsigned)((ks & 3) << 6));
+                    x[2 * q] = nout_read128(ad);
+                    x[2 * q + 1] = nout_read128_hi(ad);
+                }
+            };
+            read_group(0, xg[0]);
+#pragma unroll
+            for (int g = 0; g < NOUT_KSTEPS / 2; ++g) {
+                if (g + 1 < NOUT_KSTEPS / 2) {
+                    read_group(g + 1, xg[(g + 1) & 1]);
+                    asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+                asm volatile("" : "+v"(xg[g & 1][0]), "+v"(xg[g & 1][1]), "+v"(xg[g & 1][2]), "+v"(xg[g & 1][3]));
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[2 * g + q], xg[g & 1][2 * q], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[2 * g + q], xg[g & 1][2 * q + 1], acc[1], 0, 0, 0);
+                }
+            }
+        }
+        // lane group 2 now holds out[ts0 + f - 2] (its dt = 2 term was the last one): park it for the store after the next barrier
+        if (f >= 2 && row_ok) {
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                float o[8] = {acc[hf][0] + bias_r[0], acc[hf][1] + bias_r[1], acc[hf][2] + bias_r[2], 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int c = 0; c < 3; ++c) if (c >= a.cout) o[c] = 0.f;
+                pend[hf] = pack8(o);
+            }
+            pend_t = ts0 + f - 2;
+        }
+        // partial sums move one lane group up: dt -> dt + 1 for the next input frame; group 0 starts a new output frame
+        asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");                      // MFMA results -> inline-asm reader: explicit wait states
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v;
+                asm volatile("ds_bpermute_b32 %0, %1, %2" : "=v"(v) : "v"(perm_addr), "v"(acc[hf][r]));
+                acc[hf][r] = v;
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                asm volatile("" : "+v"(acc[hf][r]));
+                if (kg == 0) acc[hf][r] = 0.f;
+            }
+    }
+    flush();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 }  // namespace
 
 extern "C" int genie_conv_narrow_in(const void* src_cl, int src_pitch, const void* wpack, void* dst_cl, int dst_pitch, int N, int T, int H, int W,
@@ -158,6 +372,38 @@ extern "C" int genie_conv_narrow_in(const void* src_cl, int src_pitch, const voi
     else if (W == 64) GENIE_NIN(64);
     else GENIE_NIN(128);
 #undef GENIE_NIN
+    GENIE_CHECK_LAUNCH();
+    return GENIE_OK;
+}
+
+extern "C" int genie_conv_narrow_out(const void* src_cl, const void* wpack, const float* bias, void* dst_cl, int N, int T, int H, int W, int cout,
+                                     int t_lo, void* stream) {
+    GENIE_CHECK_ARG(src_cl && wpack && dst_cl, "genie_conv_narrow_out: null pointer");
+    GENIE_CHECK_ARG(W >= 32 && W % 32 == 0, "genie_conv_narrow_out: image width %d is not a multiple of 32", W);
+    GENIE_CHECK_ARG(cout >= 1 && cout <= 3 && t_lo >= -2 && t_lo <= 0, "genie_conv_narrow_out: cout %d (1..3) / t_lo %d (-2..0)", cout, t_lo);
+    GENIE_CHECK_ARG(N >= 1 && T >= 1 && H >= 1, "genie_conv_narrow_out: bad geometry");
+    GENIE_CHECK_ARG((long long)H * W * 256 < (1ll << 32), "genie_conv_narrow_out: frame of %d x %d pixels exceeds the 32-bit in-frame offset", H, W);
+    NarrowOutArgs a;
+    a.src = (const bf16_t*)src_cl; a.wpack = (const bf16_t*)wpack; a.bias = bias; a.dst = (bf16_t*)dst_cl;
+    a.N = N; a.T = T; a.H = H; a.W = W; a.cout = cout; a.t_lo = t_lo;
+    a.hblocks = (H + 3) / 4;
+    a.wblocks = W / 32;
+    // every frame segment re-reads two input frames: split time only while the chip is not yet filled twice over
+    int tsegs = 1;
+    while ((long long)N * a.hblocks * a.wblocks * tsegs < 512 && (T + tsegs) / (tsegs + 1) >= 4) ++tsegs;
+    a.tseg_len = (T + tsegs - 1) / tsegs;
+    a.tsegs = (T + a.tseg_len - 1) / a.tseg_len;
+    const long long blocks = (long long)N * a.hblocks * a.wblocks * a.tsegs;
+    GENIE_CHECK_ARG(blocks < (1ll << 31), "genie_conv_narrow_out: too many workgroups");
+    const int lds = NOUT_NBUF * NOUT_BUF_BYTES;
+    hipStream_t s = (hipStream_t)stream;
+    static bool configured = false;
+    if (!configured) {
+        GENIE_CHECK_ARG(hipFuncSetAttribute((const void*)conv_narrow_out_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess,
+                        "hipFuncSetAttribute failed");
+        configured = true;
+    }
+    conv_narrow_out_kernel<<<(unsigned)blocks, 256, lds, s>>>(a);
     GENIE_CHECK_LAUNCH();
     return GENIE_OK;
 }

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('GENIE_HIP_LIB', os.path.join(os.path.dirname(_HERE), 'lib', 'libgenie_hip.so'))
 
 GENIE_F32, GENIE_BF16 = 0, 1
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class GenieTap(C.Structure):
@@ -69,6 +69,7 @@ SIGNATURES = {
     'genie_from_channels_last': (C.c_int, [_P, _I, _PL, _P, _I, _PL, _P]),
     'genie_conv_igemm': (C.c_int, [C.POINTER(GenieConvDesc), _P]),
     'genie_conv_narrow_in': (C.c_int, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    'genie_conv_narrow_out': (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     'genie_conv_wgrad': (C.c_int, [C.POINTER(GenieWgradDesc), _P]),
     'genie_last_conv_variant': (C.c_int, []),
     'genie_pack_weight': (C.c_int, [_P, _P, _I, _I, _I, _L, _L, _L, _I, _I, _P]),

@@ -324,6 +324,34 @@ def pack_narrow_bwd(weight: Tensor) -> Tensor:
     return _narrow_pack(w, None)
 
 
+def narrow_out_ok(spec: ConvSpec, x: Tensor) -> bool:
+    """Forward of a 128 -> (<= 3) channel conv on the narrow-output kernel (the tokenizer's head conv)?"""
+    return (NARROW_CONV and spec.cin == 128 and spec.cout <= 3 and _narrow_geometry_ok(spec) and x.shape[4] % 32 == 0 and pitch_of(x) == 128
+            and 0 <= spec.pad_front[0] <= 2 and x.shape[3] * x.shape[4] * 256 < 2 ** 32)
+
+
+def pack_narrow_out(weight: Tensor) -> Tensor:
+    """weight (cout <= 3, 128, 3, 3, 3) -> bf16 [16][1152]: row = 4 * dt + co, k = (dh * 3 + dw) * 128 + ci (every other row zero)."""
+    co = weight.shape[0]
+    w = weight.detach().float().permute(2, 0, 3, 4, 1)                      # (dt, co, dh, dw, ci)
+    pack = torch.zeros((4, 4, 1152), dtype=torch.float32, device=weight.device)
+    pack[:3, :co] = w.reshape(3, co, 1152)
+    return pack.reshape(16, 1152).to(torch.bfloat16).contiguous()
+
+
+def conv_narrow_out(x: Tensor, pack: Tensor, bias: Optional[Tensor], cout: int, t_lo: int, label: str = '') -> Tensor:
+    """x: CL (N, 128, T, H, W); returns CL (N, cout <= 3, T, H, W)."""
+    n, c, t, h, w = x.shape
+    out = empty_cl(n, cout, t, h, w, x.device, zero_pad=False)           # the kernel writes whole 8-channel pixels (pad channels zero)
+    b32 = None if bias is None else bias.detach().float().contiguous()
+    t0 = PROFILER.begin() if PROFILER is not None and not PROFILER.only_triple else None
+    _hip.check(_hip.load_library().genie_conv_narrow_out(x.data_ptr(), pack.data_ptr(), _hip.ptr(b32), out.data_ptr(), n, t, h, w, cout, int(t_lo),
+                                                         _hip.stream_ptr()), 'genie_conv_narrow_out')
+    if t0 is not None:
+        PROFILER.end('conv_narrow_out_kernel', label, 2.0 * n * t * h * w * 128 * cout * 27, t0)
+    return out
+
+
 def conv_narrow_in(x: Tensor, pack: Tensor, t_lo: int, label: str = '') -> Tensor:
     """x: CL (N, c <= 4, T, H, W); returns CL (N, 128, T, H, W) = sum over the 27 taps (dt in t_lo .. t_lo + 2, dh, dw in -1 .. 1)."""
     n, c, t, h, w = x.shape

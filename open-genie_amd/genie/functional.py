@@ -165,6 +165,14 @@ class ConvOp:
             setattr(self, slot, cur)
         return cur[1]
 
+    def pack_narrow_out(self, weight: Tensor) -> Tensor:
+        key = (weight._version, weight.data_ptr())
+        cur = getattr(self, '_nout', (None, None))
+        if cur[0] != key:
+            cur = (key, _conv.pack_narrow_out(weight))
+            self._nout = cur
+        return cur[1]
+
 
 class _Conv3dFn(torch.autograd.Function):
     @staticmethod
@@ -172,6 +180,8 @@ class _Conv3dFn(torch.autograd.Function):
         _conv_gate()
         if resid is None and _conv.narrow_fwd_ok(op.spec, x):
             out = _conv.conv_narrow_in(x, op.pack_narrow(weight, bias, False), -op.spec.pad_front[0], f'fwd {op.spec.cin}->128 k3 @{tuple(x.shape[2:])}')
+        elif resid is None and _conv.narrow_out_ok(op.spec, x):
+            out = _conv.conv_narrow_out(x, op.pack_narrow_out(weight), bias, op.spec.cout, -op.spec.pad_front[0], f'fwd 128->{op.spec.cout} k3 @{tuple(x.shape[2:])}')
         else:
             out = conv_forward(x, op.pack_fwd(weight), bias, op.spec, resid=resid)
         ctx.op = op

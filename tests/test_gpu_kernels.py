@@ -653,3 +653,37 @@ def test_conv_triple_wide_kernel(G, cin, cout, kernel, causal, size, resid, monk
         dx = G.conv.conv_dgrad(G.cl.to_cl(dy.cuda()), G.conv.pack_weight_bwd(wd, spec), spec, (t, h, w))
         assert lib.genie_last_conv_variant() == 12, lib.genie_last_conv_variant()
         assert_close_bf16(dx, xr.grad, 'wide triple dgrad')
+
+
+@pytest.mark.parametrize('cout,causal,size', [(3, True, (2, 5, 10, 64)), (3, False, (1, 3, 7, 32)), (2, True, (1, 2, 4, 128)), (1, True, (2, 4, 9, 64)),
+                                               (3, True, (8, 16, 64, 64)), (3, True, (1, 16, 64, 64)), (3, True, (32, 3, 8, 32)), (3, True, (1, 1, 3, 96)), (3, False, (1, 9, 6, 32))])
+def test_conv_narrow_out_kernel(G, cout, causal, size):
+    """conv_narrow.hip, 128 -> <= 3 channels (the head conv's forward): transposed 16x16x32 MFMA with the frame taps summed in the accumulator across
+    input frames, against the oracle and against the generic kernel, over row strips / column blocks / frame segments / partial strips."""
+    from genie import functional as GF
+    torch.manual_seed(19)
+    n, t, h, w = size
+    kernel = (3, 3, 3)
+    x = bf16_round(torch.randn(n, 128, t, h, w))
+    wt = bf16_round(torch.randn(cout, 128, *kernel) / (128 * 27) ** 0.5)
+    b = torch.randn(cout)
+    spec = G.conv.causal_spec(128, cout, kernel) if causal else G.conv.same_spec(128, cout, kernel)
+    xc = G.cl.to_cl(x.cuda())
+    assert G.conv.narrow_out_ok(spec, xc)
+    op = GF.ConvOp(spec)
+    G.conv.PROFILER = prof = G.conv.LaunchProfiler()
+    try:
+        out = GF.conv3d(xc, wt.cuda(), b.cuda(), op)
+    finally:
+        G.conv.PROFILER = None
+    assert 'conv_narrow_out_kernel' in prof.summary(), list(prof.summary())
+    assert tuple(out.shape) == (n, cout, t, h, w) and G.cl.is_cl(out)
+    if n * t * h * w <= 70000:
+        ref = _conv_ref(x, wt, b, (1, 1, 1), causal)
+        assert_close_bf16(out, ref, 'narrow-out conv fwd')
+    gen = G.conv.conv_forward(xc, G.conv.pack_weight_fwd(wt.cuda(), spec), b.cuda(), spec)
+    assert_close_bf16(out, gen.float().cpu(), 'narrow-out vs generic', rel=2 ** -7, rms_frac=3e-3)
+    # pad channels of the 8-channel output pixels are zero (the CL invariant)
+    raw = out.permute(0, 2, 3, 4, 1)
+    base = torch.as_strided(raw, (n, t, h, w, 8), (t * h * w * 8, h * w * 8, w * 8, 8, 1))
+    assert (base[..., cout:] == 0).all()
