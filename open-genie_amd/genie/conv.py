@@ -378,7 +378,7 @@ def _is_pointwise(spec: 'ConvSpec') -> bool:
 
 
 def _splitk_ws(device) -> Tensor:
-    key = device.index if device.index is not None else torch.cuda.current_device()
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)   # one per stream
     buf = _splitk_cache.get(key)
     if buf is None:
         buf = _splitk_cache[key] = torch.empty(SPLITK_WS_FLOATS, dtype=torch.float32, device=device)

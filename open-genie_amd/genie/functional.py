@@ -117,8 +117,9 @@ _ws_cache = {}
 
 
 def workspace(nfloats: int, device, tag: str = 'ws') -> Tensor:
-    """Grow-only fp32 scratch per (device, tag); stream-ordered reuse on one stream is safe."""
-    key = (device.index if device.index is not None else torch.cuda.current_device(), tag)
+    """Grow-only fp32 scratch per (device, tag, current stream): reuse is stream-ordered, so every stream that launches kernels
+    (the weight-gradient / LFQ side stream, a data-parallel comm stream) gets its own buffer."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), tag, torch.cuda.current_stream(device).cuda_stream)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nfloats:
         buf = torch.empty(max(int(nfloats), 1 << 16), dtype=torch.float32, device=device)

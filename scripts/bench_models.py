@@ -10,7 +10,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'open-genie_amd')]
 import torch
 
-from genie import LATENT_ACT_DEC, LATENT_ACT_ENC, REPR_TOK_DEC, REPR_TOK_ENC, DynamicsModel, LatentAction, VideoTokenizer
+from genie import (LATENT_ACT_DEC, LATENT_ACT_ENC, MAGVIT2_DEC_DESC, MAGVIT2_ENC_DESC, REPR_TOK_DEC, REPR_TOK_ENC, DynamicsModel, Genie, LatentAction,
+                   VideoTokenizer)
 from genie.trainer import ParamArena
 
 
@@ -58,6 +59,18 @@ def main():
         tokz = VideoTokenizer(REPR_TOK_ENC, REPR_TOK_DEC, d_codebook=10, gan_loss_weight=0., perc_loss_weight=0.).cuda().train()
         v = torch.randn(B, 3, 16, 64, 64, device='cuda')
         res.append(run(f'VideoTokenizer REPR_TOK (8+8 ST blocks, C=512, 16x16x16 latent, B={B}) [frames/s]', tokz, lambda: tokz(v)[0], B * 16))
+    if 'genie4' in which:
+        # BASELINE configs[4]: full Genie on 32x128x128 clips -- frozen MAGVIT2 tokenizer (8x16x16 tokens of 2^18 codes), latent-action
+        # model over 32 frames of 128x128 pixels (spatial attention over S = 16384 positions), MaskGIT dynamics; two clips per GPU
+        # (a batch of one dies in the reference's mask.squeeze() indexing, dynamics.py:89-97, and so does it here)
+        B = 2
+        tokz = VideoTokenizer(MAGVIT2_ENC_DESC, MAGVIT2_DEC_DESC, d_codebook=18, gan_loss_weight=0., perc_loss_weight=0.).cuda().eval()
+        gen = Genie(tokz, inp_shape=(128, 128)).cuda().train()
+        gen.tokenizer.eval()
+        v = torch.randn(B, 3, 32, 128, 128, device='cuda')
+        res.append(run(f'Genie (configs[4]: frozen MAGVIT2 tokenizer + R-lam + dynamics, 32x128x128, B={B}) [frames/s]', gen,
+                       lambda: gen.compute_loss(v)[0], B * 32, steps=3, warm=1))
+        del gen, tokz
     os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
     json.dump(res, open(os.path.join(ROOT, 'gpurun_out', 'bench_models.json'), 'w'), indent=1)
 

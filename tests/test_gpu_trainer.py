@@ -188,4 +188,8 @@ def test_async_wgrad_side_stream_matches_in_order_execution():
     for g1, p1, l1 in res[1:]:
         assert abs(l0 - l1) <= 1e-3 * abs(l0)
         assert (g0 - g1).abs().max().item() <= 2e-3 * g0.abs().max().item() + 1e-6          # fp32 atomics order only
-        assert (p0 - p1).abs().max().item() <= 3e-3
+        # AdamW's first steps move every parameter by ~lr * sign(grad): where the gradient is rounding noise the atomics order can flip
+        # the sign, so the bound on a single parameter is 2 * lr per step; the bulk must agree far better than that
+        dp = (p0 - p1).abs()
+        assert dp.max().item() <= 2 * 2 * 1e-3 + 5e-4, dp.max().item()
+        assert dp.mean().item() <= 2e-5, dp.mean().item()
