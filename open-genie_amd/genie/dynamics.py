@@ -44,7 +44,7 @@ class DynamicsModel(nn.Module):
         return [self.tok_emb, self.act_emb, self.dec_layers, self.head]
 
     def _trunk(self, tokens: Tensor, act_id: Tensor) -> Tensor:
-        x = self.tok_emb(tokens) + self.act_emb(act_id)                 # (B, T, H, W, D)
+        x = GF.embedding(tokens, self.tok_emb.weight) + self.act_emb(act_id)                 # (B, T, H, W, D); sparse embedding backward
         for dec in self.dec_layers:
             x = dec(x)
         return x
@@ -62,18 +62,40 @@ class DynamicsModel(nn.Module):
     def compute_loss(self, tokens: Tensor, act_id: Tensor, mask: Tensor | None = None, fill: float = 0.) -> Tensor:
         b, t, h, w = tokens.shape
         mask = default(mask, torch.distributions.Bernoulli(torch.empty(1).uniform_(0.5, 1).item()).sample((b, t, h, w)).bool())
+        host_mask = mask if mask.device.type == 'cpu' else None
         mask = mask.to(tokens.device)
         tokens = torch.masked_fill(tokens, mask, fill)
-        logits, _ = self(tokens, act_id.detach())
         m = mask.squeeze()
         if m.shape != tokens.shape:
             # batch 1: the reference's mask.squeeze() drops the batch axis and its boolean indexing misbehaves; same code, same fate
+            logits, _ = self(tokens, act_id.detach())
             logits = logits[m]
             target = tokens[m]
             return torch.nn.functional.cross_entropy(logits.reshape(-1, logits.shape[-1]).float(), target.reshape(-1))
-        # logits[m] / tokens[m] / cross_entropy(mean) of the reference, without materialising the gathered rows, their fp32 copy,
-        # the softmax and its backward: one fused pass forward, one backward (genie_masked_ce_fwd / _bwd)
-        return GF.masked_cross_entropy(logits, tokens, m)
+        # logits[m] / tokens[m] / cross_entropy(mean) of the reference (dynamics.py:89-97).  Only the masked rows enter the loss, the head
+        # is row-wise, and the logits are not returned: gather those rows of the trunk output FIRST and run the vocabulary head, the
+        # cross-entropy and their backward on them alone (a Bernoulli(0.5 .. 1) mask drops a quarter of the 2^18-wide rows on average);
+        # the fused genie_masked_ce_fwd / _bwd then never materialise the gathered rows' fp32 copy or their softmax.
+        # A mask that lives on the host (the default one does) gives the row list without a device round trip.
+        flat = (host_mask.squeeze() if host_mask is not None else m).reshape(-1)
+        rows = flat.nonzero().squeeze(1).to(tokens.device)
+        x = self._trunk(tokens, act_id.detach())
+        d = x.shape[-1]
+        if rows.numel() == 0:
+            return x.sum() * float('nan')                                      # F.cross_entropy over zero rows (mean) is NaN
+        # the compact rows are laid out as a (t, h, 256) grid for the gather-GEMM (every axis < 1024); the few pad rows re-read row 0
+        # and are switched off in the cross-entropy (zero loss, zero gradient)
+        r = rows.numel()
+        k = (r + 255) // 256
+        gh = k if k <= 512 else 512
+        gt = (k + gh - 1) // gh
+        rp = gt * gh * 256
+        if rp != r:
+            rows = torch.cat([rows, rows.new_zeros(rp - r)])
+        valid = None if rp == r else (torch.arange(rp, device=rows.device) < r)
+        xc = x.reshape(-1, d).index_select(0, rows).view(1, gt, gh, 256, d)
+        logits = self._head(xc)                                                # (1, gt, gh, 256, V)
+        return GF.masked_cross_entropy(logits, tokens.reshape(-1).index_select(0, rows).view(1, gt, gh, 256), valid)
 
     def _last_frame_logits(self, tokens: Tensor, act_id: Tensor) -> Tensor:
         """logits[:, -1] of ``forward`` -- (B, h, w, V) bf16 -- with the vocabulary head applied to the last frame only (the head is
