@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GENIE_ABI_VERSION 6
+#define GENIE_ABI_VERSION 7
 
 #define GENIE_F32 0
 #define GENIE_BF16 1
@@ -112,6 +112,26 @@ typedef struct GenieConvDesc {
     int32_t tri_flags;
     int32_t pointwise;    /* 1: plain GEMM rows -- one tap with dt = dh = dw = 0, c0 = 0, wofs = 0 and nch = 64 * nk (a 1x1x1 stride-1
                              convolution or a Linear layer): eligible for the persistent GEMM kernel (conv_gemm.hip) */
+    /* Optional GroupNorm work in the epilogue (reference video.py:578-613: every conv of a residual block is followed / preceded by a
+     * one-group GroupNorm + SiLU).  Only for a plain destination (no shuffle, dm = 1, do = 0) whose samples are whole multiples of 256
+     * rows; the library applies it when the kernel it picks has the epilogue for it and says so through
+     * genie_last_conv_gn_fused() -- the caller runs the stand-alone pass (genie_groupnorm_fwd / _bwd) for whatever was not fused.
+     *   gn_sums  : fp64 [N][2], ACCUMULATED (zero it first): sum and sum of squares of the bf16 outputs of sample n -- the statistics of
+     *              a one-group GroupNorm over this tensor (genie_groupnorm_fwd_from_sums);
+     *   gnb_x    : this call computes the gradient of a GroupNorm(+activation) OUTPUT (it is a backward-data pass) and gnb_x is that
+     *              GroupNorm's INPUT (bf16, destination layout); gnb_gamma / gnb_beta fp32 [C] or NULL, gnb_mean / gnb_rstd fp32 [N],
+     *              gnb_act 0 none / 1 SiLU / 2 LeakyReLU(0.01); gnb_part fp32 [N][gnb_nblk][Cd][2] receives, per 256-row tile and channel,
+     *              (sum dz, sum dz * xhat), dz = dst * act'(xhat * gamma + beta) -- the input of genie_groupnorm_bwd_from_part;
+     *              gnb_nblk = rows per sample / 256. */
+    void* gn_sums;
+    const void* gnb_x;
+    const float* gnb_gamma;
+    const float* gnb_beta;
+    const float* gnb_mean;
+    const float* gnb_rstd;
+    float* gnb_part;
+    int32_t gnb_act;
+    int32_t gnb_nblk;
 } GenieConvDesc;
 
 int genie_conv_igemm(const GenieConvDesc* desc, void* stream);
@@ -131,6 +151,8 @@ int genie_conv_igemm(const GenieConvDesc* desc, void* stream);
 #define GENIE_VARIANT_WGRAD3 11
 #define GENIE_VARIANT_IGEMM3_WIDE 12     /* igemm3w_kernel: 256 x 256 tile, layers with >= 256 output channels */
 int genie_last_conv_variant(void);
+/* GroupNorm work the calling thread's last genie_conv_igemm did in its epilogue: bit 0 = gn_sums, bit 1 = gnb_part. */
+int genie_last_conv_gn_fused(void);
 
 /* Weight gradient: dW[row(n)][tap][c] += sum_m DY[dpix(m)][n'] * SRC[pix(m)*step + off_tap][c]
  * replaces: the weight/bias gradient of nn.Conv3d computed by autograd for every conv above.
@@ -193,6 +215,16 @@ int genie_groupnorm_bwd(const void* x, const void* dy, void* dx, int N, int64_t 
                         const float* gamma, const float* beta, const float* ada_scale, const float* ada_shift, int act,
                         const float* mean, const float* rstd, float* dgamma, float* dbeta, float* dada_scale,
                         float* dada_shift, float* ws, void* stream);
+/* The same two passes when a convolution already did the statistics / the backward reduction in its epilogue (GenieConvDesc.gn_sums,
+ * gnb_part): one group, no adaptive scale / shift.  fwd: mean / rstd (fp32 [N], written) from the fp64 sums, then the apply pass;
+ * bwd: parameter gradients (accumulated) + coefficients from the per-tile partials, then the apply pass.  ws: fp32 scratch of
+ * genie_groupnorm_bwd_from_part_ws_floats(N). */
+int genie_groupnorm_fwd_from_sums(const void* x, void* y, int N, int64_t npix, int C, int cpitch, const float* gamma, const float* beta,
+                                  float eps, int act, float* mean, float* rstd, const double* sums, void* stream);
+int64_t genie_groupnorm_bwd_from_part_ws_floats(int N);
+int genie_groupnorm_bwd_from_part(const void* x, const void* dy, void* dx, int N, int64_t npix, int C, int cpitch, const float* gamma,
+                                  const float* beta, int act, const float* mean, const float* rstd, float* dgamma, float* dbeta,
+                                  const float* part, int nblk, float* ws, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * BlurPooling3d with num_groups = 1 (elementwise.hip).   replaces: F.conv3d with the expanded Pascal kernel, video.py:516-534

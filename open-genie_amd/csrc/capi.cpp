@@ -20,3 +20,8 @@ extern "C" int genie_abi_version(void) { return GENIE_ABI_VERSION; }
 static thread_local int g_last_variant = -1;
 void genie_note_variant(int v) { g_last_variant = v; }
 extern "C" int genie_last_conv_variant(void) { return g_last_variant; }
+
+// GroupNorm work the last genie_conv_igemm call of this thread fused into its epilogue (bit 0: output sums, bit 1: backward partials)
+static thread_local int g_last_gn_fused = 0;
+void genie_note_gn_fused(int mask) { g_last_gn_fused = mask; }
+extern "C" int genie_last_conv_gn_fused(void) { return g_last_gn_fused; }

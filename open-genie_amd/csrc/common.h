@@ -20,6 +20,7 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
 
 void genie_set_error(const char* fmt, ...);
 void genie_note_variant(int v);   // GENIE_VARIANT_* of the kernel just launched
+void genie_note_gn_fused(int mask);   // GroupNorm work the conv call just launched does in its epilogue (genie_last_conv_gn_fused)
 
 #define GENIE_CHECK_ARG(cond, ...)                      \
     do {                                                \

@@ -426,6 +426,7 @@ int genie_conv_gemm_try(const GenieConvDesc* d, IgemmArgs a, hipStream_t s) {
     const bool wide = a.Nstore > 128 && mode != 2;                           // GENIE_GEMM_PW=2: always the 256 x 128 tile
     GemmArgs p;
     p.g = a;
+    p.g.gn_sums = nullptr; p.g.gnb_x = nullptr;                              // no GroupNorm fusion in these epilogues
     p.g.tiles_m = cdiv(a.M, 256);
     p.g.tiles_n = cdiv(a.Nstore, wide ? 256 : 128);
     p.nkt = wide ? d->nk * 2 : d->nk;

@@ -359,12 +359,31 @@ extern "C" int genie_conv_igemm(const GenieConvDesc* d, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     a.split_k = 1; a.chunks_per_split = a.nk; a.ws = nullptr; a.ws_ld = 0;
     a.tiles_n = cdiv(a.Nstore, 128);
+    // GroupNorm fusion requests: honoured by the 256-row kw-triple kernels only (conv_igemm3.hip); everything else ignores them
+    genie_note_gn_fused(0);
+    a.gn_sums = nullptr; a.gnb_x = nullptr; a.gnb_gamma = a.gnb_beta = a.gnb_mean = a.gnb_rstd = nullptr; a.gnb_part = nullptr;
+    a.gnb_act = 0; a.gnb_nblk = 0; a.gn_rows = d->To * d->Ho * d->Wo;
+    if (d->gn_sums || d->gnb_x) {
+        const bool plain = d->shuf_c >= d->Ncols && d->shuf_q == 1 && d->shuf_r == 1 && a.perm_f == 1 && d->dmt == 1 && d->dmh == 1 && d->dmw == 1 &&
+                           d->dot == 0 && d->doh == 0 && d->dow == 0 && d->Td == d->To && d->Hd == d->Ho && d->Wd == d->Wo &&
+                           (a.Nstore & 3) == 0 && (d->Cd & 3) == 0 && a.Nstore <= d->Cd;
+        if (plain && a.gn_rows % 256 == 0) {
+            a.gn_sums = (double*)d->gn_sums;
+            if (d->gnb_x) {
+                GENIE_CHECK_ARG(d->gnb_mean && d->gnb_rstd && d->gnb_part, "genie_conv_igemm: gnb_x needs gnb_mean, gnb_rstd and gnb_part");
+                GENIE_CHECK_ARG(d->gnb_nblk == a.gn_rows / 256, "genie_conv_igemm: gnb_nblk %d != rows per sample / 256 = %d", d->gnb_nblk, a.gn_rows / 256);
+                a.gnb_x = (const bf16_t*)d->gnb_x; a.gnb_gamma = d->gnb_gamma; a.gnb_beta = d->gnb_beta; a.gnb_mean = d->gnb_mean;
+                a.gnb_rstd = d->gnb_rstd; a.gnb_part = d->gnb_part; a.gnb_act = d->gnb_act; a.gnb_nblk = d->gnb_nblk;
+            }
+        }
+    }
     {
         int rc = genie_conv_gemm_try(d, a, s);
         if (rc <= 0) return rc;
         rc = genie_conv_igemm3_try(d, a, s);
         if (rc <= 0) return rc;
     }
+    a.gn_sums = nullptr; a.gnb_x = nullptr;              // the generic kernel's tiles are 128 rows: no GroupNorm fusion
     if (a.Nstore <= 32) {
         a.tiles_n = cdiv(a.Nstore, 32);
         genie_note_variant(smallc ? GENIE_VARIANT_IGEMM_32_SMALLC : GENIE_VARIANT_IGEMM_32);

@@ -1079,6 +1079,10 @@ int genie_conv_igemm3_try(const GenieConvDesc* d, IgemmArgs a, hipStream_t s) {
     p.g.chunks_per_split = per_split;                   // steps per split
     p.g.ws = split > 1 ? (float*)d->splitk_ws : nullptr;
     p.g.ws_ld = a.Nstore;
+    // GroupNorm fusion lives in the shared epilogue of the 256-row, non-split, non-persistent kernels
+    const bool gn_ok = bm == 256 && split == 1 && (d->tri_flags & 128) == 0;
+    if (!gn_ok) { p.g.gn_sums = nullptr; p.g.gnb_x = nullptr; }
+    const int gn_mask = (p.g.gn_sums ? 1 : 0) | (p.g.gnb_x ? 2 : 0);
     p.nsteps = d->n_tri_steps;
     p.WP = W + 2;
     p.img_rows = (bm / W) * (W + 2);
@@ -1092,9 +1096,11 @@ int genie_conv_igemm3_try(const GenieConvDesc* d, IgemmArgs a, hipStream_t s) {
         ((long long)p.g.tiles_m * cdiv(a.Nstore, 256) >= 256 || (d->tri_flags & 2048))) {      // bit 11: even with few tiles (tests)
         p.g.tiles_n = cdiv(a.Nstore, 256);
         genie_note_variant(GENIE_VARIANT_IGEMM3_WIDE);
+        genie_note_gn_fused(gn_mask);
         return launch_igemm3w<false>(p, d->tri_steps, s);
     }
     genie_note_variant(split > 1 ? GENIE_VARIANT_IGEMM3_256_SPLITK : (bm == 256 ? GENIE_VARIANT_IGEMM3_256 : GENIE_VARIANT_IGEMM3_128));
+    genie_note_gn_fused(gn_mask);
     if (bm == 256 && (d->tri_flags & 2) == 0) {                                                // deep-prefetch schedules
         // bit 7: the persistent form.  Measured A/B on one box (B = 8 step): the kernel itself +1 % (1117 -> 1128 TFLOP/s averaged over
         // its launches), the step unchanged (87.8 ms both ways) -- the pipeline fill / drain per tile is not what holds the

@@ -27,6 +27,16 @@ struct IgemmArgs {
     int chunks_per_split;
     float* ws;
     int ws_ld;
+    // optional GroupNorm fusion into the epilogue (one group, plain destination, whole row tiles inside a sample):
+    double* gn_sums;          // [N][2] += (sum, sum of squares) of the bf16-rounded outputs of sample n -- the statistics of the NEXT GroupNorm
+    const bf16_t* gnb_x;      // the destination is the gradient of a GroupNorm(+act) OUTPUT and this is that GroupNorm's INPUT (same layout):
+    const float* gnb_gamma;   //   gnb_part[n][row tile][c] = (sum dz, sum dz * xhat) over the tile's rows, dz = dst * act'(xhat * gamma + beta)
+    const float* gnb_beta;    //   = what gn_bwd_reduce_kernel (norm.hip) would write with one block per row tile
+    const float* gnb_mean;
+    const float* gnb_rstd;
+    float* gnb_part;
+    int gnb_act, gnb_nblk;
+    int gn_rows;              // rows (pixels) per sample
 };
 
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
@@ -64,6 +74,16 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16_t (&ac
         // 4x4 transposes inside lane quads (DPP quad_perm): lane j of a quad ends up with ONE row and FOUR consecutive
         // columns -> 8-byte stores instead of 2-byte ones (4x fewer store instructions)
         const int jq = lane & 3;
+        // GroupNorm fusion (see IgemmArgs): the tile lies inside sample gn_n, row tile gn_blk of it
+        const bool gn_fwd = BMROWS == 256 && a.gn_sums != nullptr, gn_bwd = BMROWS == 256 && a.gnb_x != nullptr;   // block-uniform; 256-row tiles only
+        int gn_n = 0, gn_blk = 0;
+        float gmu = 0.f, grs = 0.f, fs = 0.f, fss = 0.f;
+        if (gn_fwd || gn_bwd) {
+            gn_n = m0 / a.gn_rows;
+            gn_blk = (m0 - gn_n * a.gn_rows) / BMROWS;
+        }
+        if (gn_bwd) { gmu = a.gnb_mean[gn_n]; grs = a.gnb_rstd[gn_n]; }
+        float* const gn_red = reinterpret_cast<float*>(smem + 1024);                         // [row wave][256 columns][2], behind the row offsets
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int nq = n0 + wn * (TN * 32) + j * 32 + (lane & 28);         // first of this quad's 4 columns
@@ -82,6 +102,27 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16_t (&ac
             // residual rows of this column tile: all loads are issued before the first use (one load + dependent add per group
             // serialised TM * 4 global round trips per column tile -- the 1x1 shortcut dgrad, which is pure traffic, ran at half
             // the speed of the same GEMM without a residual)
+            float ga4[4] = {0.f, 0.f, 0.f, 0.f}, gb4[4] = {0.f, 0.f, 0.f, 0.f}, cs1[4] = {0.f, 0.f, 0.f, 0.f}, cs2[4] = {0.f, 0.f, 0.f, 0.f};
+            u32x2_t gxr[TM][4];
+            if (gn_bwd) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int n = nq + e;
+                    if (colok && n < a.Ncols) {
+                        const float ga = a.gnb_gamma ? a.gnb_gamma[n] : 1.f, be = a.gnb_beta ? a.gnb_beta[n] : 0.f;
+                        ga4[e] = grs * ga;
+                        gb4[e] = be - gmu * grs * ga;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int ro = rowoff[wm * (TM * 32) + i * 32 + 8 * g + 4 * khalf + jq];
+                        gxr[i][g] = u32x2_t{0u, 0u};
+                        if (ro >= 0 && colok) gxr[i][g] = *reinterpret_cast<const u32x2_t*>(a.gnb_x + (unsigned)ro + coloff);
+                    }
+            }
             u32x2_t rres[TM][4];
             if (a.resid) {
 #pragma unroll
@@ -133,7 +174,65 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16_t (&ac
                     ov[0] = pack_bf16x2(v[0], v[1]);
                     ov[1] = pack_bf16x2(v[2], v[3]);
                     *reinterpret_cast<u32x2_t*>(a.dst + (unsigned)ro + coloff) = ov;
+                    if (gn_fwd || gn_bwd) {
+                        const float o0 = __uint_as_float(ov[0] << 16), o1 = __uint_as_float(ov[0] & 0xffff0000u);     // what was stored (bf16)
+                        const float o2 = __uint_as_float(ov[1] << 16), o3 = __uint_as_float(ov[1] & 0xffff0000u);
+                        if (gn_fwd) {
+                            fs += (o0 + o1) + (o2 + o3);
+                            fss += (o0 * o0 + o1 * o1) + (o2 * o2 + o3 * o3);
+                        }
+                        if (gn_bwd) {
+                            const u32x2_t xr = gxr[i][g];
+                            const float xv[4] = {__uint_as_float(xr[0] << 16), __uint_as_float(xr[0] & 0xffff0000u),
+                                                 __uint_as_float(xr[1] << 16), __uint_as_float(xr[1] & 0xffff0000u)};
+                            const float dv[4] = {o0, o1, o2, o3};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float z = xv[e] * ga4[e] + gb4[e];
+                                const float dz = a.gnb_act == 1 ? dv[e] * silu_grad_f(z) : (a.gnb_act == 2 ? (z > 0.f ? dv[e] : 0.01f * dv[e]) : dv[e]);
+                                cs1[e] += dz;
+                                cs2[e] += dz * (xv[e] - gmu) * grs;
+                            }
+                        }
+                    }
                 }
+            }
+            if (gn_bwd) {
+                // the 8 lanes that share these 4 columns: lane quad (bits 0-1) and the two 32-lane halves (bit 5)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v1 = cs1[e], v2 = cs2[e];
+                    v1 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v1), 0xB1, 0xF, 0xF, true));
+                    v2 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v2), 0xB1, 0xF, 0xF, true));
+                    v1 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v1), 0x4E, 0xF, 0xF, true));
+                    v2 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v2), 0x4E, 0xF, 0xF, true));
+                    v1 += __shfl_xor(v1, 32, 64);
+                    v2 += __shfl_xor(v2, 32, 64);
+                    if ((lane & 35) == 0) {
+                        float* o = gn_red + ((wm * 256) + wn * (TN * 32) + j * 32 + (lane & 28) + e) * 2;
+                        o[0] = v1; o[1] = v2;
+                    }
+                }
+            }
+        }
+        if (gn_fwd) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { fs += __shfl_xor(fs, o, 64); fss += __shfl_xor(fss, o, 64); }
+            if (lane == 0) {
+                atomicAdd(a.gn_sums + 2 * gn_n, (double)fs);
+                atomicAdd(a.gn_sums + 2 * gn_n + 1, (double)fss);
+            }
+        }
+        if (gn_bwd) {
+            __syncthreads();
+            constexpr int WMV = BMROWS / (TM * 32);
+            const int bn = ((int)(blockDim.x >> 6) / WMV) * (TN * 32);                        // columns of the block tile (<= 256)
+            if (tid < bn && n0 + tid < a.Cd) {
+                float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+                for (int w = 0; w < WMV; ++w) { t1 += gn_red[(w * 256 + tid) * 2]; t2 += gn_red[(w * 256 + tid) * 2 + 1]; }
+                float* o = a.gnb_part + (((long long)gn_n * a.gnb_nblk + gn_blk) * a.Cd + n0 + tid) * 2;
+                o[0] = t1; o[1] = t2;
             }
         }
         return;

@@ -415,3 +415,52 @@ extern "C" int genie_groupnorm_bwd(const void* x, const void* dy, void* dx, int 
     }
     return GENIE_OK;
 }
+
+
+// ---- GroupNorm around convolutions that did part of the work in their epilogue (GenieConvDesc.gn_sums / gnb_part) --------------------
+// One group, no adaptive scale / shift (the residual blocks of reference video.py:539-656).
+
+// mean / rstd of sample n from the fp64 (sum, sum of squares) a conv epilogue accumulated over its output
+__global__ void gn_finalize_sums_kernel(const double* __restrict__ sums, int N, double cnt, float eps, float* __restrict__ mean, float* __restrict__ rstd) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const double m = sums[2 * n] / cnt;
+    double var = sums[2 * n + 1] / cnt - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[n] = (float)m;
+    rstd[n] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+extern "C" int genie_groupnorm_fwd_from_sums(const void* x, void* y, int N, int64_t npix, int C, int cpitch, const float* gamma, const float* beta,
+                                             float eps, int act, float* mean, float* rstd, const double* sums, void* stream) {
+    GENIE_CHECK_ARG(x && y && mean && rstd && sums, "genie_groupnorm_fwd_from_sums: null pointer");
+    GENIE_CHECK_ARG(cpitch % 8 == 0 && cpitch >= C && C >= 1, "genie_groupnorm_fwd_from_sums: bad channel pitch %d for C=%d", cpitch, C);
+    if (N == 0 || npix == 0) return GENIE_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const GnGeom g = gn_geom(N, npix, C, cpitch, 1);
+    gn_finalize_sums_kernel<<<(N + 255) / 256, 256, 0, s>>>(sums, N, (double)C * (double)npix, eps, mean, rstd);
+    GENIE_CHECK_LAUNCH();
+    gn_apply_kernel<<<dim3(g.nblk, N), 256, 0, s>>>((const bf16_t*)x, (bf16_t*)y, g, gamma, beta, nullptr, nullptr, mean, rstd, act);
+    GENIE_CHECK_LAUNCH();
+    return GENIE_OK;
+}
+
+extern "C" int64_t genie_groupnorm_bwd_from_part_ws_floats(int N) { return (int64_t)N * 2 + 64; }
+
+extern "C" int genie_groupnorm_bwd_from_part(const void* x, const void* dy, void* dx, int N, int64_t npix, int C, int cpitch, const float* gamma,
+                                             const float* beta, int act, const float* mean, const float* rstd, float* dgamma, float* dbeta,
+                                             const float* part, int nblk, float* ws, void* stream) {
+    GENIE_CHECK_ARG(x && dy && dx && mean && rstd && part && ws, "genie_groupnorm_bwd_from_part: null pointer");
+    GENIE_CHECK_ARG(cpitch % 8 == 0 && cpitch >= C && C >= 1, "genie_groupnorm_bwd_from_part: bad channel pitch %d for C=%d", cpitch, C);
+    GENIE_CHECK_ARG(nblk >= 1, "genie_groupnorm_bwd_from_part: nblk %d", nblk);
+    if (N == 0 || npix == 0) return GENIE_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const GnGeom g = gn_geom(N, npix, C, cpitch, 1);
+    GnGeom gf = g;
+    gf.nblk = nblk;                                      // the partials come one per 256-row conv tile, not one per block of the reduce pass
+    gn_bwd_finalize_kernel<<<dim3(1, N), GN_FIN_THREADS, 0, s>>>(part, gf, gamma, beta, nullptr, mean, rstd, dgamma, dbeta, nullptr, nullptr, ws);
+    GENIE_CHECK_LAUNCH();
+    gn_bwd_apply_kernel<<<dim3(g.nblk, N), 256, 0, s>>>((const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, g, gamma, beta, nullptr, nullptr, mean, rstd, ws, act);
+    GENIE_CHECK_LAUNCH();
+    return GENIE_OK;
+}

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('GENIE_HIP_LIB', os.path.join(os.path.dirname(_HERE), 'lib', 'libgenie_hip.so'))
 
 GENIE_F32, GENIE_BF16 = 0, 1
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class GenieTap(C.Structure):
@@ -37,7 +37,9 @@ class GenieConvDesc(C.Structure):
                 ('shuf_c', C.c_int32), ('shuf_q', C.c_int32), ('shuf_r', C.c_int32), ('act', C.c_int32),
                 ('splitk_ws', C.c_void_p), ('splitk_ws_bytes', C.c_int64),
                 ('tri_steps', C.c_void_p), ('n_tri_steps', C.c_int32), ('tri_bm', C.c_int32), ('tri_flags', C.c_int32),
-                ('pointwise', C.c_int32)]
+                ('pointwise', C.c_int32),
+                ('gn_sums', C.c_void_p), ('gnb_x', C.c_void_p), ('gnb_gamma', C.c_void_p), ('gnb_beta', C.c_void_p), ('gnb_mean', C.c_void_p),
+                ('gnb_rstd', C.c_void_p), ('gnb_part', C.c_void_p), ('gnb_act', C.c_int32), ('gnb_nblk', C.c_int32)]
 
 
 class GenieWgradDesc(C.Structure):
@@ -77,6 +79,10 @@ SIGNATURES = {
     'genie_groupnorm_ws_floats': (C.c_int64, [_I, _I, _I]),
     'genie_groupnorm_fwd': (C.c_int, [_P, _P, _I, _L, _I, _I, _I, _P, _P, _P, _P, _F, _I, _P, _P, _P, _P]),
     'genie_groupnorm_bwd': (C.c_int, [_P, _P, _P, _I, _L, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'genie_groupnorm_fwd_from_sums': (C.c_int, [_P, _P, _I, _L, _I, _I, _P, _P, _F, _I, _P, _P, _P, _P]),
+    'genie_groupnorm_bwd_from_part_ws_floats': (C.c_int64, [_I]),
+    'genie_groupnorm_bwd_from_part': (C.c_int, [_P, _P, _P, _I, _L, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P]),
+    'genie_last_conv_gn_fused': (C.c_int, []),
     'genie_blur_pool3d_fwd': (C.c_int, [_P, _I, _PL, _P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), _P, _I, _I, _P, _P]),
     'genie_blur_pool3d_bwd': (C.c_int, [_P, _I, _I, _PL, _P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), _P, _I, _P, _P]),
     'genie_silu_fwd': (C.c_int, [_P, _P, _L, _P]),

@@ -392,8 +392,31 @@ def _check_cl(x: Tensor, c: int, what: str):
         raise ValueError(f'{what}: expected {c} channels, got {x.shape[1]}')
 
 
+class GnBwdFuse:
+    """Request to do the reduce pass of a GroupNorm backward inside the epilogue of the backward-data conv that produces the
+    GroupNorm's output gradient (GenieConvDesc.gnb_*): `x` is the GroupNorm input, one group, `act` 0 / 1 (SiLU) / 2 (LeakyReLU).
+    After the call `part` (fp32 (N, nblk, Cp, 2)) holds the per-tile partial sums if `fused`."""
+    __slots__ = ('x', 'gamma', 'beta', 'mean', 'rstd', 'act', 'part', 'nblk', 'fused')
+
+    def __init__(self, x: Tensor, gamma: Tensor, beta: Tensor, mean: Tensor, rstd: Tensor, act: int) -> None:
+        self.x, self.gamma, self.beta, self.mean, self.rstd, self.act = x, gamma, beta, mean, rstd, act
+        self.part, self.nblk, self.fused = None, 0, False
+
+
+# GroupNorm work in conv epilogues -- 0: off (default), 1: forward statistics, 2: + the backward reduce pass.  Built, parity-tested and
+# measured at 32 clips: 285.8 / 285.9 / 285.1 ms per step for 0 / 1 / 2 -- what the stand-alone passes cost (stats 3.4 ms, reduce 8.8 ms
+# per step) comes back as epilogue time of the MFMA kernels (+9 ms), whose matrix pipes idle while it runs (DESIGN.md section 8).
+GN_FUSE = int(os.environ.get('GENIE_GN_FUSE', '0'))
+
+
+def _gn_rows_ok(t: int, h: int, w: int) -> bool:
+    return GN_FUSE and (t * h * w) % 256 == 0
+
+
 def conv_forward(x: Tensor, wpack: Tensor, bias: Optional[Tensor], spec: ConvSpec, resid: Optional[Tensor] = None,
-                 act: int = 0) -> Tensor:
+                 act: int = 0, gn_sums: Optional[list] = None) -> Tensor:
+    """`gn_sums`: pass an empty list to ask for the one-group GroupNorm statistics of the OUTPUT from the epilogue; on return it holds
+    the fp64 (N, 2) tensor of (sum, sum of squares) if the kernel that ran could do it, and stays empty otherwise."""
     _check_cl(x, spec.cin, 'conv_forward')
     n, _, t, h, w = x.shape
     to, ho, wo = spec.out_size((t, h, w))
@@ -434,8 +457,15 @@ def conv_forward(x: Tensor, wpack: Tensor, bias: Optional[Tensor], spec: ConvSpe
         sched = tri_schedule(('fwd', spec), _fwd_tap_list(spec), h, w, pitch_of(x))
         if sched is not None:
             d.tri_steps, d.n_tri_steps = sched[0].data_ptr(), sched[1]
+    sums = None
+    if gn_sums is not None and spec.shuffle is None and d.n_tri_steps > 0 and _gn_rows_ok(to, ho, wo):
+        sums = torch.zeros((n, 2), dtype=torch.float64, device=x.device)
+        d.gn_sums = sums.data_ptr()
     t0 = PROFILER.begin() if PROFILER is not None and (d.n_tri_steps > 0 or not PROFILER.only_triple) else None
-    _hip.check(_hip.load_library().genie_conv_igemm(C.byref(d), _hip.stream_ptr()), 'genie_conv_igemm(fwd)')
+    lib = _hip.load_library()
+    _hip.check(lib.genie_conv_igemm(C.byref(d), _hip.stream_ptr()), 'genie_conv_igemm(fwd)')
+    if sums is not None and (lib.genie_last_conv_gn_fused() & 1):
+        gn_sums.append(sums)
     if t0 is not None:
         flops = 2.0 * n * to * ho * wo * spec.cout * spec.cin * spec.ntaps
         PROFILER.end(_variant('fwd', spec, spec.cout if spec.shuffle is not None else spec.cout, bool(d.small_c)),
@@ -460,8 +490,9 @@ def _plain(spec: ConvSpec) -> ConvSpec:
     return ConvSpec(spec.cin, spec.cout, spec.kernel, spec.stride, spec.dilation, spec.pad_front, spec.pad_back, None)
 
 
-def conv_dgrad(dy: Tensor, wpack_bwd: Tensor, spec: ConvSpec, in_size: Triple, resid: Optional[Tensor] = None) -> Tensor:
-    """Gradient w.r.t. the conv input.  dy is the CL gradient of the (shuffled) output."""
+def conv_dgrad(dy: Tensor, wpack_bwd: Tensor, spec: ConvSpec, in_size: Triple, resid: Optional[Tensor] = None,
+               gnb: Optional[GnBwdFuse] = None) -> Tensor:
+    """Gradient w.r.t. the conv input.  dy is the CL gradient of the (shuffled) output.  `gnb`: see GnBwdFuse."""
     _check_cl(dy, spec.cfinal, 'conv_dgrad')
     if spec.shuffle is not None and spec.cfinal % 8 != 0:
         # the gather through the shuffle wants whole 16-B channel chunks per sub-pixel: un-shuffle the gradient instead; the
@@ -515,7 +546,17 @@ def conv_dgrad(dy: Tensor, wpack_bwd: Tensor, spec: ConvSpec, in_size: Triple, r
                     sched = tri_schedule(('dgrad', spec), dgrad_taps(spec, (0, 0, 0), pitch_of(dy), want_list=True), h, w, pitch_of(dy))
                     if sched is not None:
                         d.tri_steps, d.n_tri_steps = sched[0].data_ptr(), sched[1]
+                want_gnb = (gnb is not None and int(GN_FUSE) >= 2 and st == (1, 1, 1) and d.n_tri_steps > 0 and _gn_rows_ok(t, h, w) and resid is None
+                            and pitch_of(gnb.x) == pitch_of(dx) and tuple(gnb.x.shape) == tuple(dx.shape))
+                if want_gnb:
+                    gnb.nblk = t * h * w // 256
+                    gnb.part = torch.empty((n, gnb.nblk, pitch_of(dx), 2), dtype=torch.float32, device=dy.device)
+                    d.gnb_x, d.gnb_gamma, d.gnb_beta = gnb.x.data_ptr(), _hip.ptr(gnb.gamma), _hip.ptr(gnb.beta)
+                    d.gnb_mean, d.gnb_rstd, d.gnb_part = gnb.mean.data_ptr(), gnb.rstd.data_ptr(), gnb.part.data_ptr()
+                    d.gnb_act, d.gnb_nblk = gnb.act, gnb.nblk
                 _hip.check(lib.genie_conv_igemm(C.byref(d), _hip.stream_ptr()), 'genie_conv_igemm(dgrad)')
+                if want_gnb:
+                    gnb.fused = bool(lib.genie_last_conv_gn_fused() & 2)
                 first = False
     if t0 is not None:
         to, ho, wo = spec.out_size((t, h, w))

@@ -646,6 +646,37 @@ def _gn_fwd_raw(x: Tensor, gamma: Tensor, beta: Tensor, groups: int, eps: float,
     return y, mean, rstd
 
 
+GN_FUSE_COUNT = {'fwd': 0, 'bwd': 0}     # how often a GroupNorm pass was served from a conv epilogue (tests / diagnostics)
+
+
+def _gn_fwd_from_sums(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, act: int, sums: Tensor):
+    """One-group GroupNorm whose statistics the producing conv accumulated in its epilogue (conv_forward(gn_sums=...)): finalize + apply."""
+    GN_FUSE_COUNT['fwd'] += 1
+    n, c, t, h, w = x.shape
+    lib = _hip.load_library()
+    y = empty_like_cl(x)
+    mean = torch.empty(n, dtype=torch.float32, device=x.device)
+    rstd = torch.empty_like(mean)
+    P = _hip.ptr
+    _hip.check(lib.genie_groupnorm_fwd_from_sums(P(x), P(y), n, t * h * w, c, pitch_of(x), P(gamma), P(beta), eps, act, P(mean), P(rstd), P(sums),
+                                                 _hip.stream_ptr()), 'genie_groupnorm_fwd_from_sums')
+    return y, mean, rstd
+
+
+def _gn_bwd_from_part(x: Tensor, dy: Tensor, gamma: Tensor, beta: Tensor, mean: Tensor, rstd: Tensor, act: int, part: Tensor, nblk: int) -> Tensor:
+    """GroupNorm backward whose reduce pass ran in the epilogue of the conv that produced `dy` (conv_dgrad(gnb=...)): finalize + apply."""
+    GN_FUSE_COUNT['bwd'] += 1
+    n, c, t, h, w = x.shape
+    lib = _hip.load_library()
+    dx = empty_like_cl(x)
+    ws = workspace(lib.genie_groupnorm_bwd_from_part_ws_floats(n), x.device, 'gnp')
+    P = _hip.ptr
+    _hip.check(lib.genie_groupnorm_bwd_from_part(P(x), P(dy), P(dx), n, t * h * w, c, pitch_of(x), P(gamma), P(beta), act, P(mean), P(rstd),
+                                                 P(_grad_buffer(gamma)), P(_grad_buffer(beta)), P(part), nblk, P(ws), _hip.stream_ptr()),
+               'genie_groupnorm_bwd_from_part')
+    return dx
+
+
 def _gn_bwd_raw(x: Tensor, dy: Tensor, gamma: Tensor, beta: Tensor, mean: Tensor, rstd: Tensor, groups: int, act: int) -> Tensor:
     """dx; the parameter gradients accumulate into gamma.grad / beta.grad."""
     n, c, t, h, w = x.shape
@@ -658,16 +689,30 @@ def _gn_bwd_raw(x: Tensor, dy: Tensor, gamma: Tensor, beta: Tensor, mean: Tensor
     return dx
 
 
+_RESBLOCK_OUT_SUMS = {}
+
+
 class _ResBlockFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, g1w, g1b, wa, ba, g2w, g2b, wb, bb, wr, br, ops, groups: int, eps1: float, eps2: float):
+    def forward(ctx, x, g1w, g1b, wa, ba, g2w, g2b, wb, bb, wr, br, ops, groups: int, eps1: float, eps2: float, x_sums=None):
         op_a, op_b, op_r = ops
         _conv_gate()
-        xn, m1, r1 = _gn_fwd_raw(x, g1w, g1b, groups, eps1, 1)
-        h1 = conv_forward(xn, op_a.pack_fwd(wa), ba, op_a.spec)
-        hn, m2, r2 = _gn_fwd_raw(h1, g2w, g2b, groups, eps2, 1)
+        # GroupNorm statistics ride on the producing conv's epilogue where that kernel can do it (one group): conv_a's output feeds the
+        # second norm of this block, conv_b's output (the block output) the first norm of the NEXT block (`x_sums`, handed over on the tensor)
+        if groups == 1 and x_sums is not None:
+            xn, m1, r1 = _gn_fwd_from_sums(x, g1w, g1b, eps1, 1, x_sums)
+        else:
+            xn, m1, r1 = _gn_fwd_raw(x, g1w, g1b, groups, eps1, 1)
+        s1 = [] if groups == 1 else None
+        h1 = conv_forward(xn, op_a.pack_fwd(wa), ba, op_a.spec, gn_sums=s1)
+        if s1:
+            hn, m2, r2 = _gn_fwd_from_sums(h1, g2w, g2b, eps2, 1, s1[0])
+        else:
+            hn, m2, r2 = _gn_fwd_raw(h1, g2w, g2b, groups, eps2, 1)
         r = conv_forward(x, op_r.pack_fwd(wr), br, op_r.spec)
-        out = conv_forward(hn, op_b.pack_fwd(wb), bb, op_b.spec, resid=r)
+        s2 = [] if groups == 1 else None
+        out = conv_forward(hn, op_b.pack_fwd(wb), bb, op_b.spec, resid=r, gn_sums=s2)
+        _RESBLOCK_OUT_SUMS['last'] = s2[0] if s2 else None
         ctx.ops, ctx.groups = ops, groups
         ctx.size = tuple(x.shape[2:])
         ctx.save_for_backward(x, xn, h1, hn, m1, r1, m2, r2, g1w, g1b, wa, ba, g2w, g2b, wb, bb, wr, br)
@@ -680,21 +725,30 @@ class _ResBlockFn(torch.autograd.Function):
         dy = to_cl(dy)
         gb = lambda b: _grad_buffer(b) if b is not None else None
         _conv_gate()
-        d_hn = conv_dgrad(dy, op_b.pack_bwd(wb), op_b.spec, ctx.size)
+        # the reduce pass of each GroupNorm backward rides on the epilogue of the backward-data conv that produces its output gradient
+        f2 = _conv.GnBwdFuse(h1, g2w, g2b, m2, r2, 1) if ctx.groups == 1 else None
+        d_hn = conv_dgrad(dy, op_b.pack_bwd(wb), op_b.spec, ctx.size, gnb=f2)
         wg = _wgrad if getattr(wb, '_genie_arena', False) else conv_wgrad
         wg(hn, dy, op_b.spec, _grad_buffer(wb), gb(bb))
-        d_h1 = _gn_bwd_raw(h1, d_hn, g2w, g2b, m2, r2, ctx.groups, 1)
-        del d_hn
+        if f2 is not None and f2.fused:
+            d_h1 = _gn_bwd_from_part(h1, d_hn, g2w, g2b, m2, r2, 1, f2.part, f2.nblk)
+        else:
+            d_h1 = _gn_bwd_raw(h1, d_hn, g2w, g2b, m2, r2, ctx.groups, 1)
+        del d_hn, f2
         _conv_gate()                                           # wgrad of conv_b ran under the GroupNorm backward above
-        d_xn = conv_dgrad(d_h1, op_a.pack_bwd(wa), op_a.spec, ctx.size)
+        f1 = _conv.GnBwdFuse(x, g1w, g1b, m1, r1, 1) if ctx.groups == 1 and ctx.needs_input_grad[0] else None
+        d_xn = conv_dgrad(d_h1, op_a.pack_bwd(wa), op_a.spec, ctx.size, gnb=f1)
         wg(xn, d_h1, op_a.spec, _grad_buffer(wa), gb(ba))
         del d_h1
         wg(x, dy, op_r.spec, _grad_buffer(wr), gb(br))
         dx = None
         if ctx.needs_input_grad[0]:
-            d_xm = _gn_bwd_raw(x, d_xn, g1w, g1b, m1, r1, ctx.groups, 1)
+            if f1 is not None and f1.fused:
+                d_xm = _gn_bwd_from_part(x, d_xn, g1w, g1b, m1, r1, 1, f1.part, f1.nblk)
+            else:
+                d_xm = _gn_bwd_raw(x, d_xn, g1w, g1b, m1, r1, ctx.groups, 1)
             dx = conv_dgrad(dy, op_r.pack_bwd(wr), op_r.spec, ctx.size, resid=d_xm)      # dgrad of the 1x1x1 conv + main-branch gradient
-        return (dx,) + (None,) * 14
+        return (dx,) + (None,) * 15
 
 
 def residual_block(x: Tensor, norm1, conv_a, norm2, conv_b, conv_r) -> Optional[Tensor]:
@@ -710,5 +764,12 @@ def residual_block(x: Tensor, norm1, conv_a, norm2, conv_b, conv_r) -> Optional[
         return None
     if not (norm1.weight.is_contiguous() and norm2.weight.is_contiguous()):
         return None
-    return _ResBlockFn.apply(to_cl(x), norm1.weight, norm1.bias, conv_a.weight, conv_a.bias, norm2.weight, norm2.bias, conv_b.weight, conv_b.bias,
-                             conv_r.weight, conv_r.bias, (conv_a.op, conv_b.op, conv_r.op), norm1.num_groups, norm1.eps, norm2.eps)
+    x = to_cl(x)
+    fn = _ResBlockFn
+    out = fn.apply(x, norm1.weight, norm1.bias, conv_a.weight, conv_a.bias, norm2.weight, norm2.bias, conv_b.weight, conv_b.bias,
+                   conv_r.weight, conv_r.bias, (conv_a.op, conv_b.op, conv_r.op), norm1.num_groups, norm1.eps, norm2.eps,
+                   getattr(x, '_genie_gn_sums', None))
+    sums = _RESBLOCK_OUT_SUMS.pop('last', None)
+    if sums is not None:
+        out._genie_gn_sums = sums          # one-group statistics of `out`, for the GroupNorm that opens the next residual block
+    return out

@@ -687,3 +687,47 @@ def test_conv_narrow_out_kernel(G, cout, causal, size):
     raw = out.permute(0, 2, 3, 4, 1)
     base = torch.as_strided(raw, (n, t, h, w, 8), (t * h * w * 8, h * w * 8, w * 8, 8, 1))
     assert (base[..., cout:] == 0).all()
+
+
+@pytest.mark.parametrize('cin,cout,size,force', [(128, 128, (2, 4, 16, 16), True), (128, 256, (1, 2, 16, 32), True), (256, 256, (4, 16, 32, 32), False)])
+def test_residual_block_groupnorm_fused_into_conv_epilogues(G, cin, cout, size, force):
+    """GroupNorm statistics from the producing conv's epilogue (GenieConvDesc.gn_sums) and the GroupNorm-backward reduce pass from the
+    backward-data conv's epilogue (gnb_*): a chain of two residual blocks gives the same output, input gradient and parameter gradients
+    as with the stand-alone passes, and the fused path really ran (it silently falls back when the kernel cannot do it)."""
+    from genie import functional as GF
+    from genie.module.video import VideoResidualBlock
+    torch.manual_seed(23)
+    n, t, h, w = size
+    blocks = torch.nn.Sequential(VideoResidualBlock(cin, cout, num_groups=1), VideoResidualBlock(cout, cout, num_groups=1)).cuda()
+    x0 = bf16_round(torch.randn(n, cin, t, h, w)).cuda()
+    dy = bf16_round(torch.randn(n, cout, t, h, w)).cuda()
+    res = []
+    old_bm, old_fuse = G.conv.TRI_BM, G.conv.GN_FUSE
+    try:
+        if force:
+            G.conv.TRI_BM = 256                          # small problem: force the 256-row kw-triple tile (the default would split K)
+        for fuse in (0, 2):
+            G.conv.GN_FUSE = fuse
+            GF.GN_FUSE_COUNT['fwd'] = GF.GN_FUSE_COUNT['bwd'] = 0
+            for p in blocks.parameters():
+                p.grad = None
+            x = G.cl.to_cl(x0.clone()).requires_grad_(True)
+            out = blocks(x)
+            out.backward(G.cl.to_cl(dy))
+            torch.cuda.synchronize()
+            res.append((out.detach().float().cpu(), x.grad.float().cpu(), [p.grad.float().cpu().clone() for p in blocks.parameters()],
+                        dict(GF.GN_FUSE_COUNT)))
+    finally:
+        G.conv.TRI_BM, G.conv.GN_FUSE = old_bm, old_fuse
+    (o0, g0, p0, c0), (o1, g1, p1, c1) = res
+    assert c0 == {'fwd': 0, 'bwd': 0}
+    assert c1['fwd'] == 3 and c1['bwd'] == 4, c1          # norm2 of both blocks + norm1 of the second; all four backward reduces
+    # same arithmetic up to the summation order of the statistics; a statistic that moves by an fp32 ulp re-rounds a few bf16
+    # intermediates, which two convs then spread: bound the error in norm and its worst element against the tensor RMS
+    for a, b, what in ((o1, o0, 'output'), (g1, g0, 'input gradient')):
+        rms = b.pow(2).mean().sqrt().item()
+        assert (a - b).pow(2).mean().sqrt().item() < 2e-3 * rms, what
+        assert (a - b).abs().max().item() < 4e-2 * rms, what
+    for a, b, (name, _) in zip(p1, p0, blocks.named_parameters()):
+        err = (a - b).norm().item() / (b.norm().item() + 1e-12)
+        assert err < 5e-3, (name, err)
