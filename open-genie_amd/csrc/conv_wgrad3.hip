@@ -6,7 +6,7 @@
 // and read from LDS once per tap.  The three taps of a kw-triple read the SAME dy tile and the SAME x rows shifted by one
 // pixel, so here one block owns a whole triple:
 //   - dy tile [64 pixels][128 co] and an x IMAGE [(64 / W) rows of W + 2 pixels][128 ci] with explicit zero columns left and
-//     right of every image row are staged once per 64-pixel chunk and serve 3 x 16 = 48 MFMAs per wave-quad: a third of the
+//     right of every image row (written once per block; only the 64 real pixels are DMA'd) are staged once per 64-pixel chunk and serve 3 x 16 = 48 MFMAs per wave-quad: a third of the
 //     glds issues and LDS-DMA bytes per MFMA;
 //   - the dy fragments (2 transposing LDS reads each) are shared by the three taps in registers, the x fragments are read at
 //     row offsets +0 / +1 / +2: 5 fragment reads per 6 MFMAs instead of 6.
@@ -48,6 +48,7 @@ struct Wgrad3Args {
     int M, nchunks, split_k, chunks_per_split;
     int tiles_m, tiles_n;
     int img_rows, log2W;        // (64 / W) * (W + 2);  W is a power of two in [8, 64]
+    int dbg;                    // timing ablations (wrong results): 1 no MFMAs, 2 no fragment reads / MFMAs, 4 no DMA
     FastDiv3 dW_, dH_, dT_;
 };
 
@@ -89,15 +90,19 @@ __device__ __forceinline__ void w3_issue(const uint32_t (&a_addr)[TM], const uin
     }
 }
 
+#ifndef W3_NSTAGE
+#define W3_NSTAGE 4        // LDS ring depth: stages are issued W3_NSTAGE - 1 chunks ahead (4 x 36 KB = 144 KB)
+#endif
+
 template <int LOG2W, bool SHUF>
 __global__ void __launch_bounds__(512) wgrad3_kernel(const Wgrad3Args a) {
     constexpr int BK = 64;                               // pixels per chunk
     constexpr int W = 1 << LOG2W, WP = W + 2, HS = BK >> LOG2W;   // image rows per chunk
     constexpr int PITCH = 256;                           // bytes per LDS row (128 channels)
     constexpr int A_BYTES = BK * PITCH;                  // dy tile, 16 KB
-    constexpr int X_ROUNDS = 3, X_BYTES = X_ROUNDS * 32 * PITCH;   // x image, up to 96 rows (80 used at W = 8), 24 KB
-    constexpr int STAGE = A_BYTES + X_BYTES;             // 40 KB
-    constexpr int NSTAGE = 3;
+    constexpr int X_BYTES = 80 * PITCH;                  // x image: (64 / W) * (W + 2) rows, 80 at W = 8; 20 KB
+    constexpr int STAGE = A_BYTES + X_BYTES;             // 36 KB
+    constexpr int NSTAGE = W3_NSTAGE;
     constexpr int TM = 2;                                // 32-row co tiles per wave; one 32-col ci tile
     constexpr int IMG_ROWS = HS * WP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -128,7 +133,7 @@ __global__ void __launch_bounds__(512) wgrad3_kernel(const Wgrad3Args a) {
 
     // ---- staging state (per lane, fixed for the kernel): which rows / channel chunk this lane fills in every stage ----
     const int d_row = tid >> 4;                          // + 32 * round
-    const int st_lc = (tid & 15) ^ ((d_row & 3) << 2);   // logical 16-B chunk (same in every round: round * 32 keeps row & 3)
+    const int st_lc = (tid & 15) ^ ((d_row & 3) << 2);   // logical 16-B chunk of the dy tile (same in every round: round * 32 keeps row & 3)
     int d_coff;                                          // element offset of (sub-pixel, channel) inside a dy pixel, or -1
     {
         const int co = co0 + st_lc * 8;
@@ -140,29 +145,48 @@ __global__ void __launch_bounds__(512) wgrad3_kernel(const Wgrad3Args a) {
             d_coff = -1;
         }
     }
-    const int x_c = (ci0 + st_lc * 8 < a.Cs && ci0 + st_lc * 8 < ((a.Cin + 7) & ~7)) ? ci0 + st_lc * 8 : -1;
     const int tap_delta = (t_dt * a.H + t_dh) * W * a.Cs;
-    // x image rows: chunk-local home pixel (or -1: pad column / unused row) and its (t, h), advanced by HS image rows per stage
-    int x_pix[X_ROUNDS], x_to[X_ROUNDS], x_ho[X_ROUNDS];
+    // x image: only the 64 real pixels of a chunk are DMA'd (two rounds of 32 rows, like the dy tile) -- pixel q = 32 round + d_row of
+    // image row hl = q >> LOG2W lands in LDS row hl * (W + 2) + (q & (W - 1)) + 1; the zero columns left and right of every image
+    // row are written ONCE below and never touched again.  (They used to arrive from a zero page with every stage: a third DMA
+    // round, 20 % of the stage's LDS-DMA pieces and bytes.)  A wave's 1-KiB piece = 4 consecutive pixels of one image row.
+    int x_c[2], x_to[2], x_ho[2];                        // channel element offset (or -1), (t, h) of the pixel's image row
+    uint32_t x_dst[2];                                   // byte offset of the wave's piece inside the image
 #pragma unroll
-    for (int i = 0; i < X_ROUNDS; ++i) {
-        const int r = i * 32 + d_row;
-        const int hl = r / WP, wp = r - hl * WP;
-        x_pix[i] = (r < IMG_ROWS && wp >= 1 && wp <= W && x_c >= 0) ? hl * W + wp - 1 : -1;
+    for (int i = 0; i < 2; ++i) {
+        const int q = i * 32 + d_row;
+        const int hl = q >> LOG2W;
+        const int lrow = hl * WP + (q & (W - 1)) + 1;    // this lane's LDS row
+        const int lc = (tid & 15) ^ ((lrow & 3) << 2);
+        x_c[i] = (ci0 + lc * 8 < a.Cs && ci0 + lc * 8 < ((a.Cin + 7) & ~7)) ? ci0 + lc * 8 : -1;
+        const int q0 = (i * 8 + wave) * 4;               // first pixel of the wave's piece
+        x_dst[i] = (uint32_t)(((q0 >> LOG2W) * WP + (q0 & (W - 1)) + 1) * PITCH);
         const uint32_t rowid = (uint32_t)c_begin * HS + (uint32_t)hl;          // (n, t, h) row of the first staged chunk
         const uint32_t q2 = fd3(rowid, a.dH_);
         x_ho[i] = (int)(rowid - q2 * a.dH_.d);
         x_to[i] = (int)(q2 - fd3(q2, a.dT_) * a.dT_.d);
     }
+    // zero columns of every stage's image: rows hl * WP and hl * WP + W + 1 (2 * HS rows of 256 B per stage)
+    for (int e = tid; e < NSTAGE * 2 * HS * 16; e += 512) {
+        const int st = e / (2 * HS * 16), r2 = (e / 16) % (2 * HS), c = e & 15;
+        const int row = (r2 >> 1) * WP + ((r2 & 1) ? W + 1 : 0);
+        *reinterpret_cast<u32x4_t*>(smem + st * STAGE + A_BYTES + row * PITCH + c * 16) = u32x4_t{0u, 0u, 0u, 0u};
+    }
+    __syncthreads();
 
-    int next_chunk = c_begin;                            // stage() is called for consecutive chunks only
-    auto stage = [&](int buf, bool live) {
+    int next_chunk = c_begin;                            // stage pieces are issued for consecutive chunks only
+    // One stage = four 1-KiB pieces per wave: dy rounds 0 / 1 (PIECE 0 / 1), x rounds 0 / 1 (PIECE 2 / 3; the last one advances the
+    // chunk cursor).  In the main loop piece j rides inside k-step j, between the MFMAs of the two co tiles: issued back to back at
+    // the top of a chunk the four cost ~220 cycles each with nothing to hide behind (timing ablation: DMA-only 0.13 ms + reads and
+    // MFMAs 0.26 ms = the whole 0.37 ms loop -- the phases added up instead of overlapping).
+    auto stage_piece = [&](int buf, bool live, int piece) {
+        if (a.dbg & 4) { if (piece == 3) ++next_chunk; return; }
         char* abase = smem + buf * STAGE;
         char* xbase = abase + A_BYTES;
         const uint32_t mbase = (uint32_t)next_chunk * BK;
         const int left = a.M - (int)mbase;               // pixels of this chunk that exist (<= 0: none)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        if (piece < 2) {
+            const int i = piece;
             const int pl = i * 32 + d_row;
             const bf16_t* q = zero;
             if (live && pl < left && d_coff >= 0) {
@@ -177,22 +201,26 @@ __global__ void __launch_bounds__(512) wgrad3_kernel(const Wgrad3Args a) {
                 }
             }
             __builtin_amdgcn_global_load_lds(GLB_PTR(q), LDS_PTR(abase + (i * 8 + wave) * 1024), 16, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < X_ROUNDS; ++i) {
+        } else {
+            const int i = piece - 2;
+            const int pl = i * 32 + d_row;
             const bf16_t* q = zero;
             const int t = x_to[i] + t_dt, h = x_ho[i] + t_dh;
-            if (live && x_pix[i] >= 0 && x_pix[i] < left && (unsigned)t < (unsigned)a.T && (unsigned)h < (unsigned)a.H)
-                q = a.src + (int)((mbase + (uint32_t)x_pix[i]) * (uint32_t)a.Cs + (uint32_t)(tap_delta + x_c));
-            __builtin_amdgcn_global_load_lds(GLB_PTR(q), LDS_PTR(xbase + (i * 8 + wave) * 1024), 16, 0, 0);
+            if (live && x_c[i] >= 0 && pl < left && (unsigned)t < (unsigned)a.T && (unsigned)h < (unsigned)a.H)
+                q = a.src + (int)((mbase + (uint32_t)pl) * (uint32_t)a.Cs + (uint32_t)(tap_delta + x_c[i]));
+            __builtin_amdgcn_global_load_lds(GLB_PTR(q), LDS_PTR(xbase + x_dst[i]), 16, 0, 0);
             // next chunk: HS image rows further
             x_ho[i] += HS;
             while (x_ho[i] >= a.H) {
                 x_ho[i] -= a.H;
                 x_to[i] = x_to[i] + 1 == a.T ? 0 : x_to[i] + 1;
             }
+            if (piece == 3) ++next_chunk;
         }
-        ++next_chunk;
+    };
+    auto stage = [&](int buf, bool live) {
+#pragma unroll
+        for (int pc = 0; pc < 4; ++pc) stage_piece(buf, live, pc);
     };
 
     f32x16_t acc[3][TM];
@@ -238,16 +266,17 @@ __global__ void __launch_bounds__(512) wgrad3_kernel(const Wgrad3Args a) {
     const uint32_t smem_base = w3_lds_offset(smem);
     const int nch = c_end - c_begin;
     if (nch > 0) {
-        // prologue: two stages in flight, the first one landed
+        // prologue: NSTAGE - 1 stages in flight, the first one landed
         stage(0, true);
         stage(1, nch > 1);
-        asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        if (NSTAGE == 4) stage(2, nch > 2);
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * (NSTAGE - 2)) : "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         int buf = 0;
         for (int c = 0; c < nch; ++c) {
-            const int nbuf = buf >= 1 ? buf - 1 : NSTAGE - 1;            // (buf + 2) % 3
-            stage(nbuf, c + 2 < nch);                                     // slot of chunk c - 1: every wave is past the barrier behind it
+            const int nbuf = buf >= 1 ? buf - 1 : NSTAGE - 1;            // (buf + NSTAGE - 1) % NSTAGE: slot of chunk c - 1, every wave is past
+            const bool nlive = c + NSTAGE - 1 < nch;                      // the barrier behind it
             const uint32_t abase = smem_base + buf * STAGE;
             uint32_t a_addr[TM], b_addr[2][3];
 #pragma unroll
@@ -267,11 +296,18 @@ __global__ void __launch_bounds__(512) wgrad3_kernel(const Wgrad3Args a) {
                 asm volatile("" : "+v"(blo[SET][s]), "+v"(bhi[SET][s]));                                         \
                 bfr[s] = __builtin_shufflevector(blo[SET][s], bhi[SET][s], 0, 1, 2, 3, 4, 5, 6, 7);              \
             }
-#define W3_MFMA()                                                                                                \
+#define W3_MFMA(KS)                                                                                              \
             _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                     \
+                if (!(a.dbg & 1)) {                                                                              \
                 _Pragma("unroll") for (int s = 0; s < 3; ++s)                                                    \
                     acc[s][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[s], acc[s][i], 0, 0, 0);     \
                 if (do_bias) accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], ones, accb[i], 0, 0, 0);   \
+                }                                                                                                \
+                if (i == 0) {                                                                                    \
+                    __builtin_amdgcn_sched_barrier(0);                                                           \
+                    stage_piece(nbuf, nlive, KS);                                                                \
+                    __builtin_amdgcn_sched_barrier(0);                                                           \
+                }                                                                                                \
             }
 #define W3_STEP(KS, SET, NEXT)                                                                                   \
             {                                                                                                    \
@@ -279,18 +315,22 @@ __global__ void __launch_bounds__(512) wgrad3_kernel(const Wgrad3Args a) {
                 __builtin_amdgcn_sched_barrier(0);                                                               \
                 W3_CONSUME(SET)                                                                                  \
                 NEXT                                                                                             \
-                W3_MFMA()                                                                                        \
+                W3_MFMA(KS)                                                                                      \
             }
+            if (!(a.dbg & 2)) {
             w3_issue<0, LOG2W, TM>(a_addr, b_addr, alo[0], ahi[0], blo[0], bhi[0]);
             W3_STEP(0, 0, (w3_issue<1, LOG2W, TM>(a_addr, b_addr, alo[1], ahi[1], blo[1], bhi[1]));)
             W3_STEP(1, 1, (w3_issue<2, LOG2W, TM>(a_addr, b_addr, alo[0], ahi[0], blo[0], bhi[0]));)
             W3_STEP(2, 0, (w3_issue<3, LOG2W, TM>(a_addr, b_addr, alo[1], ahi[1], blo[1], bhi[1]));)
             W3_STEP(3, 1, ;)
+            } else {
+                stage(nbuf, nlive);
+            }
 #undef W3_STEP
 #undef W3_MFMA
 #undef W3_CONSUME
-            // chunk c + 1 (issued one iteration ago) must have landed; the stage just issued (5 glds) stays in flight
-            asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            // chunk c + 1 must have landed; the NSTAGE - 2 newest stages (4 glds each) stay in flight
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * (NSTAGE - 2)) : "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             buf = buf == NSTAGE - 1 ? 0 : buf + 1;
@@ -349,6 +389,7 @@ int genie_conv_wgrad3_try(const GenieWgradDesc* d, hipStream_t s) {
     a.tiles_n = cdiv((d->Cin + 7) & ~7, 128);
     a.img_rows = (64 / W) * (W + 2);
     a.log2W = W == 8 ? 3 : (W == 16 ? 4 : (W == 32 ? 5 : 6));
+    { static const int dbg = getenv("GENIE_W3_DBG") ? atoi(getenv("GENIE_W3_DBG")) : 0; a.dbg = dbg; }
     a.dW_ = make_fastdiv3(d->Wo); a.dH_ = make_fastdiv3(d->Ho); a.dT_ = make_fastdiv3(d->To);
     const long long base = (long long)a.tiles_m * a.tiles_n * a.ntriples;
     int sk = d->split_k;
@@ -369,7 +410,7 @@ int genie_conv_wgrad3_try(const GenieWgradDesc* d, hipStream_t s) {
     }
     a.chunks_per_split = cdiv(a.nchunks, sk);
     a.split_k = cdiv(a.nchunks, a.chunks_per_split);
-    constexpr int lds = 3 * (64 * 256 + 3 * 32 * 256);
+    constexpr int lds = W3_NSTAGE * (64 * 256 + 80 * 256);
     void (*kern)(const Wgrad3Args) = nullptr;
     switch (a.log2W * 2 + (shuffled ? 1 : 0)) {
         case 6: kern = wgrad3_kernel<3, false>; break;
