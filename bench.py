@@ -269,7 +269,7 @@ def main():
                    'grad_allreduce': {'payload': 'fp32' if args.grad_compress == 'none' else 'bf16', 'buckets': len(dp.buckets),
                                       'bytes_per_step': dp.bytes_reduced // max(1, args.steps + args.warmup), 'overlapped_with_backward': dp.active,
                                       'loopback': bool(args.dp_loopback and world == 1)},
-                   'final_loss': round(scal[0].item(), 5)},
+                   'final_loss': round(scal[0].item(), 5), 'peak_mem_GB': round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)},
         'model_tflops_per_gpu': round(TRAIN_GFLOP_PER_CLIP * B * args.steps / elapsed / 1e3, 2),
     }
     if prof is not None:

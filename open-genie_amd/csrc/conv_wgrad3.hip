@@ -397,7 +397,8 @@ int genie_conv_wgrad3_try(const GenieWgradDesc* d, hipStream_t s) {
         // one block per CU (8 waves, 120 KB LDS): a whole number of 256-block rounds, as many rounds (up to 3) as leave >= 32
         // chunks per block -- the 196 KB of atomics per block and the pipeline fill need a long K loop to amortise
         sk = 0;
-        for (int rounds = 3; rounds >= 1 && sk == 0; --rounds) {
+        static const int max_rounds = getenv("GENIE_W3_ROUNDS") ? atoi(getenv("GENIE_W3_ROUNDS")) : 3;
+        for (int rounds = max_rounds; rounds >= 1 && sk == 0; --rounds) {
             const int cand = (int)((256ll * rounds) / base);
             if (cand >= 1 && a.nchunks / cand >= 32) sk = cand;
         }

@@ -3,7 +3,7 @@
 #   gpurun --timeout 1200 -- 'bash scripts/profile_bench.sh r01 8'
 set -u
 TAG=${1:-r01}
-BATCH=${2:-32}
+BATCH=${2:-64}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
