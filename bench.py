@@ -129,7 +129,8 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=6)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--batch', type=int, default=int(os.environ.get('GENIE_BENCH_BATCH', 32)), help='clips per GPU per step (32: sized for 288 GB of HBM; measured 1840 frames/s vs 1520 at 8)')
+    ap.add_argument('--batch', type=int, default=int(os.environ.get('GENIE_BENCH_BATCH', 64)),
+                    help='clips per GPU per step (64: 69 GB of the 288 GB HBM; same-box sweep 8 / 16 / 32 / 64 / 96 clips: 1520 / 1766 / 1816 / 1863 / 1863 frames/s)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-events', action='store_true')
     ap.add_argument('--all-kernel-events', action='store_true', help='HIP events around EVERY conv launch (full conv_kernels table; costs ~4 %% of the step)')
