@@ -129,24 +129,28 @@ __global__ void __launch_bounds__(256) lfq_factor_kernel(const T* __restrict__ z
     for (int b = threadIdx.x; b < g.nb; b += 256) Bout[row * g.nb + b] = B[b];
 }
 
-// P[cb][a][b] = (1/ntok) sum_tok A[tok,cb][a] * B[tok,cb][b];  64x64 tile per block, 4x4 per thread
+// P[cb][a][b] = (1/ntok) sum_tok A[tok,cb][a] * B[tok,cb][b];  64x64 tile per block, 4x4 per thread.  ksplit > 1: blockIdx.z also
+// carries a token range and the partial tiles are added atomically into a zeroed P (a 512 x 512 table is only 64 tiles: a quarter
+// of the chip; the token split fills it)
 __global__ void __launch_bounds__(256) lfq_avgprob_kernel(const float* __restrict__ Ain, const float* __restrict__ Bin, LfqGeom g,
-                                                          float* __restrict__ P) {
+                                                          float* __restrict__ P, int ksplit) {
     __shared__ float As[16][64], Bs[16][64];
-    const int cb = blockIdx.z, a0 = blockIdx.y * 64, b0 = blockIdx.x * 64;
+    const int cb = blockIdx.z / ksplit, ks = blockIdx.z % ksplit, a0 = blockIdx.y * 64, b0 = blockIdx.x * 64;
+    const long long tper = ((g.ntok + ksplit - 1) / ksplit + 15) / 16 * 16;
+    const long long tbeg = ks * tper, tend = tbeg + tper < g.ntok ? tbeg + tper : g.ntok;
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     float acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
-    for (long long t0 = 0; t0 < g.ntok; t0 += 16) {
+    for (long long t0 = tbeg; t0 < tend; t0 += 16) {
         for (int i = threadIdx.x; i < 16 * 64; i += 256) {
             const int r = i >> 6, c = i & 63;
             const long long tok = t0 + r;
             const long long row = tok * g.ncb + cb;
-            As[r][c] = (tok < g.ntok && a0 + c < g.na) ? Ain[row * g.na + a0 + c] : 0.f;
-            Bs[r][c] = (tok < g.ntok && b0 + c < g.nb) ? Bin[row * g.nb + b0 + c] : 0.f;
+            As[r][c] = (tok < tend && a0 + c < g.na) ? Ain[row * g.na + a0 + c] : 0.f;
+            Bs[r][c] = (tok < tend && b0 + c < g.nb) ? Bin[row * g.nb + b0 + c] : 0.f;
         }
         __syncthreads();
 #pragma unroll
@@ -167,7 +171,11 @@ __global__ void __launch_bounds__(256) lfq_avgprob_kernel(const float* __restric
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int a = a0 + ty * 4 + i, b = b0 + tx * 4 + j;
-            if (a < g.na && b < g.nb) P[((long long)cb * g.na + a) * g.nb + b] = acc[i][j] * inv;
+            if (a < g.na && b < g.nb) {
+                float* o = P + ((long long)cb * g.na + a) * g.nb + b;
+                if (ksplit > 1) atomicAdd(o, acc[i][j] * inv);
+                else *o = acc[i][j] * inv;
+            }
         }
 }
 
@@ -409,7 +417,13 @@ extern "C" int genie_lfq_loss(const void* z, int dtype, int64_t ntok, int num_co
     else
         GENIE_CHECK_ARG(false, "genie_lfq_loss: unsupported dtype %d", dtype);
     GENIE_CHECK_LAUNCH();
-    lfq_avgprob_kernel<<<dim3(cdiv(g.nb, 64), cdiv(g.na, 64), num_codebook), 256, 0, s>>>(A, B, g, P);
+    {
+        const long long tiles = (long long)cdiv(g.nb, 64) * cdiv(g.na, 64) * num_codebook;
+        int ksplit = 1;
+        while (tiles * ksplit < 256 && ntok / (ksplit * 2) >= 256 && ksplit < 16) ksplit *= 2;
+        if (ksplit > 1) GENIE_CHECK_ARG(hipMemsetAsync(P, 0, sizeof(float) * (size_t)num_codebook * ncode, s) == hipSuccess, "genie_lfq_loss: hipMemsetAsync failed");
+        lfq_avgprob_kernel<<<dim3(cdiv(g.nb, 64), cdiv(g.na, 64), num_codebook * ksplit), 256, 0, s>>>(A, B, g, P, ksplit);
+    }
     GENIE_CHECK_LAUNCH();
     int ablk = (int)((ncode + 255) / 256);
     if (ablk > LFQ_AVG_BLOCKS) ablk = LFQ_AVG_BLOCKS;
