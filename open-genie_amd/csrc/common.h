@@ -91,10 +91,13 @@ __device__ __forceinline__ float wave_sum(float v) {
     return (r0 + r1) + (r2 + r3);
 }
 
-__device__ __forceinline__ float silu_f(float z) { return z / (1.f + __expf(-z)); }
+// sigmoid through v_exp_f32 + v_rcp_f32 (1 ulp each): `1.f / x` and `a / x` compile to the IEEE division sequence (v_div_scale,
+// v_rcp, four FMAs, v_div_fmas, v_div_fixup -- ~10 VALU) without -ffast-math, and these run once per element of every GroupNorm pass
+__device__ __forceinline__ float sigmoid_fast_f(float z) { return __builtin_amdgcn_rcpf(1.f + __expf(-z)); }
+__device__ __forceinline__ float silu_f(float z) { return z * sigmoid_fast_f(z); }
 // d silu(z) / dz = s (1 + z (1 - s)),  s = sigmoid(z)
 __device__ __forceinline__ float silu_grad_f(float z) {
-    float s = 1.f / (1.f + __expf(-z));
+    const float s = sigmoid_fast_f(z);
     return s * (1.f + z * (1.f - s));
 }
 
