@@ -60,7 +60,8 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const bf16_t* __restrict_
 #pragma unroll
         for (int j = 0; j < 8; ++j) s[j] = q[j] = 0.f;
         if (pr < R) {
-            for (long long p = p0 + pr; p < p1; p += R) {
+    #pragma unroll 2
+        for (long long p = p0 + pr; p < p1; p += R) {
                 float f[8];
                 unpack8(*reinterpret_cast<const u32x4_t*>(xs + p * g.Cp + cc * 8), f);
 #pragma unroll
@@ -169,6 +170,7 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const bf16_t* __restrict_
             float mu, rs, ge;
             gn_coef(n, cc * 8 + j, g, gamma, beta, ada_s, ada_b, mean, rstd, a[j], b[j], mu, rs, ge);
         }
+#pragma unroll 2
         for (long long p = p0 + pr; p < p1; p += R) {
             float f[8];
             unpack8(*reinterpret_cast<const u32x4_t*>(xs + p * g.Cp + cc * 8), f);
@@ -248,7 +250,8 @@ __global__ void __launch_bounds__(256) gn_bwd_reduce_kernel(const bf16_t* __rest
                 float ge;
                 gn_coef(n, cc * 8 + j, g, gamma, beta, ada_s, ada_b, mean, rstd, a[j], b[j], mu[j], rs[j], ge);
             }
-            for (long long p = p0 + pr; p < p1; p += R) {
+    #pragma unroll 2
+        for (long long p = p0 + pr; p < p1; p += R) {
                 float f[8], d[8];
                 unpack8(*reinterpret_cast<const u32x4_t*>(xs + p * g.Cp + cc * 8), f);
                 unpack8(*reinterpret_cast<const u32x4_t*>(ds + p * g.Cp + cc * 8), d);
@@ -368,6 +371,7 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const bf16_t* __restr
                 k1[j] = k2[j] = k3[j] = 0.f;
             }
         }
+#pragma unroll 2
         for (long long p = p0 + pr; p < p1; p += R) {
             float f[8], d[8];
             unpack8(*reinterpret_cast<const u32x4_t*>(xs + p * g.Cp + cc * 8), f);
