@@ -185,7 +185,7 @@ def bench_hbm(iters, quick=False):
 # ------------------------------------------------------------------------------------------------
 def bench_conv(iters):
     from genie.conv import ConvSpec, causal_spec, conv_dgrad, conv_forward, conv_wgrad, pack_weight_bwd, pack_weight_fwd, same_spec
-    B = 8
+    B = int(os.environ.get('MB_BATCH', 8))
     shapes = [
         ('res 128->128 k3 @16x64x64', same_spec(128, 128, (3, 3, 3)), (16, 64, 64)),
         ('res 256->256 k3 @16x32x32', same_spec(256, 256, (3, 3, 3)), (16, 32, 32)),

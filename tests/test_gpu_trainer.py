@@ -174,14 +174,16 @@ def test_async_wgrad_side_stream_matches_in_order_execution():
             m = _model()
             arena = ParamArena(m)
             arena.attach_weight_packs(m)
-            for _ in range(2):
+            g = None
+            for it in range(2):
                 loss, _ = m(x)
                 loss.backward()
                 GF.join_wgrad()
-                g = arena.grads.clone()
+                if it == 0:
+                    g, l_first = arena.grads.clone(), loss.item()      # same parameters in every mode: the gradients must agree
                 arena.adamw_step(lr=1e-3, weight_decay=0.01)
             torch.cuda.synchronize()
-            res.append((g, arena.params.clone(), loss.item()))
+            res.append((g, arena.params.clone(), l_first))
         finally:
             GF.ASYNC_WGRAD = 0
     (g0, p0, l0) = res[0]
