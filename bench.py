@@ -69,7 +69,7 @@ def _cpu_baseline_worker(threads: int, frames: int, q) -> None:
         return time.perf_counter() - t0
 
     first = step()                                          # warm-up 1 (also tells how many more steps the budget allows)
-    warm, timed = (2, 3) if first < 9.0 else ((1, 1) if first < 40.0 else (1, 0))
+    warm, timed = (2, 3) if first < 14.0 else ((1, 1) if first < 40.0 else (1, 0))
     for _ in range(warm - 1):
         step()
     times = [step() for _ in range(timed)] or [first]
@@ -79,7 +79,7 @@ def _cpu_baseline_worker(threads: int, frames: int, q) -> None:
 def cpu_baseline(budget_s: float = 170.0):
     """The oracle (a port of the reference's algorithm, fp32 torch CPU) doing the SAME training step -- fwd + bwd + AdamW of the MAGVIT2
     tokenizer on one 16x64x64 clip -- on the host cores: BASELINE.md section 3 protocol, 2 warm-up + 3 timed steps, median (fewer
-    when one step takes longer than 9 s; 4-frame clips if nothing finishes inside the budget).  Runs in a child process with a
+    when the first (cold) step takes longer than 14 s; 4-frame clips if nothing finishes inside the budget).  Runs in a child process with a
     hard time budget; threads = the CPUs this process may use (affinity / cgroup quota), capped at 64."""
     import multiprocessing as mp
     threads = min(effective_cpus(), 64)
