@@ -558,8 +558,8 @@ int genie_igemm_splitk_finish(const IgemmArgs& a, hipStream_t s);      // conv_i
 template <bool SPLITK>
 __global__ void __launch_bounds__(512) igemm3w_kernel(const Igemm3Args p, const GenieTriStep* __restrict__ steps) {
     constexpr int BM = 256, BN = 256, NWAVE = 8, WN = 2, TM = 2, TN = 4;
-    constexpr int RPR = 64, A_ROUNDS = 5;
-    constexpr int A_BYTES = A_ROUNDS * RPR * 128, B_BYTES = BN * 64;        // 40 KB images, 16 KB weight half-tiles
+    constexpr int RPR = 64, A_ROUNDS = 4;                                    // DMA rounds per image: the 256 REAL pixels (zero columns: below)
+    constexpr int A_BYTES = 5 * RPR * 128, B_BYTES = BN * 64;               // 40 KB images (<= 320 rows with the zero columns), 16 KB weight half-tiles
     constexpr int B_LOADS = 2;                                               // 16 rows x 64 B per wave instruction, 256 rows / 8 waves
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const IgemmArgs& a = p.g;
@@ -582,20 +582,32 @@ __global__ void __launch_bounds__(512) igemm3w_kernel(const Igemm3Args p, const 
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page3);
 
-    unsigned a_base[A_ROUNDS];
+    // Image staging: only the 256 real pixels of the tile are DMA'd (4 rounds of 64 rows); pixel q of image row hl = q / W lands in LDS
+    // row hl * (W + 2) + q % W + 1, and the zero columns left and right of every image row are written ONCE per buffer here.  (They used
+    // to arrive from a zero page with every image: a fifth round, 20 % of the image pieces.)  A wave's 1-KiB piece = 8 consecutive
+    // pixels of one image row (W >= 8).
+    unsigned a_base[A_ROUNDS], a_dst[A_ROUNDS];
     int a_th[A_ROUNDS];
     const int row0_id = m0 / W;
 #pragma unroll
     for (int i = 0; i < A_ROUNDS; ++i) {
-        const int r = i * RPR + (tid >> 3);
+        const int q = i * RPR + (tid >> 3);
+        const int hl = q / W, w = q - hl * W;
+        const int r = hl * WP + w + 1;                                       // this lane's LDS row
         const int lc = (tid & 7) ^ ((r >> 1) & 7);
-        const int hl = r / WP, w = r - hl * WP - 1;
         const int rowid = row0_id + hl;
         const long long m = (long long)rowid * W + w;
-        const bool valid = r < p.img_rows && w >= 0 && w < W && m < a.M;
+        const bool valid = m < a.M;
         a_base[i] = valid ? (unsigned)m * (unsigned)a.Cs + lc * 8 : 0u;
         a_th[i] = valid ? ((((rowid / H) % T) << 16) | (rowid % H)) : (int)0x80000000;
+        const int q0 = (i * NWAVE + wave) * 8;                               // first pixel of the wave's piece
+        a_dst[i] = (unsigned)(((q0 / W) * WP + q0 % W + 1) * 128);
     }
+    for (int e = tid; e < 2 * 2 * (BM / 8) * 8; e += 512) {                  // (buffer, side, image row, 16-B chunk); image rows beyond BM / W: skipped
+        const int c = e & 7, hl = (e >> 3) % (BM / 8), side = (e >> 3) / (BM / 8) & 1, buf = e / (2 * (BM / 8) * 8);
+        if (hl * W < BM) *reinterpret_cast<u32x4_t*>(smem + buf * A_BYTES + (hl * WP + (side ? W + 1 : 0)) * 128 + c * 16) = u32x4_t{0u, 0u, 0u, 0u};
+    }
+    __syncthreads();
     const bf16_t* b_ptr[B_LOADS];
 #pragma unroll
     for (int j = 0; j < B_LOADS; ++j) {
@@ -610,7 +622,7 @@ __global__ void __launch_bounds__(512) igemm3w_kernel(const Igemm3Args p, const 
         const bool ok = live & ((unsigned)t < (unsigned)T) & ((unsigned)h < (unsigned)H);
         const bf16_t* q = a.src + (int)(a_base[i] + (unsigned)e.a_delta);
         q = ok ? q : zero;
-        __builtin_amdgcn_global_load_lds(GLB_PTR(q), LDS_PTR(abuf + (i * NWAVE + wave) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(GLB_PTR(q), LDS_PTR(abuf + a_dst[i]), 16, 0, 0);
     };
     auto stage_b = [&](int wofs, bool live, char* bbuf) {                      // one 32-channel half of a weight tile
 #pragma unroll
@@ -726,10 +738,8 @@ __global__ void __launch_bounds__(512) igemm3w_kernel(const Igemm3Args p, const 
                     stage_b(cur.wofs2 + 32, true, B0 + ((k + 5) & 3) * B_BYTES);,
                     acur, 1, 2, 3)
         GENIE_HTILE(3, 1, 1,
-                    stage_a(nxt, has_next, 4, anxt);
-                    __builtin_amdgcn_sched_barrier(0);
                     stage_b(nxt.wofs0, has_next, B0 + ((k + 6) & 3) * B_BYTES);,
-                    acur, 2, 0, 3)
+                    acur, 2, 0, 2)
         GENIE_HTILE(4, 2, 0,
                     stage_b(nxt.wofs0 + 32, has_next, B0 + ((k + 7) & 3) * B_BYTES);,
                     acur, 2, 2, 2)
