@@ -286,8 +286,8 @@ __global__ void __launch_bounds__(BM * 2) igemm3_kernel(const Igemm3Args p, cons
 template <bool PRE, bool SPLITK, int NWAVE>
 __global__ void __launch_bounds__(64 * NWAVE) igemm3d_kernel(const Igemm3Args p, const GenieTriStep* __restrict__ steps) {
     constexpr int BM = 256, BN = 128, NT = 64 * NWAVE, WN = 2, WM = NWAVE / WN, TM = BM / (WM * 32), TN = 2;
-    constexpr int RPR = NT / 8, A_ROUNDS = 320 / RPR;
-    constexpr int A_BYTES = A_ROUNDS * RPR * 128, B_BYTES = BN * 128;
+    constexpr int RPR = NT / 8, A_ROUNDS = BM / RPR;     // DMA rounds per image: the 256 REAL pixels (the zero columns are written once, below)
+    constexpr int A_BYTES = 320 * 128, B_BYTES = BN * 128;     // an image holds <= 320 rows with its zero columns
     constexpr int B_LOADS = BN / RPR;                   // 2 (8 waves) or 4 (4 waves)
     static_assert(NWAVE == 8 || (NWAVE == 4 && PRE), "the 4-wave form exists for the pre-read schedule only");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -320,20 +320,30 @@ __global__ void __launch_bounds__(64 * NWAVE) igemm3d_kernel(const Igemm3Args p,
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page3);
 
-    unsigned a_base[A_ROUNDS];
+    // Image staging as in igemm3w_kernel: only the 256 real pixels are DMA'd (pixel q of image row hl = q / W -> LDS row
+    // hl * (W + 2) + q % W + 1); the zero columns left and right of every image row are written once per buffer here.
+    unsigned a_base[A_ROUNDS], a_dst[A_ROUNDS];
     int a_th[A_ROUNDS];
     const int row0_id = m0 / W;
 #pragma unroll
     for (int i = 0; i < A_ROUNDS; ++i) {
-        const int r = i * RPR + (tid >> 3);
+        const int q = i * RPR + (tid >> 3);
+        const int hl = q / W, w = q - hl * W;
+        const int r = hl * WP + w + 1;                                       // this lane's LDS row
         const int lc = (tid & 7) ^ ((r >> 1) & 7);
-        const int hl = r / WP, w = r - hl * WP - 1;
         const int rowid = row0_id + hl;
         const long long m = (long long)rowid * W + w;
-        const bool valid = r < p.img_rows && w >= 0 && w < W && m < a.M;
+        const bool valid = m < a.M;
         a_base[i] = valid ? (unsigned)m * (unsigned)a.Cs + lc * 8 : 0u;
         a_th[i] = valid ? ((((rowid / H) % T) << 16) | (rowid % H)) : (int)0x80000000;
+        const int q0 = (i * NWAVE + wave) * 8;                               // first pixel of the wave's 1-KiB piece (8 pixels of one image row)
+        a_dst[i] = (unsigned)(((q0 / W) * WP + q0 % W + 1) * 128);
     }
+    for (int e = tid; e < 2 * 2 * (BM / 8) * 8; e += NT) {                   // (buffer, side, image row, 16-B chunk)
+        const int c = e & 7, hl = (e >> 3) % (BM / 8), side = (e >> 3) / (BM / 8) & 1, buf = e / (2 * (BM / 8) * 8);
+        if (hl * W < BM) *reinterpret_cast<u32x4_t*>(smem + buf * A_BYTES + (hl * WP + (side ? W + 1 : 0)) * 128 + c * 16) = u32x4_t{0u, 0u, 0u, 0u};
+    }
+    __syncthreads();
     bool b_ok[B_LOADS];
     const bf16_t* b_ptr[B_LOADS];
 #pragma unroll
@@ -350,7 +360,7 @@ __global__ void __launch_bounds__(64 * NWAVE) igemm3d_kernel(const Igemm3Args p,
         const bool ok = live & ((unsigned)t < (unsigned)T) & ((unsigned)h < (unsigned)H);
         const bf16_t* q = a.src + (int)(a_base[i] + (unsigned)e.a_delta);
         q = ok ? q : zero;
-        __builtin_amdgcn_global_load_lds(GLB_PTR(q), LDS_PTR(abuf + (i * NWAVE + wave) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(GLB_PTR(q), LDS_PTR(abuf + a_dst[i]), 16, 0, 0);
     };
     auto stage_b = [&](int wofs, bool live, char* bbuf) {
 #pragma unroll
@@ -431,10 +441,10 @@ __global__ void __launch_bounds__(64 * NWAVE) igemm3d_kernel(const Igemm3Args p,
         // and then waiting an LDS round trip while the matrix pipes idle (SQ counters on the plain version: pipes 56 % busy,
         // waves parked 37 % of their cycles).  Publication is one barrier earlier than consumption:
         //   at the barrier ending K-tile k, weight tiles k+1 AND k+2 have landed (tile k+3 is issued during K-tile k), and at
-        //   s = 1 the image of the next step as well (all five rounds go out at s = 0) -- so the pre-read for K-tile k+1, issued
+        //   s = 1 the image of the next step as well (all its rounds go out at s = 0) -- so the pre-read for K-tile k+1, issued
         //   before that barrier, only touches data published at barrier k-1.
-        //   groups: s = 0: 5 image rounds then tile k+3 (7 glds), s = 1, 2: tile k+3 (2 glds); the wait at the end of K-tile k
-        //   leaves exactly group k in flight: vmcnt(7) / vmcnt(2) / vmcnt(2).
+        //   groups: s = 0: 4 image rounds then tile k+3 (6 glds), s = 1, 2: tile k+3 (2 glds); the wait at the end of K-tile k
+        //   leaves exactly group k in flight: vmcnt(6) / vmcnt(2) / vmcnt(2).
         //   WAR: slot (k+3) & 3 = (k-1) & 3 was last read in K-tile k-1 (its pre-read targets slot k & 3); the spare image was last
         //   read in K-tile 3i-1 and is refilled from K-tile 3i on.
         bf16x8_t af0[TM], bf0[TN];
@@ -512,14 +522,13 @@ __global__ void __launch_bounds__(64 * NWAVE) igemm3d_kernel(const Igemm3Args p,
             compute(acur, 0, B0 + (k & 3) * B_BYTES);
             asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
             raw_barrier();
-            // ---- s = 1: image rounds 3, 4, then weight tile k+4 = (i+1, 1) ----
+            // ---- s = 1: image round 3, then weight tile k+4 = (i+1, 1) ----
             stage_a(nxt, has_next, 3, anxt);
-            stage_a(nxt, has_next, 4, anxt);
             __builtin_amdgcn_sched_barrier(0);
             stage_b(nxt.wofs1, has_next, B0 + ((k + 4) & 3) * B_BYTES);
             __builtin_amdgcn_sched_barrier(0);
             compute(acur, 1, B0 + ((k + 1) & 3) * B_BYTES);
-            asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             raw_barrier();
             // ---- s = 2: weight tile k+5 = (i+1, 2); the new image must have landed before the barrier ----
             stage_b(nxt.wofs2, has_next, B0 + ((k + 5) & 3) * B_BYTES);
