@@ -150,6 +150,7 @@ int genie_conv_igemm(const GenieConvDesc* desc, void* stream);
 #define GENIE_VARIANT_WGRAD_32x128 10
 #define GENIE_VARIANT_WGRAD3 11
 #define GENIE_VARIANT_IGEMM3_WIDE 12     /* igemm3w_kernel: 256 x 256 tile, layers with >= 256 output channels */
+#define GENIE_VARIANT_WGRAD_PW 13        /* wgrad_pw_kernel: pointwise weight gradient, 256 x 256 tile */
 int genie_last_conv_variant(void);
 /* GroupNorm work the calling thread's last genie_conv_igemm did in its epilogue: bit 0 = gn_sums, bit 1 = gnb_part. */
 int genie_last_conv_gn_fused(void);
@@ -173,6 +174,9 @@ typedef struct GenieWgradDesc {
     int32_t split_k;      /* 0 = choose */
     int32_t tri_mode;     /* 1: the taps are ordered as kw-triples (dw = -1, 0, +1 consecutive, same dt / dh) of a stride-1,
                              same-size convolution -> conv_wgrad3.hip may take it (2: must, whatever the problem size); 0: generic kernel */
+    int32_t pointwise;    /* 1: ONE tap with dt = dh = dw = 0 (a 1x1x1 stride-1 convolution or a Linear layer): with >= 256 channels on
+                             both sides and >= 192 output tiles of 256 x 256 (the vocabulary head) the transposing-read GEMM of
+                             conv_wgrad_pw.hip takes it; 2: that kernel whatever the tile count */
 } GenieWgradDesc;
 
 int genie_conv_wgrad(const GenieWgradDesc* desc, void* stream);

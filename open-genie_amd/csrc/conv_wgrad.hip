@@ -360,6 +360,7 @@ static int launch_wgrad(WgradArgs& a, hipStream_t s) {
 }
 
 int genie_conv_wgrad3_try(const GenieWgradDesc* d, hipStream_t s);   // conv_wgrad3.hip
+int genie_conv_wgrad_pw_try(const GenieWgradDesc* d, hipStream_t s);  // conv_wgrad_pw.hip
 
 extern "C" int genie_conv_wgrad(const GenieWgradDesc* d, void* stream) {
     GENIE_CHECK_ARG(d, "genie_conv_wgrad: null descriptor");
@@ -369,7 +370,9 @@ extern "C" int genie_conv_wgrad(const GenieWgradDesc* d, void* stream) {
     GENIE_CHECK_ARG((long long)d->N * d->Ts * d->Hs * d->Ws * d->Cs < (1ll << 31) && (long long)d->N * d->Td * d->Hd * d->Wd * d->Cd < (1ll << 31),
                     "genie_conv_wgrad: tensor exceeds 2^31 elements");
     {
-        const int rc = genie_conv_wgrad3_try(d, (hipStream_t)stream);
+        int rc = genie_conv_wgrad3_try(d, (hipStream_t)stream);
+        if (rc <= 0) return rc;
+        rc = genie_conv_wgrad_pw_try(d, (hipStream_t)stream);
         if (rc <= 0) return rc;
     }
     WgradArgs a;

@@ -63,7 +63,7 @@ PROFILER: Optional[LaunchProfiler] = None
 
 VARIANT_NAMES = {0: 'igemm_kernel<128,generic>', 1: 'igemm_kernel<128,smallc>', 2: 'igemm_kernel<32,generic>', 3: 'igemm_kernel<32,smallc>',
                  4: 'igemm3_kernel<128>', 5: 'igemm3_kernel<256>', 6: 'gemm_pw_kernel', 7: 'igemm3_kernel<256,splitk>', 8: 'wgrad_kernel<128,128>', 9: 'wgrad_kernel<128,32>',
-                 10: 'wgrad_kernel<32,128>', 11: 'wgrad3_kernel', 12: 'igemm3_kernel<256x256>'}
+                 10: 'wgrad_kernel<32,128>', 11: 'wgrad3_kernel', 12: 'igemm3_kernel<256x256>', 13: 'wgrad_pw_kernel<256x256>'}
 
 
 def _variant(kind: str, spec: 'ConvSpec', ncols: int, small_c: bool) -> str:
@@ -407,6 +407,7 @@ class GnBwdFuse:
 # measured at 32 clips: 285.8 / 285.9 / 285.1 ms per step for 0 / 1 / 2 -- what the stand-alone passes cost (stats 3.4 ms, reduce 8.8 ms
 # per step) comes back as epilogue time of the MFMA kernels (+9 ms), whose matrix pipes idle while it runs.
 GN_FUSE = int(os.environ.get('GENIE_GN_FUSE', '0'))
+WGRAD_PW = 1     # GenieWgradDesc.pointwise for 1x1x1 convolutions / Linear layers: 1 = the library decides, 2 = force conv_wgrad_pw.hip (tests)
 
 
 def _gn_rows_ok(t: int, h: int, w: int) -> bool:
@@ -597,6 +598,7 @@ def conv_wgrad(x: Tensor, dy: Tensor, spec: ConvSpec, dweight: Tensor, dbias: Op
     d.split_k = FORCE_SPLIT_K
     d.tri_mode = TRI_WGRAD if (TRI_WGRAD and spec.stride == (1, 1, 1) and spec.kernel[2] == 3 and spec.dilation[2] == 1
                        and spec.pad_front[2] == 1 and spec.pad_back[2] == 1 and (to, ho, wo) == (t, h, w)) else 0
+    d.pointwise = WGRAD_PW if _is_pointwise(spec) else 0
     t0 = PROFILER.begin() if PROFILER is not None and not PROFILER.only_triple else None
     _hip.check(_hip.load_library().genie_conv_wgrad(C.byref(d), _hip.stream_ptr()), 'genie_conv_wgrad')
     if t0 is not None:

@@ -416,6 +416,31 @@ def test_conv_wgrad(G, cin, cout, kernel, stride, causal, size, wfmt):
     torch.testing.assert_close(dw.cpu(), 2 * wt.grad, rtol=1e-3, atol=2e-3 * scale)
 
 
+@pytest.mark.parametrize('cin,cout,size', [(256, 512, (2, 4, 16, 16)), (512, 256, (1, 3, 9, 11)), (320, 264, (1, 2, 5, 29)), (256, 256 * 260, (1, 1, 3, 97))])
+def test_conv_wgrad_pointwise_kernel(G, cin, cout, size, monkeypatch):
+    """conv_wgrad_pw.hip (pointwise weight gradient, 256 x 256 tile, transposing reads on both operands, VALU bias gradient) against
+    autograd of F.conv3d: split-K with atomics (few output tiles), partial tiles in both channel dimensions and in the last 32-pixel
+    chunk, and the single-split read-modify-write path (260 output tiles, the shape class of the vocabulary head)."""
+    torch.manual_seed(14)
+    n, t, h, w = size
+    x = bf16_round(torch.randn(n, cin, t, h, w))
+    wt = torch.randn(cout, cin, 1, 1, 1, requires_grad=True)
+    b = torch.randn(cout, requires_grad=True)
+    ref = F.conv3d(x, wt, b)
+    dy = bf16_round(torch.randn_like(ref))
+    ref.backward(dy)
+    spec = G.conv.same_spec(cin, cout, (1, 1, 1))
+    dw = torch.zeros(cout, cin, 1, 1, 1, device='cuda')
+    db = torch.zeros(cout, device='cuda')
+    monkeypatch.setattr(G.conv, 'WGRAD_PW', 2)           # few output tiles would go to the generic kernel by default
+    G.conv.conv_wgrad(G.cl.to_cl(x.cuda()), G.cl.to_cl(dy.cuda()), spec, dw, db)
+    assert G.hip.load_library().genie_last_conv_variant() == 13
+    torch.testing.assert_close(dw.cpu(), wt.grad, rtol=1e-3, atol=1e-3 * wt.grad.abs().max().item())
+    torch.testing.assert_close(db.cpu(), b.grad, rtol=1e-3, atol=1e-3 * b.grad.abs().max().item())
+    G.conv.conv_wgrad(G.cl.to_cl(x.cuda()), G.cl.to_cl(dy.cuda()), spec, dw, None)      # accumulates
+    torch.testing.assert_close(dw.cpu(), 2 * wt.grad, rtol=1e-3, atol=2e-3 * wt.grad.abs().max().item())
+
+
 TRI_WGRAD_CASES = [
     # cin, cout, kernel, causal, size (n, t, h, w), shuffle
     (64, 128, (3, 3, 3), False, (2, 4, 8, 8), None),
