@@ -351,8 +351,13 @@ __global__ void __launch_bounds__(512) wgrad3_kernel(const Wgrad3Args a) {
             const int co_nat = a.shuf_f > 1 ? ch * a.shuf_f + sub : co;
             float* row = a.dw + co_nat * a.s_cout + (long long)(3 * tr) * a.s_tap;
             if (ci < a.Cin) {
+                if (a.split_k == 1) {                           // one owner per element: plain read-modify-write (no atomics)
 #pragma unroll
-                for (int s = 0; s < 3; ++s) atomicAdd(row + s * a.s_tap + ci * a.s_cin, acc[s][i][r16]);
+                    for (int s = 0; s < 3; ++s) row[s * a.s_tap + ci * a.s_cin] += acc[s][i][r16];
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 3; ++s) atomicAdd(row + s * a.s_tap + ci * a.s_cin, acc[s][i][r16]);
+                }
             }
             if (do_bias && (lane & 31) == 0) atomicAdd(a.dbias + co_nat, accb[i][r16]);
         }
@@ -407,6 +412,8 @@ int genie_conv_wgrad3_try(const GenieWgradDesc* d, hipStream_t s) {
             const int want = (int)((256 + base - 1) / base);
             if (a.nchunks / want >= 16) sk = want;
         }
+        static const int small_sk1 = getenv("GENIE_W3_SMALL_SK1") ? atoi(getenv("GENIE_W3_SMALL_SK1")) : 0;
+        if (small_sk1 && base >= small_sk1) sk = 1;      // >= that many blocks without a split: one split, plain read-modify-write epilogue
         if (d->tri_mode == 1 && (base * sk < 200 || a.nchunks / sk < 16)) return 1;      // too little work: generic kernel (tri_mode 2 forces)
     }
     a.chunks_per_split = cdiv(a.nchunks, sk);
