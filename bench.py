@@ -118,10 +118,12 @@ def side_kernels():
             att[r['name']] = {'ms': r['ms'], 'tflops': r['tflops'], 'mfma_frac': r['mfma_frac']}
         elif r['section'] == 'hbm' and 'gbps' in r:
             hbm[r['name']] = {'ms': r['ms'], 'gbps': r['gbps'], 'hbm_frac': r['hbm_frac']}
+            if 'hbm_frac_min' in r:                      # against the operation's minimal traffic (1R + 1W forward, 2R + 1W backward)
+                hbm[r['name']].update({'gbps_min': r['gbps_min'], 'hbm_frac_min': r['hbm_frac_min']})
     best = max((v['mfma_frac'] for k, v in att.items() if 'fwd' in k), default=None)
     return {'st_attention': {'peak_tflops': BF16_MFMA_PEAK_TFLOPS, 'flop_count': 'dense 4 S^2 C per sequence forward, 2.5x that backward',
                              'best_fwd_mfma_frac': best, 'kernels': att},
-            'hbm_kernels': {'peak_gbps': 8000.0, 'bytes': 'algorithmic (stated per entry)', 'kernels': hbm}}
+            'hbm_kernels': {'peak_gbps': 8000.0, 'bytes': 'what the passes of the call move (stated per entry); *_min: the minimal traffic of the operation', 'kernels': hbm}}
 
 
 def main():

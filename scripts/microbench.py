@@ -50,7 +50,9 @@ def timeit(fn, iters, warm=5, reps=3):
     return best
 
 
-def report(section, name, ms, flops=None, bytes_=None, **extra):
+def report(section, name, ms, flops=None, bytes_=None, min_bytes=None, **extra):
+    """bytes_: what the kernels of this call move by construction; min_bytes: SURVEY.md 8(d)'s algorithmic minimum for the operation (one
+    read + one write for a normalisation forward; read x, read dy, write dx for its backward) -- reported as gbps_min / hbm_frac_min."""
     r = {'section': section, 'name': name, 'ms': round(ms, 5)}
     if flops is not None:
         r['tflops'] = round(flops / ms / 1e9, 2)
@@ -58,6 +60,9 @@ def report(section, name, ms, flops=None, bytes_=None, **extra):
     if bytes_ is not None:
         r['gbps'] = round(bytes_ / ms / 1e6, 1)
         r['hbm_frac'] = round(bytes_ / ms / 1e6 / PEAK_HBM, 4)
+    if min_bytes is not None:
+        r['gbps_min'] = round(min_bytes / ms / 1e6, 1)
+        r['hbm_frac_min'] = round(min_bytes / ms / 1e6 / PEAK_HBM, 4)
     r.update(extra)
     RESULTS.append(r)
     print(json.dumps(r), flush=True)
@@ -145,14 +150,14 @@ def bench_hbm(iters, quick=False):
         def f():
             nonlocal y
             y = GF.group_norm(x, g, gamma, beta, 1e-5, act=True)
-        report('hbm', f'GroupNorm+SiLU fwd C={c} {t}x{h}x{w} G={g} B={B} (alg: 2 reads + 1 write)', timeit(f, iters), bytes_=3 * nbytes)
+        report('hbm', f'GroupNorm+SiLU fwd C={c} {t}x{h}x{w} G={g} B={B} (alg: 2 reads + 1 write)', timeit(f, iters), bytes_=3 * nbytes, min_bytes=2 * nbytes)
         xr = x.detach().requires_grad_(True)
         yy = GF.group_norm(xr, g, gamma, beta, 1e-5, act=True)
         dy = rand_cl(B, c, t, h, w)
 
         def fb():
             torch.autograd.grad(yy, [xr], [dy], retain_graph=True)
-        report('hbm', f'GroupNorm+SiLU bwd C={c} {t}x{h}x{w} G={g} B={B} (alg: 4 reads + 1 write)', timeit(fb, iters), bytes_=5 * nbytes)
+        report('hbm', f'GroupNorm+SiLU bwd C={c} {t}x{h}x{w} G={g} B={B} (alg: 4 reads + 1 write)', timeit(fb, iters), bytes_=5 * nbytes, min_bytes=3 * nbytes)
         del x, xr, yy, dy, y
     # stem / head CausalConv3d
     from genie.module.video import CausalConv3d
