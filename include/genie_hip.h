@@ -308,6 +308,13 @@ int genie_conv_narrow_in(const void* src_cl, int src_pitch, const void* wpack, v
  * W a multiple of 32, H * W * 256 < 2^32. */
 int genie_conv_narrow_out(const void* src_cl, const void* wpack, const float* bias, void* dst_cl, int N, int T, int H, int W, int cout,
                           int t_lo, void* stream);
+/* Weight gradients of the two narrow convolutions above (stem 3 -> 128: big = output gradient, small = input, t_lo = -2, ones = 1;
+ * head 128 -> 3: big = input, small = output gradient, taps flipped by the caller, t_lo = 0): one pass over the 128-channel tensor.
+ * G: fp32 [128][128], ACCUMULATED (zero it first): G[ch][tap * 4 + c] = sum_pixels big[p][ch] * small[p + (t_lo + dt, dh - 1, dw - 1)][c]
+ * for tap = (dt * 3 + dh) * 3 + dw, c < 4 (channels >= small's real count read as stored: keep its pad channels zero); with ones = 1
+ * column 108 holds sum_pixels big[p][ch] (the bias gradient of the stem).  W in {32, 64, 128} (W = 32: even H). */
+int genie_conv_narrow_wgrad(const void* big_cl, const void* small_cl, int small_pitch, float* G, int N, int T, int H, int W, int t_lo,
+                            int ones, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Losses and optimiser (elementwise.hip).

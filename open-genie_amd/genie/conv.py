@@ -280,6 +280,7 @@ def pack_weight_bwd(weight: Tensor, spec: ConvSpec) -> Tensor:
 # HBM-bound narrow convolutions (conv_narrow.hip): <= 4 input channels -> 128 output channels, 3x3x3, stride 1 -- the tokenizer's
 # stem (video.py:154-192 via MAGVIT2_ENC_DESC[0]) and the backward-data pass of its head conv (128 -> 3)
 # ------------------------------------------------------------------------------------------------
+NARROW_WGRAD = os.environ.get('GENIE_NARROW_WGRAD', '1') != '0'
 NARROW_CONV = os.environ.get('GENIE_NARROW_CONV', '1') != '0'
 _NARROW_W = (32, 64, 128)
 
@@ -322,6 +323,41 @@ def pack_narrow_bwd(weight: Tensor) -> Tensor:
     """weight (cout <= 4, 128, 3, 3, 3) of the FORWARD conv -> pack of its backward-data pass: rows = input channels, taps flipped."""
     w = weight.detach().float().flip(2, 3, 4).permute(1, 2, 3, 4, 0).reshape(weight.shape[1], 27, weight.shape[0])
     return _narrow_pack(w, None)
+
+
+def narrow_wgrad_ok(spec: ConvSpec, x: Tensor, dy: Tensor) -> bool:
+    """Weight gradient of the stem ((<= 4) -> 128) or head (128 -> (<= 4)) conv on the one-pass narrow kernel?"""
+    if not (NARROW_CONV and NARROW_WGRAD and _narrow_geometry_ok(spec) and x.shape[4] in _NARROW_W and (x.shape[4] != 32 or x.shape[3] % 2 == 0)):
+        return False
+    if spec.cin <= 4 and spec.cout == 128:
+        return pitch_of(dy) == 128 and pitch_of(x) % 4 == 0
+    return spec.cin == 128 and spec.cout <= 4 and pitch_of(x) == 128 and pitch_of(dy) % 4 == 0
+
+
+def conv_narrow_wgrad(x: Tensor, dy: Tensor, spec: ConvSpec, dweight: Tensor, dbias: Optional[Tensor], label: str = '') -> None:
+    """dW (+ dbias) of a narrow conv accumulated from ONE pass over the 128-channel tensor (genie_conv_narrow_wgrad):
+    G[ch][tap * 4 + c] = sum_p big[p][ch] * small[p + tap][c].  Stem: big = dy, small = x, G[co][tap, ci] is dW[co][ci][tap] and column
+    108 the bias gradient.  Head: big = x, small = dy with the taps flipped, G[ci][tap', co] is dW[co][ci][2 - tap']."""
+    n, _, t, h, w = x.shape
+    G = torch.zeros((128, 128), dtype=torch.float32, device=x.device)
+    stem = spec.cin <= 4
+    big, small = (dy, x) if stem else (x, dy)
+    t_lo = -spec.pad_front[0] if stem else spec.pad_front[0] - 2
+    t0 = PROFILER.begin() if PROFILER is not None and not PROFILER.only_triple else None
+    _hip.check(_hip.load_library().genie_conv_narrow_wgrad(big.data_ptr(), small.data_ptr(), pitch_of(small), G.data_ptr(), n, t, h, w, int(t_lo),
+                                                           int(stem and dbias is not None), _hip.stream_ptr()), 'genie_conv_narrow_wgrad')
+    if t0 is not None:
+        PROFILER.end('conv_narrow_wgrad_kernel', label, 2.0 * n * t * h * w * 128 * min(spec.cin, spec.cout) * 27, t0)
+    taps = G[:, :108].view(128, 3, 3, 3, 4)
+    if stem:
+        dweight += taps[..., :spec.cin].permute(0, 4, 1, 2, 3)                  # (co, ci, dt, dh, dw)
+        if dbias is not None:
+            dbias += G[:, 108]
+    else:
+        dweight += taps[..., :spec.cout].flip(1, 2, 3).permute(4, 0, 1, 2, 3)   # (co, ci, dt, dh, dw) <- G[ci][2 - dt, 2 - dh, 2 - dw][co]
+        if dbias is not None:
+            rows = dy.permute(0, 2, 3, 4, 1).reshape(-1, dy.shape[1])             # a view of the CL tensor: (pixels, cout)
+            dbias += rows.sum(0, dtype=torch.float32)
 
 
 def narrow_out_ok(spec: ConvSpec, x: Tensor) -> bool:
@@ -577,6 +613,8 @@ def conv_wgrad(x: Tensor, dy: Tensor, spec: ConvSpec, dweight: Tensor, dbias: Op
     P, Q, R = spec.shuffle if spec.shuffle is not None else (1, 1, 1)
     assert tuple(dy.shape[2:]) == (to * P, ho * Q, wo * R)
     assert dweight.dtype == torch.float32 and tuple(dweight.shape) == (spec.cout, spec.cin, *spec.kernel)
+    if narrow_wgrad_ok(spec, x, dy):
+        return conv_narrow_wgrad(x, dy, spec, dweight, dbias, f'wgrad {spec.cin}->{spec.cout} k3 @{(t, h, w)}')
     s = dweight.stride()
     kt, kh, kw = spec.kernel
     if kt * kh * kw > 1 and not (s[3] == kw * s[4] and s[2] == kh * s[3]):

@@ -171,6 +171,16 @@ def bench_hbm(iters, quick=False):
                bytes_=npx * (8 + 128) * 2)
         report('hbm', f'head CausalConv3d 128->3 k3 B={B} fwd', timeit(lambda: head(feat), iters), flops=2.0 * npx * 128 * 3 * 27,
                bytes_=npx * (8 + 128) * 2)
+        # weight gradients of the two narrow convs: one pass over the 128-channel tensor (+ the 8-channel-pitch narrow one)
+        from genie.conv import conv_wgrad
+        gy = rand_cl(B, 128, 16, 64, 64)
+        dws = torch.zeros_like(stem.conv3d.weight); dbs = torch.zeros(128, device='cuda')
+        report('hbm', f'stem CausalConv3d 3->128 k3 B={B} wgrad', timeit(lambda: conv_wgrad(vid, gy, stem.conv3d.spec, dws, dbs), iters),
+               flops=2.0 * npx * 128 * 3 * 27, bytes_=npx * (8 + 128) * 2)
+        g3 = to_cl(torch.randn(B, 3, 16, 64, 64, device='cuda'))
+        dwh = torch.zeros_like(head.conv3d.weight); dbh = torch.zeros(3, device='cuda')
+        report('hbm', f'head CausalConv3d 128->3 k3 B={B} wgrad', timeit(lambda: conv_wgrad(feat, g3, head.conv3d.spec, dwh, dbh), iters),
+               flops=2.0 * npx * 128 * 3 * 27, bytes_=npx * (8 + 128) * 2)
     if quick:
         return
     # layout conversion + mse

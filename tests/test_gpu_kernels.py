@@ -441,6 +441,38 @@ def test_conv_wgrad_pointwise_kernel(G, cin, cout, size, monkeypatch):
     torch.testing.assert_close(dw.cpu(), 2 * wt.grad, rtol=1e-3, atol=2e-3 * wt.grad.abs().max().item())
 
 
+@pytest.mark.parametrize('cin,cout,causal,size', [(3, 128, True, (2, 5, 10, 64)), (4, 128, False, (1, 3, 8, 32)), (1, 128, True, (1, 2, 4, 128)),
+                                                  (128, 3, True, (2, 4, 9, 64)), (128, 2, False, (1, 3, 6, 32)), (128, 1, True, (1, 2, 5, 128)),
+                                                  (3, 128, True, (4, 16, 64, 64)), (128, 3, True, (4, 16, 64, 64))])
+def test_conv_narrow_wgrad_kernel(G, cin, cout, causal, size):
+    """conv_narrow.hip, weight gradients of the stem ((<= 4) -> 128) and head (128 -> (<= 4)) convolutions in ONE pass over the
+    128-channel tensor (im2col tile of the narrow tensor built in LDS, transposing reads on both MFMA operands), against autograd of
+    the fp32 convolution: causal and symmetric padding, every supported width, bias gradients, accumulation into non-zero buffers."""
+    from oracle import genie_oracle as O
+    torch.manual_seed(21)
+    n, t, h, w = size
+    x = bf16_round(torch.randn(n, cin, t, h, w))
+    wt = torch.randn(cout, cin, 3, 3, 3, requires_grad=True)
+    b = torch.randn(cout, requires_grad=True)
+    ref = O.causal_conv3d(x, wt, b) if causal else F.conv3d(x, wt, b, padding=1)
+    dy = bf16_round(torch.randn_like(ref))
+    ref.backward(dy)
+    spec = G.conv.causal_spec(cin, cout, (3, 3, 3)) if causal else G.conv.same_spec(cin, cout, (3, 3, 3))
+    xc, dyc = G.cl.to_cl(x.cuda()), G.cl.to_cl(dy.cuda())
+    assert G.conv.narrow_wgrad_ok(spec, xc, dyc)
+    dw = torch.full((cout, cin, 3, 3, 3), 0.5, device='cuda').contiguous(memory_format=torch.channels_last_3d)
+    db = torch.full((cout,), -1.0, device='cuda')
+    G.conv.PROFILER = prof = G.conv.LaunchProfiler()
+    try:
+        G.conv.conv_wgrad(xc, dyc, spec, dw, db)
+    finally:
+        G.conv.PROFILER = None
+    assert 'conv_narrow_wgrad_kernel' in prof.summary(), list(prof.summary())
+    sw, sb = wt.grad.abs().max().item(), b.grad.abs().max().item()
+    torch.testing.assert_close(dw.cpu() - 0.5, wt.grad, rtol=1e-3, atol=1e-3 * sw)
+    torch.testing.assert_close(db.cpu() + 1.0, b.grad, rtol=1e-3, atol=1e-3 * sb)
+
+
 TRI_WGRAD_CASES = [
     # cin, cout, kernel, causal, size (n, t, h, w), shuffle
     (64, 128, (3, 3, 3), False, (2, 4, 8, 8), None),
