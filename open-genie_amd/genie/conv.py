@@ -356,8 +356,9 @@ def conv_narrow_wgrad(x: Tensor, dy: Tensor, spec: ConvSpec, dweight: Tensor, db
     else:
         dweight += taps[..., :spec.cout].flip(1, 2, 3).permute(4, 0, 1, 2, 3)   # (co, ci, dt, dh, dw) <- G[ci][2 - dt, 2 - dh, 2 - dw][co]
         if dbias is not None:
-            rows = dy.permute(0, 2, 3, 4, 1).reshape(-1, dy.shape[1])             # a view of the CL tensor: (pixels, cout)
-            dbias += rows.sum(0, dtype=torch.float32)
+            cp = pitch_of(dy)
+            rows = dy.as_strided((n * t * h * w, cp), (cp, 1))                     # the CL storage as (pixels, channel pitch): a view
+            dbias += rows.sum(0, dtype=torch.float32)[:spec.cout]
 
 
 def narrow_out_ok(spec: ConvSpec, x: Tensor) -> bool:
