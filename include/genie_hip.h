@@ -45,6 +45,10 @@ const char* genie_last_error(void);
  * ------------------------------------------------------------------------------------------- */
 int genie_to_channels_last(const void* src, int src_dtype, const int64_t* dims, const int64_t* strides,
                            void* dst_cl, int cpitch, void* stream);
+/* Inverse depth-to-space-time on a CL tensor: src CL [N][T P][H Q][W R][src_pitch] with cf % 8 == 0 channels -> dst CL
+ * [N][T][H][W][P Q R cf], channel ((p Q + q) R + r) cf + c (sub-pixel-major).  replaces: the inverse of video.py:403-408's rearrange
+ * in the backward-data pass of DepthToSpaceTimeUpsample. */
+int genie_unshuffle_cl(const void* src_cl, int src_pitch, void* dst_cl, int N, int T, int H, int W, int cf, int P, int Q, int R, void* stream);
 int genie_from_channels_last(const void* src_cl, int cpitch, const int64_t* dims, void* dst, int dst_dtype,
                              const int64_t* strides, void* stream);
 

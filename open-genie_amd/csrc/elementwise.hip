@@ -101,6 +101,38 @@ extern "C" int genie_to_channels_last(const void* src, int src_dtype, const int6
     return GENIE_OK;
 }
 
+// Inverse of the depth-to-space-time rearrange on a CL tensor (reference video.py:403-408 'b (c p q r) t h w -> b c (t p)(h q)(w r)'):
+// src CL [N][T P][H Q][W R][sp] (cf channels) -> dst CL [N][T][H][W][P Q R cf], channel ((p Q + q) R + r) cf + c -- the sub-pixel-major
+// order of the transposed weight pack, so that the backward-data pass of an upsample conv becomes a PLAIN conv over dst (kw-triple
+// kernels) instead of a gather through the shuffle.  One 16-byte chunk per thread; reads and writes are whole cf * 2-byte runs.
+__global__ void __launch_bounds__(256) unshuffle_cl_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int N, int T, int H, int W,
+                                                            int cf, int sp, int P, int Q, int R, long long total) {
+    const int cc = cf / 8, sub = P * Q * R;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c8 = (int)(i % cc);
+        long long j = i / cc;
+        const int s = (int)(j % sub); j /= sub;
+        const int w = (int)(j % W); j /= W;
+        const int h = (int)(j % H); j /= H;
+        const int t = (int)(j % T);
+        const int n = (int)(j / T);
+        const int r = s % R, q = (s / R) % Q, p = s / (R * Q);
+        const long long so = ((((long long)n * T * P + (t * P + p)) * (H * Q) + (h * Q + q)) * (long long)(W * R) + (w * R + r)) * sp + c8 * 8;
+        *reinterpret_cast<u32x4_t*>(dst + i * 8) = *reinterpret_cast<const u32x4_t*>(src + so);
+    }
+}
+
+extern "C" int genie_unshuffle_cl(const void* src_cl, int src_pitch, void* dst_cl, int N, int T, int H, int W, int cf, int P, int Q, int R,
+                                  void* stream) {
+    GENIE_CHECK_ARG(src_cl && dst_cl, "genie_unshuffle_cl: null pointer");
+    GENIE_CHECK_ARG(cf >= 8 && cf % 8 == 0 && src_pitch >= cf && src_pitch % 8 == 0, "genie_unshuffle_cl: channels %d (pitch %d) must be a multiple of 8", cf, src_pitch);
+    GENIE_CHECK_ARG(N >= 1 && T >= 1 && H >= 1 && W >= 1 && P >= 1 && Q >= 1 && R >= 1, "genie_unshuffle_cl: bad geometry");
+    const long long total = (long long)N * T * H * W * P * Q * R * (cf / 8);
+    unshuffle_cl_kernel<<<ew_grid(total), 256, 0, (hipStream_t)stream>>>((const bf16_t*)src_cl, (bf16_t*)dst_cl, N, T, H, W, cf, src_pitch, P, Q, R, total);
+    GENIE_CHECK_LAUNCH();
+    return GENIE_OK;
+}
+
 extern "C" int genie_from_channels_last(const void* src, int cpitch, const int64_t* dims, void* dst, int dst_dtype,
                                         const int64_t* strides, void* stream) {
     GENIE_CHECK_ARG(src && dst && dims && strides, "genie_from_channels_last: null pointer");

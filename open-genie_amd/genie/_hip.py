@@ -69,6 +69,7 @@ SIGNATURES = {
     'genie_abi_version': (C.c_int, []),
     'genie_last_error': (C.c_char_p, []),
     'genie_to_channels_last': (C.c_int, [_P, _I, _PL, _PL, _P, _I, _P]),
+    'genie_unshuffle_cl': (C.c_int, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     'genie_from_channels_last': (C.c_int, [_P, _I, _PL, _P, _I, _PL, _P]),
     'genie_conv_igemm': (C.c_int, [C.POINTER(GenieConvDesc), _P]),
     'genie_conv_narrow_in': (C.c_int, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P]),

@@ -184,8 +184,9 @@ def test_conv_forward_dgrad(G, cin, cout, kernel, stride, causal, size):
     assert torch.equal(G.conv.pack_weight_fwd(wcl, spec), wf)
 
 
-@pytest.mark.parametrize('cin,cf,fac,size', [(64, 32, (2, 2, 2), (1, 2, 4, 4)), (128, 64, (1, 2, 2), (2, 2, 3, 5)), (64, 3, (1, 4, 4), (1, 2, 4, 4))])
-def test_conv_shuffle_forward_dgrad(G, cin, cf, fac, size):
+@pytest.mark.parametrize('cin,cf,fac,size', [(64, 32, (2, 2, 2), (1, 2, 4, 4)), (128, 64, (1, 2, 2), (2, 2, 3, 5)), (64, 3, (1, 4, 4), (1, 2, 4, 4)),
+                                             (256, 32, (2, 2, 2), (1, 2, 4, 8))])
+def test_conv_shuffle_forward_dgrad(G, cin, cf, fac, size, monkeypatch):
     from oracle import genie_oracle as O
     torch.manual_seed(4)
     n, t, h, w = size
@@ -205,6 +206,10 @@ def test_conv_shuffle_forward_dgrad(G, cin, cf, fac, size):
     wb = G.conv.pack_weight_bwd(wt.cuda(), spec)          # cf % 8 != 0 takes the un-shuffle path
     dx = G.conv.conv_dgrad(G.cl.to_cl(dy.cuda()), wb, spec, (t, h, w))
     assert_close_bf16(dx, xr.grad, 'shuffle dgrad')
+    # the two routes of the backward-data pass: gather through the shuffle (generic kernel) vs genie_unshuffle_cl + plain conv
+    monkeypatch.setattr(G.conv, 'UPCONV_DGRAD_UNSHUFFLE', not G.conv.UPCONV_DGRAD_UNSHUFFLE)
+    dx2 = G.conv.conv_dgrad(G.cl.to_cl(dy.cuda()), wb, spec, (t, h, w))
+    assert_close_bf16(dx2, xr.grad, 'shuffle dgrad (other route)')
 
 
 TRI_CASES = [
