@@ -330,9 +330,10 @@ static int launch_wgrad(WgradArgs& a, hipStream_t s) {
         const int max_sk = (a.nchunks + 7) / 8;          // keep >= 8 chunks (512 pixels) per block
         sk = 1;
         if (a.ntaps == 1) {
-            // 1x1x1 convs stream x and dy exactly once (HBM-bound): measured best at ~256 blocks in total -- every extra split
-            // adds a BM x BN fp32 tile of atomics (128->128 @16x64x64, B = 8: 0.094 ms at 1024 splits, 0.065 ms at 256)
-            const int cand = (int)(256 / base);
+            // 1x1x1 convs stream x and dy exactly once (HBM-bound): every extra split adds a BM x BN fp32 tile of atomics (128->128
+            // @16x64x64, B = 8: 0.094 ms at 1024 splits, 0.065 ms at 256); at 64 clips 512 blocks win (step 517.2 -> 515.1 ms)
+            static const int pw_blocks = getenv("GENIE_WGRAD_PW1_BLOCKS") ? atoi(getenv("GENIE_WGRAD_PW1_BLOCKS")) : 512;
+            const int cand = (int)(pw_blocks / base);
             sk = cand >= 1 ? (cand < max_sk ? cand : max_sk) : 1;
         } else
         for (int rounds = 3; rounds >= 1; --rounds) {
