@@ -29,7 +29,8 @@ struct GnGeom {
 static GnGeom gn_geom(int N, long long npix, int C, int Cp, int G) {
     GnGeom g;
     g.N = N; g.C = C; g.Cp = Cp; g.G = G; g.CH = Cp / 8; g.npix = npix;
-    long long want = (2048 + N - 1) / N;                 // ~2048 blocks in flight over the whole batch
+    static const long long gn_blocks = getenv("GENIE_GN_BLOCKS") ? atoll(getenv("GENIE_GN_BLOCKS")) : 2048;
+    long long want = (gn_blocks + N - 1) / N;            // ~2048 blocks in flight over the whole batch
     long long by_size = (npix * g.CH + 2047) / 2048;     // at least ~8 x 16 B per thread
     long long nb = want < by_size ? want : by_size;
     if (nb > GN_MAX_BLK) nb = GN_MAX_BLK;
