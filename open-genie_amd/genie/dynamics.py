@@ -86,16 +86,22 @@ class DynamicsModel(nn.Module):
         # the compact rows are laid out as a (t, h, 256) grid for the gather-GEMM (every axis < 1024); the few pad rows re-read row 0
         # and are switched off in the cross-entropy (zero loss, zero gradient)
         r = rows.numel()
-        k = (r + 255) // 256
-        gh = k if k <= 512 else 512
-        gt = (k + gh - 1) // gh
-        rp = gt * gh * 256
+        gt, gh, rp = self._compact_grid(r)
         if rp != r:
             rows = torch.cat([rows, rows.new_zeros(rp - r)])
         valid = None if rp == r else (torch.arange(rp, device=rows.device) < r)
         xc = x.reshape(-1, d).index_select(0, rows).view(1, gt, gh, 256, d)
         logits = self._head(xc)                                                # (1, gt, gh, 256, V)
         return GF.masked_cross_entropy(logits, tokens.reshape(-1).index_select(0, rows).view(1, gt, gh, 256), valid)
+
+    @staticmethod
+    def _compact_grid(r: int):
+        """(t, h, padded rows) of the (t, h, 256) grid that holds r >= 1 gathered rows: every axis stays below the 1024 the gather-GEMM's
+        row decomposition allows, at most 255 pad rows up to 131072 rows (512 * 256 - 1 beyond)."""
+        k = (r + 255) // 256
+        gh = k if k <= 512 else 512
+        gt = (k + gh - 1) // gh
+        return gt, gh, gt * gh * 256
 
     def _last_frame_logits(self, tokens: Tensor, act_id: Tensor) -> Tensor:
         """logits[:, -1] of ``forward`` -- (B, h, w, V) bf16 -- with the vocabulary head applied to the last frame only (the head is

@@ -164,3 +164,14 @@ def test_pointwise_spec_detection():
     assert not conv._is_pointwise(conv.causal_spec(128, 256, (1, 1, 1), stride=(1, 2, 2)))
     assert not conv._is_pointwise(conv.causal_spec(64, 64 * 8, (1, 1, 1), shuffle=(2, 2, 2)))
     assert not conv._is_pointwise(conv.causal_spec(64, 64, (2, 1, 1)))          # causal front padding in time
+
+
+def test_dynamics_compact_row_grid():
+    """DynamicsModel.compute_loss lays the gathered masked rows out as a (t, h, 256) grid for the vocabulary head: the grid must hold
+    every row, keep each axis under the kernels' 1024 limit, and pad little."""
+    from genie.dynamics import DynamicsModel
+    for r in (1, 255, 256, 257, 3072, 4096, 131072, 131073, 1 << 20, 50_000_000):
+        gt, gh, rp = DynamicsModel._compact_grid(r)
+        assert rp == gt * gh * 256 and rp >= r
+        assert 1 <= gt < 1024 and 1 <= gh < 1024
+        assert rp - r < (256 if r <= 131072 else 512 * 256)
