@@ -175,7 +175,9 @@ def main(kind: str, argv=None) -> int:
     from .trainer import Trainer
     trainer = Trainer(**(cfg.get('trainer') or {}))
     if cfg['_command'] == 'fit':
-        trainer.fit(model, data)
+        # `ckpt_path` (LightningCLI's `fit --ckpt_path`): resume weights, AdamW moments and the step counter from a last.ckpt;
+        # replicas are synchronised from rank 0 and then reseeded per rank (seed_everything + rank)
+        trainer.fit(model, data, ckpt_path=cfg.get('ckpt_path'), seed=int(cfg.get('seed_everything', 0)))
     else:
         from .trainer import DataParallel
         model.to('cuda')

@@ -149,6 +149,17 @@ TRI_FLAGS = int(os.environ.get('GENIE_TRI_FLAGS', '0'))
 TRI_WGRAD = int(os.environ.get('GENIE_TRI_WGRAD', '1'))          # conv_wgrad3.hip: 0 never, 1 when it pays, 2 whenever eligible
 _tri_cache = {}
 FORCE_SPLIT_K = 0                   # experiments only: split-K factor handed to genie_conv_wgrad (0 = library chooses)
+# GENIE_DETERMINISTIC=1 (or conv.set_deterministic(True)): weight gradients with ONE K split per output tile -- a single owner adds each
+# element in a fixed order, so they are bit-reproducible run to run (the default split-K partial sums meet in fp32 atomics whose
+# order the hardware picks: reproducible to ~1e-6 relative, tests/test_gpu_properties.py::test_gradient_determinism).  Slower (the
+# low-resolution layers lose their parallelism); the stem / head weight gradients go through the generic kernel in this mode.
+DETERMINISTIC = os.environ.get('GENIE_DETERMINISTIC', '0') not in ('0', '')
+
+
+def set_deterministic(on: bool) -> bool:
+    global DETERMINISTIC
+    old, DETERMINISTIC = DETERMINISTIC, bool(on)
+    return old
 
 
 def tri_rows(taps, hs: int, ws: int, cs: int):
@@ -328,7 +339,7 @@ def pack_narrow_bwd(weight: Tensor) -> Tensor:
 
 def narrow_wgrad_ok(spec: ConvSpec, x: Tensor, dy: Tensor) -> bool:
     """Weight gradient of the stem ((<= 4) -> 128) or head (128 -> (<= 4)) conv on the one-pass narrow kernel?"""
-    if not (NARROW_CONV and NARROW_WGRAD and _narrow_geometry_ok(spec) and x.shape[4] in _NARROW_W and (x.shape[4] != 32 or x.shape[3] % 2 == 0)):
+    if not (NARROW_CONV and NARROW_WGRAD and not DETERMINISTIC and _narrow_geometry_ok(spec) and x.shape[4] in _NARROW_W and (x.shape[4] != 32 or x.shape[3] % 2 == 0)):
         return False
     if spec.cin <= 4 and spec.cout == 128:
         return pitch_of(dy) == 128 and pitch_of(x) % 4 == 0
@@ -643,7 +654,7 @@ def conv_wgrad(x: Tensor, dy: Tensor, spec: ConvSpec, dweight: Tensor, dbias: Op
     else:
         d.shuf_c, d.shuf_q, d.shuf_r = spec.cout, 1, 1
     d.s_cout, d.s_tap, d.s_cin = s[0], s[4], s[1]
-    d.split_k = FORCE_SPLIT_K
+    d.split_k = 1 if DETERMINISTIC else FORCE_SPLIT_K
     d.tri_mode = TRI_WGRAD if (TRI_WGRAD and spec.stride == (1, 1, 1) and spec.kernel[2] == 3 and spec.dilation[2] == 1
                        and spec.pad_front[2] == 1 and spec.pad_back[2] == 1 and (to, ho, wo) == (t, h, w)) else 0
     d.pointwise = WGRAD_PW if _is_pointwise(spec) else 0

@@ -587,6 +587,8 @@ def maskgit_sample(logits: Tensor, u: Tensor, temp: float = 1.):
     inside a sample; u: (B * n,) uniforms in [0, 1).  Returns (pred int64 (B, n), conf fp32 (B, n)): the inverse-CDF draw from
     softmax(logits / temp) and its probability (reference dynamics.py:138-143 with injected noise)."""
     _hip.require_gpu(logits, 'maskgit_sample')
+    if logits.dtype not in (torch.bfloat16, torch.float32):
+        logits = logits.float()            # FIRST: the conversion re-packs a strided view, pitches are read from the result (ADVICE r2)
     if logits.dim() == 4:
         b, h, w, v = logits.shape
         if h > 1 and w > 1 and logits.stride(1) != w * logits.stride(2):
@@ -595,8 +597,6 @@ def maskgit_sample(logits: Tensor, u: Tensor, temp: float = 1.):
     else:
         b, n, v = logits.shape
         pitch = logits.stride(1)
-    if logits.dtype not in (torch.bfloat16, torch.float32):
-        logits = logits.float()
     if (v > 1 and logits.stride(-1) != 1) or (n > 1 and pitch < v):
         logits = logits.reshape(b, n, v).contiguous()
         pitch = v

@@ -58,13 +58,16 @@ class Genie(LightningModule):
 
     # -- helpers ---------------------------------------------------------------------------------------------------------------
     def _token_grid(self, video: Tensor) -> Tensor:
-        """(B, t', h', w') int64 token indices of a clip; the reference's ``idxs.squeeze()`` drops a batch of one, put it back."""
-        _, idxs = self.tokenizer.tokenize(video)
-        if idxs.dim() == 3:
-            idxs = idxs.unsqueeze(0)
-        if idxs.dim() != 4:
-            raise ValueError(f'Genie works on one-codebook tokenizers with (B, t, h, w) index grids; got {tuple(idxs.shape)}')
-        return idxs
+        """(B, t', h', w') int64 token indices of a clip.  The reference's ``idxs.squeeze()`` (quantization.py:110) drops EVERY size-1
+        axis -- a batch of one, but also a single latent frame (an image prompt) -- so the grid is rebuilt from the quantised latent's
+        shape (B, d, t', h', w') instead of guessed from ``idxs.dim()``."""
+        quant, idxs = self.tokenizer.tokenize(video)
+        if self.tokenizer.quant.num_codebooks != 1 or quant.dim() != 5:
+            raise ValueError(f'Genie works on one-codebook tokenizers with (B, d, t, h, w) latents; got {tuple(quant.shape)} / {tuple(idxs.shape)}')
+        grid = (quant.shape[0], *quant.shape[2:])
+        if idxs.numel() != grid[0] * grid[1] * grid[2] * grid[3]:
+            raise ValueError(f'token indices {tuple(idxs.shape)} do not fill the latent grid {grid}')
+        return idxs.reshape(grid)
 
     def _codes(self, tokens: Tensor) -> Tensor:
         """token indices (B, t, h, w) -> the {-1, +1} latent (B, d, t, h, w) the decoder consumes (MSB-first bits, quantization.py:72)."""
@@ -99,8 +102,7 @@ class Genie(LightningModule):
     def compute_loss(self, video: Tensor):
         tokens = self._token_grid(video)                                        # frozen tokenizer, no graph
         act_id, act_loss, (act_rec_loss, act_q_loss) = self.latent_action(video)
-        if act_id.dim() == 1:
-            act_id = act_id.unsqueeze(0)
+        act_id = act_id.reshape(video.shape[0], video.shape[2])                 # (LFQ's squeeze() drops a batch / a clip of one)
         tf = video.shape[2] // tokens.shape[1]                                  # the tokenizer's time compression
         if tf < 1 or tf * tokens.shape[1] != video.shape[2]:
             raise ValueError(f'{video.shape[2]} video frames do not map onto {tokens.shape[1]} latent frames')

@@ -149,8 +149,10 @@ class VideoTokenizer(LightningModule):
         self.save_hyperparameters()
 
     def forward_order(self):
-        """Sub-modules in execution order (trainer.execution_order lays the parameter arena out this way)."""
-        return [self.enc_layers, self.quant, self.dec_layers, self.gan_crit]
+        """Sub-modules in execution order (trainer.execution_order lays the parameter arena out this way).  The GAN critic is NOT listed:
+        its `dis_loss` branch is detached from the reconstruction, so no tensor hook can tell when its gradients are complete; unlisted
+        parameters are laid out first and reduced last, by DataParallel.finish(), when every gradient is known to exist."""
+        return [self.enc_layers, self.quant, self.dec_layers]
 
     def encode(self, video: Tensor, cond: Tensor | None = None) -> Tensor:
         return run_layers(self.enc_layers, self.enc_ext, video, cond)

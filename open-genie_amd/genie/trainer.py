@@ -265,6 +265,8 @@ class DataParallel:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
         self._done = [False] * len(self.buckets)
         self.last_fired, self.fired = self.fired, []
+        if hasattr(self, 'armed'):
+            self.last_armed, self.armed = self.armed, []
 
     def reduce_scalars(self, values: Sequence[Tensor]) -> Tensor:
         """One all-reduce for all logged scalars of a step (mean over ranks)."""
@@ -297,6 +299,7 @@ class DataParallel:
         self.buckets = list(zip(cuts[:-1], cuts[1:]))
         self._done = [False] * len(self.buckets)
         index_of = {lo: i for i, (lo, _) in enumerate(self.buckets)}
+        self.armed: List[int] = []                       # buckets whose early-reduction hook was registered in the current step
         for off, mod in pairs:
             if off not in index_of:
                 continue
@@ -304,10 +307,39 @@ class DataParallel:
 
             def pre_hook(_m, args, idx=idx):
                 x = args[0] if args else None
-                if isinstance(x, Tensor) and x.requires_grad:
+                if isinstance(x, Tensor) and x.requires_grad and idx not in self.armed:
+                    self.armed.append(idx)
                     x.register_hook(lambda g, idx=idx: self.bucket_ready(idx))
 
-            self._hooks.append(mod.register_forward_pre_hook(pre_hook))
+            # a stage that is a container (nn.ModuleList iterated by the model's own loop, e.g. VideoTokenizer.enc_layers / dec_layers) is
+            # never CALLED, so a pre-hook on it would never fire: hook the module that actually receives the stage's input.
+            # A stage whose input carries no gradient (integer tokens) or that is entered through another method than __call__ simply
+            # stays un-armed in that step and is reduced by finish() -- late, never early.
+            self._hooks.append(self.entry_module(mod).register_forward_pre_hook(pre_hook))
+
+    @staticmethod
+    def entry_module(mod: nn.Module) -> nn.Module:
+        """The sub-module that receives a stage's input: descends through containers that have no forward of their own."""
+        while isinstance(mod, (nn.ModuleList, nn.ModuleDict)) and len(mod) > 0:
+            mod = mod[0] if isinstance(mod, nn.ModuleList) else next(iter(mod.values()))
+        return mod
+
+
+def sync_replicas(arena: ParamArena, model: nn.Module, group=None, seed: Optional[int] = None) -> None:
+    """Make every rank start from rank 0's weights and buffers (what Lightning's DDP strategy -- the reference's
+    ``strategy: ddp``, config/tokenize.yaml:77 -- does when it wraps the module), then give each rank its OWN random stream
+    (seed + rank) so that per-rank stochastic operations (MaskGIT Bernoulli masks, GAN frame picks, synthetic clips) differ across
+    ranks.  Without the broadcast, replica equality would rest on every rank having seeded identically before building the model
+    (ADVICE r2).  Call BEFORE ``arena.attach_weight_packs`` (the bf16 mirror is built from the arena)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) < 2:
+        return
+    dist.broadcast(arena.params, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    for b in model.buffers():
+        if b.numel():
+            dist.broadcast(b, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    torch.autograd.graph.increment_version(arena._plist)
+    if seed is not None:
+        torch.manual_seed(int(seed) + dist.get_rank(group))
 
 
 def shard_clips(num_clips: int, rank: int, world: int) -> range:
@@ -364,39 +396,83 @@ class Trainer:
         model.train()
         self._log(model, dp, 'val')
 
-    def save_last(self, model) -> str:
+    def save_last(self, model, arena: Optional[ParamArena] = None, hp: Optional[dict] = None, epoch: int = 0) -> str:
+        """``last.ckpt`` in the layout of a Lightning checkpoint (``ModelCheckpoint(save_last=True)`` of the reference's config,
+        config/tokenize.yaml:80-86): ``state_dict``, ``global_step``, ``epoch`` and ``optimizer_states`` -- AdamW's step / exp_avg /
+        exp_avg_sq per parameter (keyed by parameter NAME, so a resume does not depend on the arena layout) -- which is what makes the
+        run resumable (``fit(ckpt_path=...)``).  Tensors are copied to the host one at a time."""
         import os
         path = os.path.join(self.default_root_dir, 'last.ckpt')
         if not dist.is_initialized() or dist.get_rank() == 0:
             os.makedirs(self.default_root_dir, exist_ok=True)
-            torch.save({'state_dict': {k: v.detach().cpu() for k, v in model.state_dict().items()}, 'global_step': self.global_step}, path)
+            ck = {'state_dict': {k: v.detach().cpu() for k, v in model.state_dict().items()}, 'global_step': self.global_step, 'epoch': epoch,
+                  'loops': {'batches_done_in_epoch': getattr(self, '_batches_done', 0)}, 'genie_runtime': 'genie-mi355x'}
+            if arena is not None:
+                state = {}
+                for name, (off, n) in arena.slots.items():
+                    state[name] = {'step': arena.step_count, 'exp_avg': arena.exp_avg[off:off + n].cpu(), 'exp_avg_sq': arena.exp_avg_sq[off:off + n].cpu()}
+                ck['optimizer_states'] = [{'state': state, 'param_groups': [dict(hp or {}, params=list(arena.slots))]}]
+            torch.save(ck, path)
         return path
 
-    def fit(self, model, datamodule) -> 'Trainer':
+    @staticmethod
+    def load_checkpoint(path: str, model, arena: ParamArena) -> dict:
+        """Restore parameters (through the arena views), buffers and the AdamW moments saved by ``save_last``; returns the checkpoint."""
+        ck = torch.load(path, map_location='cpu')
+        model.load_state_dict(ck['state_dict'])                     # copies INTO the arena views (p.data are views)
+        torch.autograd.graph.increment_version(arena._plist)
+        opt = ck.get('optimizer_states')
+        if opt:
+            state = opt[0]['state']
+            for name, (off, n) in arena.slots.items():
+                st = state.get(name)
+                if st is None:
+                    raise KeyError(f'checkpoint has no optimiser state for {name}')
+                arena.exp_avg[off:off + n].copy_(st['exp_avg'].reshape(-1))
+                arena.exp_avg_sq[off:off + n].copy_(st['exp_avg_sq'].reshape(-1))
+                arena.step_count = int(st['step'])
+        return ck
+
+    def fit(self, model, datamodule, ckpt_path: Optional[str] = None, seed: Optional[int] = None) -> 'Trainer':
+        """`ckpt_path`: resume from a ``last.ckpt`` (weights, AdamW moments, step counter).  `seed`: after the replicas have been
+        synchronised each rank reseeds with seed + rank."""
         from .module.data import DevicePrefetcher
         dev = torch.device('cuda', torch.cuda.current_device())
         model.to(dev).train()
         datamodule.setup('fit')
         hp = self._adamw_hparams(model)
         arena = ParamArena(model)
+        start_epoch, skip = 0, 0
+        if ckpt_path:
+            ck = self.load_checkpoint(ckpt_path, model, arena)
+            self.global_step, start_epoch = int(ck.get('global_step', 0)), int(ck.get('epoch', 0))
+            skip = int((ck.get('loops') or {}).get('batches_done_in_epoch', 0))
+        sync_replicas(arena, model, seed=seed)
         arena.attach_weight_packs(model)
+        self.arena = arena
         dp = DataParallel(arena.grads, compress=self.grad_compress)
         if dp.active and hasattr(model, 'forward_order'):
             # one bucket per top-level stage that owns parameters; the first stage's bucket is reduced by finish()
             stages = [m for m in model.forward_order() if any(p.requires_grad for p in m.parameters())]
             if len(stages) > 1:
                 dp.install_overlap_hooks(arena, model, stages[1:])
-        done = False
-        for epoch in range(self.max_epochs):
+        done = self.max_steps is not None and self.global_step >= self.max_steps
+        epoch = start_epoch
+        for epoch in range(start_epoch, self.max_epochs if not done else start_epoch):
             loader = datamodule.train_dataloader()
             if hasattr(getattr(loader, 'sampler', None), 'set_epoch'):
                 loader.sampler.set_epoch(epoch)
+            self._batches_done = 0
             for i, batch in enumerate(DevicePrefetcher(loader)):
+                if epoch == start_epoch and i < skip:             # resumed mid-epoch: these batches were consumed before the checkpoint
+                    self._batches_done = i + 1
+                    continue
                 loss = model.training_step(batch, i)
                 loss.backward()
                 dp.finish()
                 arena.adamw_step(**hp)
                 self.global_step += 1
+                self._batches_done = i + 1
                 if self.global_step % self.log_every_n_steps == 0:
                     self._log(model, dp, 'train')
                 if self.val_check_interval and self.global_step % self.val_check_interval == 0:
@@ -407,5 +483,5 @@ class Trainer:
             if done:
                 break
         self._log(model, dp, 'train')
-        self.save_last(model)
+        self.save_last(model, arena, hp, epoch)
         return self

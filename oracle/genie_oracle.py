@@ -46,6 +46,79 @@ def _get(sd: SD, key: str) -> Optional[Tensor]:
 
 
 # ----------------------------------------------------------------------------------------------
+# Optional bf16 emulation of the HIP path's STORES (test infrastructure; off by default)
+# ----------------------------------------------------------------------------------------------
+# The reference computes in fp32 throughout.  The HIP path computes every operator in fp32 too, but keeps activations and
+# activation gradients in HBM as bf16: one rounding where a kernel stores its result.  With ``set_rounding('bf16_at_stores')``
+# the oracle rounds at exactly those places -- forward values at every operator output the HIP path stores (`_st`), and the
+# gradient that an operator's backward kernel stores for its input (`_gr`) -- and nowhere else (statistics, softmax, losses and
+# parameter gradients stay fp32, as in the kernels).  The model-level parity tests compare the HIP path with THIS mode so that
+# their tolerance measures implementation error, not the (expected, much larger) bf16-vs-fp32 representation error; the fp32
+# numbers are still reported next to it.  ``None`` (default) is the reference's arithmetic, bit for bit what it was.
+_ROUNDING: Optional[str] = None
+
+
+def set_rounding(mode: Optional[str]) -> Optional[str]:
+    """mode: None (fp32 reference arithmetic) or 'bf16_at_stores'.  Returns the previous mode."""
+    global _ROUNDING
+    if mode not in (None, 'bf16_at_stores'):
+        raise ValueError(f'unknown rounding mode {mode!r}')
+    old, _ROUNDING = _ROUNDING, mode
+    return old
+
+
+class rounding:
+    """``with rounding('bf16_at_stores'): ...``"""
+
+    def __init__(self, mode: Optional[str]):
+        self.mode = mode
+
+    def __enter__(self):
+        self.old = set_rounding(self.mode)
+        return self
+
+    def __exit__(self, *exc):
+        set_rounding(self.old)
+        return False
+
+
+def _bf16(x: Tensor) -> Tensor:
+    return x.to(torch.bfloat16).to(x.dtype)
+
+
+class _StoreFn(torch.autograd.Function):
+    """A tensor the HIP path keeps in HBM: value rounded to bf16 on the way forward, its gradient on the way back."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return _bf16(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _bf16(g)
+
+
+class _GradFn(torch.autograd.Function):
+    """Identity forward; the gradient stored for this operator input is bf16."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _bf16(g)
+
+
+def _st(x: Tensor) -> Tensor:
+    return _StoreFn.apply(x) if _ROUNDING else x
+
+
+def _gr(x: Optional[Tensor]) -> Optional[Tensor]:
+    return _GradFn.apply(x) if (_ROUNDING and x is not None and x.requires_grad) else x
+
+
+# ----------------------------------------------------------------------------------------------
 # a1  CausalConv3d                                   genie/module/video.py:106-200
 # ----------------------------------------------------------------------------------------------
 def causal_pad_amounts(kernel_size, stride=(1, 1, 1), dilation=(1, 1, 1), padding=None):
@@ -66,19 +139,23 @@ def causal_pad_amounts(kernel_size, stride=(1, 1, 1), dilation=(1, 1, 1), paddin
 
 
 def causal_conv3d(x: Tensor, w: Tensor, b: Optional[Tensor], stride=(1, 1, 1), dilation=(1, 1, 1),
-                  padding=None) -> Tensor:
-    """video.py:178-192: F.pad(x, (wp, wp, hp, hp, tp, 0)) then conv3d without padding."""
+                  padding=None, resid: Optional[Tensor] = None, round_dx: bool = True) -> Tensor:
+    """video.py:178-192: F.pad(x, (wp, wp, hp, hp, tp, 0)) then conv3d without padding.
+    (`resid`: an addend the caller sums with the result -- video.py:648 -- passed in so that the rounding mode can round the SUM once,
+    as the GEMM epilogue does.)"""
     stride, dilation = _triple(stride), _triple(dilation)
     tp, hp, wp = causal_pad_amounts(w.shape[2:], stride, dilation, padding)
-    x = F.pad(x, (wp, wp, hp, hp, tp, 0))
-    return F.conv3d(x, w, b, stride=stride, dilation=dilation)
+    x = F.pad(_gr(x) if round_dx else x, (wp, wp, hp, hp, tp, 0))       # (a negative tp crops, as F.pad does in the reference)
+    y = F.conv3d(x, w, b, stride=stride, dilation=dilation)
+    return _st(y if resid is None else y + resid)
 
 
-def conv3d_same(x: Tensor, w: Tensor, b: Optional[Tensor]) -> Tensor:
+def conv3d_same(x: Tensor, w: Tensor, b: Optional[Tensor], resid: Optional[Tensor] = None, round_dx: bool = True) -> Tensor:
     """nn.Conv3d(k, padding=(k-1)//2) as used by VideoResidualBlock (video.py:580-586, 614-620)
     and the ST-block FFN (attention.py:429-438).  Symmetric zero padding: NOT causal (QUIRK 5)."""
     pad = tuple((k - 1) // 2 for k in w.shape[2:])
-    return F.conv3d(x, w, b, padding=pad)
+    y = F.conv3d(_gr(x) if round_dx else x, w, b, padding=pad)
+    return _st(y if resid is None else y + resid)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -108,15 +185,15 @@ def silu(x: Tensor) -> Tensor:
 # ----------------------------------------------------------------------------------------------
 def adaptive_group_norm(x: Tensor, cond: Tensor, sd: SD, prefix: str, num_groups: int, eps: float = 1e-5) -> Tensor:
     """norm.py:55-69: group_norm(x) * Linear_std(mean_{t,h,w} cond) + Linear_avg(mean cond)."""
-    y = group_norm(x, num_groups, _get(sd, prefix + 'weight'), _get(sd, prefix + 'bias'), eps)
-    c = cond.reshape(cond.shape[0], cond.shape[1], -1).mean(-1)          # norm.py:62
+    y = group_norm(_gr(x), num_groups, _get(sd, prefix + 'weight'), _get(sd, prefix + 'bias'), eps)
+    c = _gr(cond).reshape(cond.shape[0], cond.shape[1], -1).mean(-1)     # norm.py:62
     std = F.linear(c, sd[prefix + 'std.weight'], sd[prefix + 'std.bias'])
     shape = std.shape + (1,) * (x.dim() - 2)
     y = y * std.reshape(shape)
     if prefix + 'avg.weight' in sd:
         avg = F.linear(c, sd[prefix + 'avg.weight'], sd[prefix + 'avg.bias'])
         y = y + avg.reshape(shape)
-    return y
+    return _st(y)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -144,7 +221,7 @@ def blur_pool3d(x: Tensor, kernel_size, time_factor: int, space_factor, num_grou
     ker = blur_kernel((kt, kh, kw)).to(x.dtype)
     ker = ker[None, None].expand(o, c // num_groups, kt, kh, kw)
     pad = ((kt - 1) // 2, (kh - 1) // 2, (kw - 1) // 2)
-    return F.conv3d(x, ker, stride=(time_factor, *sf), padding=pad, groups=num_groups)
+    return _st(F.conv3d(_gr(x), ker, stride=(time_factor, *sf), padding=pad, groups=num_groups))
 
 
 # ----------------------------------------------------------------------------------------------
@@ -171,16 +248,16 @@ def video_residual_block(x: Tensor, sd: SD, prefix: str, in_channels: int, out_c
         downsample = (downsample, downsample)
     ks = _triple(kernel_size)
 
-    def conv(t: Tensor, key: str) -> Tensor:
+    def conv(t: Tensor, key: str, resid: Optional[Tensor] = None, round_dx: bool = True) -> Tensor:
         if use_causal:   # CausalConv3d wraps the conv as .conv3d and ignores the passed `padding`
             w, b = sd[prefix + key + '.conv3d.weight'], _get(sd, prefix + key + '.conv3d.bias')
             pad = tuple((k - 1) // 2 for k in w.shape[2:])
             # video.py:580-586 passes padding=(pt, ph, pw); CausalConv3d reads padding[0], padding[1]
             # as (height, width) pads (video.py:157-158): for the 1x1x1 res conv padding is None.
             if w.shape[2:] == (1, 1, 1):
-                return causal_conv3d(t, w, b)
-            return causal_conv3d(t, w, b, padding=(pad[0], pad[1]))
-        return conv3d_same(t, sd[prefix + key + '.weight'], _get(sd, prefix + key + '.bias'))
+                return causal_conv3d(t, w, b, resid=resid, round_dx=round_dx)
+            return causal_conv3d(t, w, b, padding=(pad[0], pad[1]), resid=resid, round_dx=round_dx)
+        return conv3d_same(t, sd[prefix + key + '.weight'], _get(sd, prefix + key + '.bias'), resid=resid, round_dx=round_dx)
 
     def down(t: Tensor, key: str, ch: int) -> Tensor:
         if downsample is None:
@@ -191,17 +268,19 @@ def video_residual_block(x: Tensor, sd: SD, prefix: str, in_channels: int, out_c
         w, b = sd[prefix + key + '.go_down.conv3d.weight'], _get(sd, prefix + key + '.go_down.conv3d.bias')
         return causal_conv3d(t, w, b, stride=(tf, sf, sf))
 
-    def norm(t: Tensor, key: str) -> Tensor:
-        if not use_norm:
-            return t
-        return group_norm(t, num_groups, sd[prefix + key + '.weight'], sd[prefix + key + '.bias'])
+    def norm_act(t: Tensor, key: str) -> Tensor:       # (one pass, one store on the HIP path)
+        t = _gr(t)
+        if use_norm:
+            t = group_norm(t, num_groups, sd[prefix + key + '.weight'], sd[prefix + key + '.bias'])
+        return _st(_act(act_fn, t))
 
     out_channels = out_channels if out_channels is not None else in_channels
-    res = conv(down(x, 'res.0', in_channels), 'res.1')
-    h = conv(_act(act_fn, norm(x, 'main.0')), 'main.2')
+    # (fused block on the HIP path: the shortcut's backward-data GEMM takes the main branch's stored input gradient as its epilogue
+    # addend -- dx = bf16(dgrad_res(dy) + bf16(d_main)) -- so the shortcut's own dx is never rounded separately)
+    res = conv(down(x, 'res.0', in_channels), 'res.1', round_dx=downsample is not None)
+    h = conv(norm_act(x, 'main.0'), 'main.2')
     h = down(h, 'main.3', out_channels)
-    h = conv(_act(act_fn, norm(h, 'main.4')), 'main.6')
-    return h + res
+    return conv(norm_act(h, 'main.4'), 'main.6', resid=res)       # video.py:648: main(x) + res(x)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -358,15 +437,16 @@ def attention_core(x: Tensor, sd: SD, prefix: str, n_head: int, d_head: int, cau
     unless `cond` is given, in which case k = to_k(cond) and v = to_v(k) ... see below.
     QUIRK 1: scale = n_head * d_head**-0.5 (attention.py:195)."""
     c = n_head * d_head
+    # (no separate gradient store for x: the rotary+LayerNorm backward kernel adds the skip branch's gradient in fp32 and stores the sum)
     if rotary_kind is not None:
         x = rotary_apply(x, sd[prefix + 'embed.freq'])
-    q = F.layer_norm(x, (c,), sd[prefix + 'norm.weight'], sd[prefix + 'norm.bias'])
+    q = _st(F.layer_norm(x, (c,), sd[prefix + 'norm.weight'], sd[prefix + 'norm.bias']))     # one pass, one store on the HIP path
     key = q if cond is None else cond
     val = key                                                       # attention.py:222-223
     # Adapter.forward attention.py:133-149: key = default(key, qry); val = default(val, key)
-    k = F.linear(key, sd[prefix + 'to_qkv.to_k.weight'], _get(sd, prefix + 'to_qkv.to_k.bias')) \
+    k = _st(F.linear(key, sd[prefix + 'to_qkv.to_k.weight'], _get(sd, prefix + 'to_qkv.to_k.bias'))) \
         if prefix + 'to_qkv.to_k.weight' in sd else key
-    v = F.linear(val, sd[prefix + 'to_qkv.to_v.weight'], _get(sd, prefix + 'to_qkv.to_v.bias')) \
+    v = _st(F.linear(val, sd[prefix + 'to_qkv.to_v.weight'], _get(sd, prefix + 'to_qkv.to_v.bias'))) \
         if prefix + 'to_qkv.to_v.weight' in sd else val
 
     def heads(t: Tensor) -> Tensor:
@@ -374,14 +454,26 @@ def attention_core(x: Tensor, sd: SD, prefix: str, n_head: int, d_head: int, cau
 
     qh, kh, vh = heads(q), heads(k), heads(v)
     scale = scale if scale is not None else n_head * d_head ** -0.5
-    att = torch.matmul(qh, kh.transpose(-1, -2)) * scale
-    if causal:
-        sq, sk = att.shape[-2:]
-        m = torch.ones(sq, sk, dtype=torch.bool).tril()              # SDPA is_causal: top-left aligned
-        att = att.masked_fill(~m, float('-inf'))
-    att = att.softmax(dim=-1)
-    out = torch.matmul(att, vh).transpose(1, 2).reshape(x.shape[0], x.shape[1], c)
-    return out
+
+    def sdpa(qc: Tensor, kc: Tensor, vc: Tensor) -> Tensor:
+        att = torch.matmul(qc, kc.transpose(-1, -2)) * scale
+        if causal:
+            sq, sk = att.shape[-2:]
+            m = torch.ones(sq, sk, dtype=torch.bool).tril()          # SDPA is_causal: top-left aligned
+            att = att.masked_fill(~m, float('-inf'))
+        return torch.matmul(att.softmax(dim=-1), vc)
+
+    nseq, sq, sk = qh.shape[0], qh.shape[2], kh.shape[2]
+    if nseq > 1 and nseq * n_head * sq * sk > (1 << 27):
+        # long sequences (LAM at 64x64: 16 x 4 x 4096 x 4096 scores = 4.3 GB per tensor): same arithmetic one sequence at a time, the score
+        # matrices recomputed in backward instead of kept
+        from torch.utils.checkpoint import checkpoint
+        outs = [checkpoint(sdpa, qh[i:i + 1], kh[i:i + 1], vh[i:i + 1], use_reentrant=False) if torch.is_grad_enabled() and
+                (qh.requires_grad or kh.requires_grad or vh.requires_grad) else sdpa(qh[i:i + 1], kh[i:i + 1], vh[i:i + 1]) for i in range(nseq)]
+        o = torch.cat(outs, dim=0)
+    else:
+        o = sdpa(qh, kh, vh)
+    return o.transpose(1, 2).reshape(x.shape[0], x.shape[1], c)
 
 
 def spatial_attention(video: Tensor, sd: SD, prefix: str, n_head: int, d_head: int, transpose: bool, embed: bool = True,
@@ -421,13 +513,13 @@ def space_time_block(video: Tensor, sd: SD, prefix: str, n_head: int, d_head: in
         cond = (cond, cond)
     if isinstance(embed, bool):
         embed = (embed, embed)
-    video = spatial_attention(video, sd, prefix + 'space_attn.', n_head, d_head, transpose, embed[0], cond[0], scale) + video
-    video = temporal_attention(video, sd, prefix + 'temp_attn.', n_head, d_head, transpose, embed[1], cond[1], scale) + video
+    # (rounding mode: each sub-layer's `f(x) + x` leaves its kernel as ONE bf16 store; the skip branch's gradient is the stored dout itself)
+    video = _st(spatial_attention(video, sd, prefix + 'space_attn.', n_head, d_head, transpose, embed[0], cond[0], scale) + video)
+    video = _st(temporal_attention(video, sd, prefix + 'temp_attn.', n_head, d_head, transpose, embed[1], cond[1], scale) + video)
     x = video if transpose else video.permute(0, 4, 1, 2, 3)
-    y = group_norm(x, n_head, sd[prefix + 'ffn.1.net.0.weight'], sd[prefix + 'ffn.1.net.0.bias'])
-    y = conv3d_same(y, sd[prefix + 'ffn.1.net.1.0.weight'], _get(sd, prefix + 'ffn.1.net.1.0.bias'))
-    y = y if transpose else y.permute(0, 2, 3, 4, 1)
-    return y + video
+    y = _st(group_norm(_gr(x), n_head, sd[prefix + 'ffn.1.net.0.weight'], sd[prefix + 'ffn.1.net.0.bias']))
+    y = conv3d_same(y, sd[prefix + 'ffn.1.net.1.0.weight'], _get(sd, prefix + 'ffn.1.net.1.0.bias'), resid=x)     # ffn(x) + x
+    return y if transpose else y.permute(0, 2, 3, 4, 1)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -460,11 +552,11 @@ def run_layer(name: str, kw: dict, x: Tensor, sd: SD, prefix: str, cond=None, us
     if name == 'depth2spacetime_upsample':
         return depth2spacetime_upsample(x, sd, prefix, **kw)
     if name == 'group_norm':
-        return group_norm(x, kw['num_groups'], _get(sd, prefix + 'weight'), _get(sd, prefix + 'bias'), kw.get('eps', 1e-5))
+        return _st(group_norm(_gr(x), kw['num_groups'], _get(sd, prefix + 'weight'), _get(sd, prefix + 'bias'), kw.get('eps', 1e-5)))
     if name == 'adaptive_group_norm':
         return adaptive_group_norm(x, cond, sd, prefix, kw['num_groups'], kw.get('eps', 1e-5))
     if name == 'silu':
-        return silu(x)
+        return _st(silu(_gr(x)))
     if name == 'space-time_attn':
         return space_time_block(x, sd, prefix, cond=cond if use_cond else None, **kw)
     raise ValueError(f'Unknown module name: {name}')
@@ -473,19 +565,30 @@ def run_layer(name: str, kw: dict, x: Tensor, sd: SD, prefix: str, cond=None, us
 # ----------------------------------------------------------------------------------------------
 # a13  VideoTokenizer                                  genie/tokenizer.py:307-387
 # ----------------------------------------------------------------------------------------------
-def tokenizer_encode(video: Tensor, sd: SD, enc_desc) -> Tensor:
-    x = video
-    for i, (name, kw, has_ext) in enumerate(expand_blueprint(enc_desc)):
-        x = run_layer(name, kw, x, sd, f'enc_layers.{i}.', cond=None, use_cond=has_ext)
+def _run_layers(x: Tensor, sd: SD, desc, prefix: str, cond: Optional[Tensor]) -> Tensor:
+    """The layer loop of tokenizer.py:314-315 / 326-328.  In the rounding mode a 'group_norm' directly followed by 'silu' is ONE
+    stored tensor (the HIP path runs the pair as one pass); the arithmetic is the same either way."""
+    layers = expand_blueprint(desc)
+    i = 0
+    while i < len(layers):
+        name, kw, has_ext = layers[i]
+        if _ROUNDING and name == 'group_norm' and not has_ext and i + 1 < len(layers) and layers[i + 1][0] == 'silu' and not layers[i + 1][2]:
+            p = f'{prefix}{i}.'
+            x = _st(silu(group_norm(_gr(x), kw['num_groups'], _get(sd, p + 'weight'), _get(sd, p + 'bias'), kw.get('eps', 1e-5))))
+            i += 2
+            continue
+        x = run_layer(name, kw, x, sd, f'{prefix}{i}.', cond=cond if has_ext else None, use_cond=has_ext)
+        i += 1
     return x
+
+
+def tokenizer_encode(video: Tensor, sd: SD, enc_desc) -> Tensor:
+    return _run_layers(video, sd, enc_desc, 'enc_layers.', None)
 
 
 def tokenizer_decode(quant: Tensor, sd: SD, dec_desc, cond: Optional[Tensor] = None) -> Tensor:
     cond = quant if cond is None else cond                           # tokenizer.py:324
-    x = quant
-    for i, (name, kw, has_ext) in enumerate(expand_blueprint(dec_desc)):
-        x = run_layer(name, kw, x, sd, f'dec_layers.{i}.', cond=cond if has_ext else None, use_cond=has_ext)
-    return x
+    return _run_layers(quant, sd, dec_desc, 'dec_layers.', cond)
 
 
 def tokenizer_tokenize(video: Tensor, sd: SD, enc_desc, d_codebook: int, n_codebook: int = 1, beta: float = 100.):
@@ -513,10 +616,10 @@ def tokenizer_forward_hotpath(video: Tensor, sd: SD, enc_desc, dec_desc, d_codeb
 # ----------------------------------------------------------------------------------------------
 def dynamics_forward(tokens: Tensor, act_id: Tensor, sd: SD, desc) -> Tuple[Tensor, Tensor]:
     """dynamics.py:44-64.  tokens (B,T,H,W) int64, act_id (B,T) int64 -> logits (B,T,H,W,V)."""
-    x = F.embedding(tokens, sd['tok_emb.weight']) + F.embedding(act_id, sd['act_emb.0.weight'])[:, :, None, None, :]
+    x = _st(F.embedding(tokens, sd['tok_emb.weight']) + F.embedding(act_id, sd['act_emb.0.weight'])[:, :, None, None, :])
     for i, (name, kw, has_ext) in enumerate(expand_blueprint(desc)):
         x = run_layer(name, kw, x, sd, f'dec_layers.{i}.')             # dynamics.py:59: no cond passed
-    logits = F.linear(x, sd['head.weight'], sd['head.bias'])
+    logits = _st(F.linear(_gr(x), sd['head.weight'], sd['head.bias']))
     return logits, logits[:, -1]
 
 
@@ -603,21 +706,38 @@ def dynamics_generate(tokens: Tensor, act_id: Tensor, sd: SD, desc, uniforms: Te
 # ----------------------------------------------------------------------------------------------
 # a17  LatentAction, repaired (R-lam)    genie/action.py:111-176
 # ----------------------------------------------------------------------------------------------
-def latent_action_forward(video: Tensor, sd: SD, enc_desc, dec_desc, d_codebook: int, training: bool = True,
-                          quant_loss_weight: float = 1., beta: float = 100.):
-    """action.py:111-176 with the three R-lam repairs applied by the CALLER's blueprint (transpose=True ST
-    blocks with n_head*d_head == n_embd, 'depth2spacetime_upsample', LFQ input_dim = d_codebook)."""
+def latent_action_encode(video: Tensor, sd: SD, enc_desc) -> Tensor:
+    """action.py:111-122 up to the encoder output: proj_in then the encoder blueprint (no condition, no mask)."""
     x = causal_conv3d(video, sd['proj_in.conv3d.weight'], _get(sd, 'proj_in.conv3d.bias'))
     for i, (name, kw, _) in enumerate(expand_blueprint(enc_desc)):
         x = run_layer(name, kw, x, sd, f'enc_layers.{i}.')
-    enc_video = x
-    b, c, t = x.shape[:3]
-    act = F.linear(x.permute(0, 2, 1, 3, 4).reshape(b, t, -1), sd['to_act.1.weight'])   # 'b c t ... -> b t (c ...)'
-    (q_act, idxs), q_loss = lfq_forward(act, sd, 'quant.', d_codebook, training=training, beta=beta, transpose=False)
+    return x
+
+
+def latent_action_to_act(enc_video: Tensor, sd: SD) -> Tensor:
+    """action.py:83-90, 124: 'b c t ... -> b t (c ...)' then Linear(no bias) -> (B, T, d) pre-quantisation action latent."""
+    b, c, t = enc_video.shape[:3]
+    return _st(F.linear(_gr(enc_video).permute(0, 2, 1, 3, 4).reshape(b, t, -1), _gr(sd['to_act.1.weight'])))
+
+
+def latent_action_decode(enc_video: Tensor, q_act: Tensor, sd: SD, dec_desc) -> Tensor:
+    """action.py:136-160: decoder blueprint with the quantised action as TEMPORAL condition of the `has_ext` layers, then proj_out."""
     y = enc_video
     for i, (name, kw, has_ext) in enumerate(expand_blueprint(dec_desc)):
         y = run_layer(name, kw, y, sd, f'dec_layers.{i}.', cond=(None, q_act if has_ext else None), use_cond=True)
-    recon = causal_conv3d(y, sd['proj_out.conv3d.weight'], _get(sd, 'proj_out.conv3d.bias'))
+    return causal_conv3d(y, sd['proj_out.conv3d.weight'], _get(sd, 'proj_out.conv3d.bias'))
+
+
+def latent_action_forward(video: Tensor, sd: SD, enc_desc, dec_desc, d_codebook: int, training: bool = True,
+                          quant_loss_weight: float = 1., beta: float = 100., trace: Optional[dict] = None):
+    """action.py:111-176 with the three R-lam repairs applied by the CALLER's blueprint (transpose=True ST
+    blocks with n_head*d_head == n_embd, 'depth2spacetime_upsample', LFQ input_dim = d_codebook)."""
+    enc_video = latent_action_encode(video, sd, enc_desc)
+    act = latent_action_to_act(enc_video, sd)                                             # 'b c t ... -> b t (c ...)' + Linear
+    if trace is not None:
+        trace.update(enc_video=enc_video, act=act)
+    (q_act, idxs), q_loss = lfq_forward(act, sd, 'quant.', d_codebook, training=training, beta=beta, transpose=False)
+    recon = latent_action_decode(enc_video, q_act, sd, dec_desc)
     rec_loss = F.mse_loss(recon, video)
     loss = rec_loss + (q_loss * quant_loss_weight if q_loss is not None else 0)
     return idxs, loss, (rec_loss, q_loss), recon

@@ -141,6 +141,45 @@ def _model_worker(rank: int, world: int, port: int, q, compress):
         dist.destroy_process_group()
 
 
+def _sync_worker(rank: int, world: int, port: int, q):
+    """(a) replicas built from DIFFERENT seeds are equal after sync_replicas and draw different random numbers afterwards (ADVICE r2);
+    (b) stages given as nn.ModuleList containers (what VideoTokenizer.forward_order() returns: the model's own loop iterates them, they
+    are never called) still arm their early-reduction hooks, through their first layer."""
+    _setup(rank, world, port)
+    try:
+        from genie.trainer import DataParallel, ParamArena, sync_replicas
+        torch.manual_seed(1234 + rank)                             # a config without seed_everything: every rank initialises differently
+        model = _Toy()
+        model.register_buffer('table', torch.randn(5))
+        arena = ParamArena(model)
+        before = arena.params.clone()
+        sync_replicas(arena, model, seed=7)
+        gathered = [torch.empty_like(arena.params) for _ in range(world)]
+        dist.all_gather(gathered, arena.params)
+        assert all(torch.equal(g, gathered[0]) for g in gathered)
+        if rank > 0:
+            assert not torch.equal(before, arena.params)
+        bufs = [torch.empty(5) for _ in range(world)]
+        dist.all_gather(bufs, model.table)
+        assert torch.equal(bufs[0], bufs[1])
+        # parameters are views of the arena: the module sees the broadcast weights
+        assert torch.equal(model.late.weight.detach().reshape(-1), arena.params[arena.slots['late.weight'][0]:][:16])
+        draws = [torch.empty(3) for _ in range(world)]
+        dist.all_gather(draws, torch.rand(3))
+        assert not torch.equal(draws[0], draws[1])                 # per-rank random streams after the broadcast
+        dp = DataParallel(arena.grads)
+        dp.install_overlap_hooks(arena, model, [model.quant, model.dec, model.late])     # model.dec is a ModuleList
+        assert DataParallel.entry_module(model.dec) is model.dec[0]
+        x = torch.randn(4, 16)
+        model(x).backward()
+        assert dp.fired == [3, 2, 1], dp.fired                     # all three armed and fired during backward
+        dp.finish()
+        assert dp.last_armed == [1, 2, 3] and dp.last_fired == [3, 2, 1, 0]
+        q.put((rank, float(arena.params.sum())))
+    finally:
+        dist.destroy_process_group()
+
+
 def _run(target, extra=()):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
@@ -167,3 +206,8 @@ def test_world_size_2_module_arena_hooks():
 
 def test_world_size_2_module_arena_hooks_bf16_compress():
     _run(_model_worker, ('bf16',))
+
+
+def test_world_size_2_replica_sync_and_container_stages():
+    res = _run(_sync_worker)
+    assert res[0][1] == res[1][1]

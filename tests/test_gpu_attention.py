@@ -172,6 +172,12 @@ CORE_CASES = [
     (2, 2, 64, 150, 70, False, True),
     (4, 2, 64, 40, 40, True, False),
     (2, 4, 32, 96, 96, False, False),
+    # the sequence lengths the benchmarks run: LatentAction at 64 x 64 (S = 4096, 4 x 64: the `st_attention` headline shape),
+    # Genie at 128 x 128 (S = 16384), a long causal sequence (diagonal tiles far from the origin)
+    (2, 4, 64, 4096, 4096, False, False),
+    (1, 2, 64, 16384, 16384, False, False),
+    (1, 2, 64, 2048, 2048, True, False),
+    (1, 1, 128, 4096, 4096, False, False),
     # short self-attention sequences: the packed kernels (several sequences per wave, block-diagonal mask)
     (7, 2, 64, 16, 16, True, False),
     (5, 4, 32, 5, 5, True, False),

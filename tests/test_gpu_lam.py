@@ -1,0 +1,158 @@
+"""LatentAction (reference genie/action.py:111-176, R-lam repaired blueprints) on the HIP path against the oracle
+(-m gpu): action indices, both losses and EVERY parameter gradient -- on a toy and at the BASELINE configs[2] size (n_embd 256 = 4 x 64,
+16 x 64 x 64 clips: 4096-position spatial attention, the K = 262144 `to_act` projection, 256-channel FFN convs at 16 x 64 x 64)."""
+import pytest
+import torch
+
+from util import bf16_round, report
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_rms(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return ((a - b).pow(2).mean().sqrt() / (b.pow(2).mean().sqrt() + 1e-20)).item()
+
+
+def build_lam(enc, dec, d, shape, n_embd, seed):
+    from genie import LatentAction
+    torch.manual_seed(seed)
+    m = LatentAction(enc, dec, d_codebook=d, inp_shape=shape, n_embd=n_embd)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if 'freq' in n:
+                continue
+            if p.dim() >= 2:
+                p.copy_(bf16_round(p))
+            elif 'norm' in n or '.net.0.' in n:
+                p.copy_(torch.randn_like(p) * 0.2 + (1.0 if n.endswith('weight') else 0.0))     # non-trivial affine terms
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    return m.cuda().train(), sd
+
+
+def lam_stages_hip(m, x):
+    """LatentAction.forward (genie/action.py) spelled out so that the stage boundaries can be read back."""
+    from genie import functional as GF
+    xc = x.cuda()
+    v = m.proj_in(xc)
+    for enc in m.enc_layers:
+        v = enc(v, mask=None)
+    v.retain_grad()
+    a = m._project_to_action(v)
+    a.retain_grad()
+    (qa, idxs), ql = m.quant(a, transpose=False)
+    qa.retain_grad()
+    rec = m.decode(v, qa)
+    rec_loss = GF.mse_loss(rec, xc)
+    loss = rec_loss + ql * m.quant_loss_weight
+    loss.backward()
+    return dict(enc_video=v, act=a, q_act=qa, idxs=idxs, q_loss=ql, rec=rec, rec_loss=rec_loss, loss=loss)
+
+
+def lam_stages_oracle(h, x, sd, enc, dec, d, mode):
+    """The same four stages on the oracle, each fed the HIP path's own stage input and upstream gradient (the scheme of
+    test_magvit2_full_training_step_parity): decoder, quantiser, action projection, encoder.  Returns parameter-gradient errors
+    and the stage-boundary gradient errors."""
+    from oracle import genie_oracle as O
+    import torch.nn.functional as F
+    with O.rounding(mode):
+        sd_req = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and 'freq' not in k else v) for k, v in sd.items()}
+        ev = h['enc_video'].detach().float().cpu().requires_grad_(True)
+        qa = h['q_act'].detach().float().cpu().requires_grad_(True)
+        rec = O.latent_action_decode(ev, qa, sd_req, dec)
+        F.mse_loss(rec, x).backward()
+        d_ev_dec, d_qa = ev.grad.clone(), qa.grad.clone()
+        a_in = h['act'].detach().float().cpu().requires_grad_(True)
+        (q_o, idx_o), ql_o = O.lfq_forward(a_in, sd, 'quant.', d, training=True, transpose=False)
+        ((q_o * h['q_act'].grad.float().cpu()).sum() + ql_o).backward()
+        ev2 = h['enc_video'].detach().float().cpu().requires_grad_(True)
+        O.latent_action_to_act(ev2, sd_req).backward(h['act'].grad.float().cpu())
+        O.latent_action_encode(x, sd_req, enc).backward(h['enc_video'].grad.float().cpu())
+    errs = {}
+    for name, p in h['model'].named_parameters():
+        g_ref = sd_req[name].grad if name in sd_req and isinstance(sd_req[name], torch.Tensor) and sd_req[name].requires_grad else None
+        if g_ref is None or g_ref.abs().max() == 0:
+            continue
+        assert p.grad is not None, name
+        errs[name] = rel_rms(p.grad, g_ref)
+    edges = dict(rec=rel_rms(h['rec'], rec), d_q_act=rel_rms(h['q_act'].grad, d_qa), d_act=rel_rms(h['act'].grad, a_in.grad),
+                 d_enc_video=rel_rms(h['enc_video'].grad, d_ev_dec + ev2.grad), q_loss=abs(ql_o.item() - h['q_loss'].item()))
+    return errs, edges, idx_o
+
+
+def summary(errs):
+    vals = sorted(errs.values())
+    worst = max(errs, key=errs.get)
+    return vals[len(vals) // 2], errs[worst], worst
+
+
+SMALL_ENC = (('space-time_attn', {'n_head': 2, 'd_head': 32, 'transpose': True}),
+             ('spacetime_downsample', {'in_channels': 64, 'kernel_size': 3, 'time_factor': 1, 'space_factor': 2}),
+             ('space-time_attn', {'n_head': 2, 'd_head': 32, 'transpose': True}))
+SMALL_DEC = (('space-time_attn', {'n_head': 2, 'd_head': 32, 'transpose': True, 'has_ext': True, 'time_attn_kw': {'key_dim': 4}}),
+             ('depth2spacetime_upsample', {'in_channels': 64, 'kernel_size': 3, 'time_factor': 1, 'space_factor': 2}),
+             ('space-time_attn', {'n_head': 2, 'd_head': 32, 'transpose': True, 'has_ext': True, 'time_attn_kw': {'key_dim': 4}}))
+
+
+def check_lam(tag, enc, dec, d, n_embd, clip, seed, tol_fp32, tol_emul):
+    from oracle import genie_oracle as O
+    b, t, hh, ww = clip
+    m, sd = build_lam(enc, dec, d, (hh, ww), n_embd, seed)
+    torch.manual_seed(seed + 1)
+    x = bf16_round(torch.randn(b, 3, t, hh, ww))
+    h = lam_stages_hip(m, x)
+    h['model'] = m
+    # end to end against the reference's fp32 arithmetic: scalars, reconstruction, action indices
+    tr = {}
+    with torch.no_grad():
+        idx_ref, loss_ref, (rec_ref, q_ref), recon_ref = O.latent_action_forward(x, sd, enc, dec, d, training=True, trace=tr)
+    assert tuple(h['idxs'].shape) == tuple(idx_ref.shape)
+    assert abs(h['rec_loss'].item() - rec_ref.item()) < 2e-2 * abs(rec_ref.item()), (h['rec_loss'].item(), rec_ref.item())
+    assert abs(h['q_loss'].item() - q_ref.item()) < 2e-2 * abs(q_ref.item()) + 1e-3, (h['q_loss'].item(), q_ref.item())
+    assert rel_rms(h['rec'], recon_ref) < 3e-2, rel_rms(h['rec'], recon_ref)
+    assert rel_rms(h['enc_video'], tr['enc_video']) < 3e-2
+    # the action id is the sign pattern of a K = n_embd * H/2 * W/2 projection of bf16 activations: it may differ from the fp32 oracle's only
+    # where the oracle's pre-sign value is within eps of zero; everywhere else the ids agree bit for bit
+    act_ref = tr['act']
+    eps = 3e-2 * act_ref.pow(2).mean().sqrt().item()
+    bits_h = (h['act'].detach().float().cpu() > 0)
+    bits_r = act_ref > 0
+    flipped = bits_h != bits_r
+    assert (act_ref[flipped].abs() < eps).all(), (act_ref[flipped].abs().max().item(), eps)
+    safe = (act_ref.abs() >= eps).all(-1)                                   # frames whose whole code is decided by a margin
+    idx_h = h['idxs'].cpu().reshape(idx_ref.shape)
+    assert torch.equal(idx_h.reshape(-1)[safe.reshape(-1)], idx_ref.reshape(-1)[safe.reshape(-1)])
+    match = (idx_h == idx_ref).float().mean().item()
+    # per stage, same inputs: fp32 arithmetic (loose, reported) and the bf16-at-stores emulation (the parity bound)
+    errs, edges, idx_o = lam_stages_oracle(h, x, sd, enc, dec, d, None)
+    assert torch.equal(h['idxs'].cpu().reshape(idx_o.shape), idx_o)          # operator boundary: bit-exact on the same latent
+    errs_e, edges_e, idx_e = lam_stages_oracle(h, x, sd, enc, dec, d, 'bf16_at_stores')
+    assert torch.equal(h['idxs'].cpu().reshape(idx_e.shape), idx_e)
+    n_params = sum(1 for n, p in m.named_parameters() if p.requires_grad and 'freq' not in n)
+    assert len(errs) == len(errs_e) == n_params, (len(errs), len(errs_e), n_params)      # EVERY parameter gradient is compared
+    med, worst, wname = summary(errs)
+    med_e, worst_e, wname_e = summary(errs_e)
+    print(f'{tag}: idx match {match:.4f} ({int(flipped.sum())} bits inside eps), rec_loss {h["rec_loss"].item():.5f} vs {rec_ref.item():.5f}; {len(errs)} gradients: '
+          f'fp32 median {med:.4f} worst {worst:.4f} ({wname}); bf16-at-stores median {med_e:.5f} worst {worst_e:.5f} ({wname_e}); edges {edges} -> {edges_e}')
+    report(tag, clip=list(clip), n_embd=n_embd, params=len(errs), idx_match_rate=match, bits_flipped_inside_eps=int(flipped.sum()), eps=eps,
+           rec_loss_hip=h['rec_loss'].item(), rec_loss_oracle=rec_ref.item(), q_loss_hip=h['q_loss'].item(), q_loss_oracle=q_ref.item(),
+           median_rel_rms=med, worst_rel_rms=worst, worst_param=wname, emulated_median_rel_rms=med_e, emulated_worst_rel_rms=worst_e,
+           emulated_worst_param=wname_e, edges_fp32=edges, edges_emulated=edges_e)
+    assert worst < tol_fp32, (wname, worst)
+    assert worst_e < tol_emul, (wname_e, worst_e)
+    assert edges_e['q_loss'] < 1e-4 + 1e-4 * abs(q_ref.item())
+    return m, h
+
+
+def test_latent_action_small_all_gradients():
+    """A toy R-lam model: indices, losses and every parameter gradient (the r2 test compared one scalar)."""
+    m, h = check_lam('latent_action_small', SMALL_ENC, SMALL_DEC, 4, 64, (2, 4, 16, 16), 11, tol_fp32=0.08, tol_emul=0.03)
+    assert m.sample(h['idxs']).shape == (2, 4, 4)
+
+
+def test_latent_action_configs2_size_parity():
+    """BASELINE configs[2]: LATENT_ACT_ENC / _DEC (R-lam), n_embd 256 = 4 heads x 64, 8-action codebook (d = 3 would be 8 codes; the README's
+    d_codebook = 8 is kept), one 16 x 64 x 64 clip: S = 4096 spatial attention over 16 frames, causal temporal attention over 4096 pixels,
+    the K = 262144 projection, the quantised-action condition of the decoder -- the launches scripts/bench_models.py times."""
+    from genie import LATENT_ACT_DEC, LATENT_ACT_ENC
+    check_lam('latent_action_configs2', LATENT_ACT_ENC, LATENT_ACT_DEC, 8, 256, (1, 16, 64, 64), 5, tol_fp32=0.10, tol_emul=0.03)

@@ -71,7 +71,11 @@ def test_maskgit_sample_operator(rows, v, dtype, temp, spread):
     prob = torch.softmax(lf / temp, -1)
     assert pred.dtype == torch.int64 and tuple(pred.shape) == (1, rows)
     n_diff = _explain_draws(prob, u, pred_ref, pred.cpu()[0], EPS_ULP)
-    assert n_diff <= max(1, rows // 16), f'{n_diff} of {rows} draws differ at the operator level'
+    report('maskgit_sample_operator', rows=rows, v=v, dtype=str(dtype).split('.')[-1], temp=temp, n_diff=n_diff)
+    # "bit-exact up to proven CDF ties": a draw may differ only if its threshold sits within 2e-6 (relative) of a CDF boundary -- the fp32
+    # exp / summation-order noise between the device's and torch-CPU's softmax -- which a uniform threshold does with probability
+    # ~ 2 * 2e-6 * (boundaries near u) per row: at most ONE such row is tolerated per call (measured: 0 in every configuration)
+    assert n_diff <= 1, f'{n_diff} of {rows} draws differ at the operator level'
     same = pred_ref == pred.cpu()[0]
     torch.testing.assert_close(conf.cpu()[0][same], conf_ref[same], rtol=2e-4, atol=1e-30)       # torch's CPU softmax sums 2^18 terms in fp32 lanes (measured 2.3e-5 off the exact sum)
     assert int(pred.min()) >= 0 and int(pred.max()) < v
@@ -89,6 +93,12 @@ def test_maskgit_sample_strided_last_frame():
     pred_ref, conf_ref = O.maskgit_sample_step(full[:, -1, :, :, :v].float(), u, 1.0)
     prob = torch.softmax(full[:, -1, :, :, :v].float(), -1).reshape(-1, v)
     assert _explain_draws(prob, u, pred_ref, pred.cpu().reshape(-1), EPS_ULP) <= 1
+    # a dtype the kernel does not read (fp16) on the same padded-pitch view: the conversion re-packs it, pitches must follow
+    half = full.to(torch.float16)
+    pred16, _ = GF.maskgit_sample(half.cuda()[:, -1, :, :, :v], u, 1.0)
+    pred16_ref, _ = O.maskgit_sample_step(half[:, -1, :, :, :v].float(), u, 1.0)
+    prob16 = torch.softmax(half[:, -1, :, :, :v].float(), -1).reshape(-1, v)
+    assert _explain_draws(prob16, u, pred16_ref, pred16.cpu().reshape(-1), EPS_ULP) <= 1
 
 
 @pytest.mark.parametrize('b,n,ks', [(2, 16, (1, 5, 10)), (3, 256, (1, 6, 11, 17, 23, 28, 34, 40, 46, 50)), (1, 1000, (999, 1)), (2, 4096, (1000, 3000, 96)), (4, 1, (1,))])

@@ -192,8 +192,11 @@ def test_magvit2_full_training_step_parity():
     runtime set-up -- parameter arena in execution order, optimiser-maintained bf16 weight packs, fused residual-block nodes, the
     256-row kw-triple kernels at C = 256 / 512, wgrad3, split-K on the low-resolution layers -- one full training step forward and
     backward against oracle autograd, every one of the 449 parameter tensors, with the three-stage scheme of
-    test_tokenizer_training_step_parity (each stage shares its input with the oracle).  Tolerances: loss 3 %; per-parameter
-    relative-RMS gradient error < 20 % with a median < 6 % (bf16 activations and gradients through 40 residual blocks)."""
+    test_tokenizer_training_step_parity (each stage shares its input with the oracle).  Two comparisons: (1) the reference's fp32
+    arithmetic -- loss 3 %, per-parameter relative-RMS gradient error < 20 %, median < 6 % (what bf16 STORAGE of activations and
+    gradients through 40 residual blocks costs; reported); (2) the same oracle rounding to bf16 exactly where the HIP path stores
+    (oracle.set_rounding('bf16_at_stores')) -- every parameter gradient within 1 %, median < 0.3 %: the parity bound proper.  A 5 %
+    systematic error in one layer's weight gradient passes (1) and fails (2)."""
     from genie import MAGVIT2_DEC_DESC, MAGVIT2_ENC_DESC, VideoTokenizer
     from genie import functional as GF
     from genie.trainer import ParamArena
@@ -224,34 +227,53 @@ def test_magvit2_full_training_step_parity():
     loss_ref, (rec_ref, q_ref), _, _ = O.tokenizer_forward_hotpath(x, sd, enc, dec, d)
     assert abs(loss.item() - loss_ref.item()) < 3e-2 * abs(loss_ref.item()), (loss.item(), loss_ref.item())
 
-    sd_req = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
-    q_in = qh.detach().float().cpu().requires_grad_(True)
-    torch.nn.functional.mse_loss(O.tokenizer_decode(q_in, sd_req, dec), x).backward()
-    assert rel_rms(qh.grad, q_in.grad) < 0.12, rel_rms(qh.grad, q_in.grad)
-    z_in = e.detach().float().cpu().requires_grad_(True)
-    (q_o, idx_o), ql_o = O.lfq_forward(z_in, sd, 'quant.', d, 1, training=True, transpose=True)
-    ((q_o * qh.grad.float().cpu()).sum() + ql_o).backward()
+    def oracle_stages(mode):
+        """The three stages on the oracle, each fed the HIP path's own stage input; `mode` None = the reference's fp32 arithmetic,
+        'bf16_at_stores' = the same arithmetic with activations / activation gradients rounded where the HIP path stores them."""
+        with O.rounding(mode):
+            sd_req = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+            q_in = qh.detach().float().cpu().requires_grad_(True)
+            torch.nn.functional.mse_loss(O.tokenizer_decode(q_in, sd_req, dec), x).backward()
+            z_in = e.detach().float().cpu().requires_grad_(True)
+            (q_o, idx_o), ql_o = O.lfq_forward(z_in, sd, 'quant.', d, 1, training=True, transpose=True)
+            ((q_o * qh.grad.float().cpu()).sum() + ql_o).backward()
+            O.tokenizer_encode(x, sd_req, enc).backward(e.grad.float().cpu())
+        errs = {}
+        for name, p in m.named_parameters():
+            g_ref = sd_req[name].grad
+            if g_ref is None or g_ref.abs().max() == 0:
+                continue
+            assert p.grad is not None, name
+            errs[name] = rel_rms(p.grad, g_ref)
+        return errs, rel_rms(qh.grad, q_in.grad), rel_rms(e.grad, z_in.grad), idx_o, ql_o
+
+    def summary(errs):
+        vals = sorted(errs.values())
+        worst = max(errs, key=errs.get)
+        return vals[len(vals) // 2], vals[int(len(vals) * .95)], errs[worst], worst
+
+    # (1) against the reference's fp32 arithmetic: what bf16 storage costs end to end (reported; loose bound)
+    errs, dq, dz, idx_o, ql_o = oracle_stages(None)
     assert torch.equal(idx.cpu(), idx_o)                                       # LFQ indices bit-exact at the operator boundary
     assert abs(ql_o.item() - qlh.item()) < 1e-4 + 1e-4 * abs(ql_o.item())
-    assert rel_rms(e.grad, z_in.grad) < 1e-2, rel_rms(e.grad, z_in.grad)
-    O.tokenizer_encode(x, sd_req, enc).backward(e.grad.float().cpu())
-    errs = {}
-    for name, p in m.named_parameters():
-        g_ref = sd_req[name].grad
-        if g_ref is None or g_ref.abs().max() == 0:
-            continue
-        assert p.grad is not None, name
-        errs[name] = rel_rms(p.grad, g_ref)
+    assert dq < 0.12 and dz < 1e-2, (dq, dz)
     assert len(errs) >= 440, len(errs)
-    vals = sorted(errs.values())
-    worst = max(errs, key=errs.get)
-    print(f'MAGVIT2 B=2 training step: {len(errs)} parameter gradients, median rel-RMS {vals[len(vals) // 2]:.4f}, 95 % {vals[int(len(vals) * .95)]:.4f}, '
-          f'worst {errs[worst]:.4f} ({worst})')
-    report('magvit2_full_training_step_parity', clips=2, params=len(errs), loss_hip=loss.item(), loss_oracle=loss_ref.item(), median_rel_rms=vals[len(vals) // 2],
-           p95_rel_rms=vals[int(len(vals) * .95)], worst_rel_rms=errs[worst], worst_param=worst, dlatent_rel_rms=rel_rms(qh.grad, q_in.grad),
-           lfq_indices_bit_exact=True)
-    assert errs[worst] < 0.20, (worst, errs[worst])
-    assert vals[len(vals) // 2] < 0.06, vals[len(vals) // 2]
+    med, p95, worst, wname = summary(errs)
+    assert worst < 0.20 and med < 0.06, (wname, worst, med)
+    # (2) against the bf16-store-emulating oracle: the same roundings in the same places, so what is left is implementation error
+    #     (accumulation order, a value that lands on the other side of a bf16 rounding boundary) -- THIS is the parity bound
+    errs_e, dq_e, dz_e, idx_e, _ = oracle_stages('bf16_at_stores')
+    assert torch.equal(idx.cpu(), idx_e)
+    med_e, p95_e, worst_e, wname_e = summary(errs_e)
+    print(f'MAGVIT2 B=2 training step: {len(errs)} parameter gradients; vs fp32 oracle median {med:.4f} / 95 % {p95:.4f} / worst {worst:.4f} ({wname}); '
+          f'vs bf16-at-stores oracle median {med_e:.5f} / 95 % {p95_e:.5f} / worst {worst_e:.5f} ({wname_e}); dlatent {dq:.4f} -> {dq_e:.5f}')
+    report('magvit2_full_training_step_parity', clips=2, params=len(errs), loss_hip=loss.item(), loss_oracle=loss_ref.item(), median_rel_rms=med,
+           p95_rel_rms=p95, worst_rel_rms=worst, worst_param=wname, dlatent_rel_rms=dq, lfq_indices_bit_exact=True,
+           emulated_median_rel_rms=med_e, emulated_p95_rel_rms=p95_e, emulated_worst_rel_rms=worst_e, emulated_worst_param=wname_e,
+           emulated_dlatent_rel_rms=dq_e, emulated_dz_rel_rms=dz_e)
+    assert worst_e < 0.01, (wname_e, worst_e)                                  # VERDICT r2 item 2: every parameter gradient within 1 %
+    assert med_e < 0.003, med_e
+    assert dq_e < 0.01, dq_e
 
 
 @pytest.mark.default_grads

@@ -195,3 +195,41 @@ def test_async_wgrad_side_stream_matches_in_order_execution():
         dp = (p0 - p1).abs()
         assert dp.max().item() <= 2 * 2 * 1e-3 + 5e-4, dp.max().item()
         assert dp.mean().item() <= 2e-5, dp.mean().item()
+
+
+def test_checkpoint_resume_continues_the_run(tmp_path):
+    """last.ckpt carries the weights, AdamW's moments / step counter and the position in the epoch (the reference's
+    ModelCheckpoint(save_last) is resumable): 2 steps + resume + 2 steps == 4 steps straight, up to the atomic-add order of the weight
+    gradients."""
+    from genie.dataset import LightningSynthetic
+    from genie.trainer import Trainer
+
+    def data():
+        return LightningSynthetic(num_clips=16, shape=(3, 4, 16, 16), seed=3, batch_size=2, num_workers=0, train_shuffle=False)
+
+    straight = _model()
+    Trainer(max_steps=4, default_root_dir=str(tmp_path / 'a'), log_every_n_steps=100).fit(straight, data())
+    first = _model()
+    Trainer(max_steps=2, default_root_dir=str(tmp_path / 'b'), log_every_n_steps=100).fit(first, data())
+    ck = torch.load(str(tmp_path / 'b' / 'last.ckpt'), map_location='cpu')
+    assert ck['global_step'] == 2 and ck['loops']['batches_done_in_epoch'] == 2
+    st = ck['optimizer_states'][0]['state']
+    assert set(st) == {n for n, p in first.named_parameters() if p.requires_grad}
+    assert all(v['step'] == 2 and v['exp_avg'].abs().sum() >= 0 for v in st.values())
+    resumed = _model()
+    with torch.no_grad():
+        for p in resumed.parameters():
+            p.add_(1.0)                                       # whatever the fresh model holds must be overwritten by the checkpoint
+    tr = Trainer(max_steps=4, default_root_dir=str(tmp_path / 'c'), log_every_n_steps=100).fit(resumed, data(), ckpt_path=str(tmp_path / 'b' / 'last.ckpt'))
+    assert tr.global_step == 4 and tr.arena.step_count == 4
+    for (n, a), (_, b) in zip(straight.named_parameters(), resumed.named_parameters()):
+        torch.testing.assert_close(a.detach(), b.detach(), rtol=1e-4, atol=1e-5, msg=n)
+    # the checkpoint's moments matter: zero them and the continuation leaves the straight run
+    ck2 = torch.load(str(tmp_path / 'b' / 'last.ckpt'), map_location='cpu')
+    for v in ck2['optimizer_states'][0]['state'].values():
+        v['exp_avg'].zero_(); v['exp_avg_sq'].zero_()
+    torch.save(ck2, str(tmp_path / 'b' / 'no_moments.ckpt'))
+    cold = _model()
+    Trainer(max_steps=4, default_root_dir=str(tmp_path / 'd'), log_every_n_steps=100).fit(cold, data(), ckpt_path=str(tmp_path / 'b' / 'no_moments.ckpt'))
+    diff = max((a.detach() - b.detach()).abs().max().item() for a, b in zip(straight.parameters(), cold.parameters()))
+    assert diff > 1e-4, diff
