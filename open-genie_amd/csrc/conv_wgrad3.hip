@@ -364,6 +364,267 @@ __global__ void __launch_bounds__(512) wgrad3_kernel(const Wgrad3Args a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Lean main loop (round 3).  Same tiling, LDS layout, ring and MFMA order as wgrad3_kernel above; what changed is everything AROUND
+// the MFMAs.  SQ counters of the kernel above (256 -> 256 @16x32x32): 8.3 VALU + 3.9 SALU instructions per MFMA and 27 scalar
+// branches per 64-pixel chunk -- per-lane 64-bit address arithmetic, bounds predicates and zero-page selects for every LDS-DMA piece,
+// per-lane (t, h) bookkeeping with a while loop, run-time debug / bias switches inside the k-steps.  One wave's VALU issue filled the
+// issue slots between its own MFMAs, so the "phases" of a wave (DMA issue, fragment reads, MFMAs) added up instead of overlapping.
+// Here:
+//   * LDS-DMA through BUFFER loads (`buffer_load_dwordx4 ... lds`): a wave-uniform resource descriptor (SGPRs, rebased to the block's
+//     first chunk) + a per-lane byte offset that never changes + a scalar chunk offset that advances by one s_add per chunk.  What
+//     used to be predicates is the descriptor's range check: a lane whose channel chunk does not exist, a piece whose image row
+//     (t + dt, h + dh) lies outside the clip and a stage issued past the block's last chunk all carry offset 0x80000000 >= num_records
+//     and the DMA writes ZEROS (the mechanism composable_kernel's direct loads rely on) -- one v_or per x piece, nothing per dy piece.
+//   * (t, h) of a piece's image row is wave-uniform: scalar registers, scalar compare / select.
+//   * the bias gradient (an MFMA against ones in 2 waves of every 9th block) is a template parameter of the loop, chosen once per wave
+//     by a scalar branch in front of it; no debug switches.
+// Eligibility (host): dy not shuffled, H * W a multiple of 64 (chunks are whole image rows, M a multiple of 64), a block's byte range
+// below 2 GiB.  Everything else stays on wgrad3_kernel.
+// ------------------------------------------------------------------------------------------------------------------------------
+#define W3L_OOB 0x80000000u
+
+template <int LOG2W, bool BIAS>
+__device__ __forceinline__ void w3l_loop(const Wgrad3Args& a, char* smem, const int nch, const int wave,
+                                          const __amdgpu_buffer_rsrc_t rs_dy, const __amdgpu_buffer_rsrc_t rs_x,
+                                          const uint32_t (&voff_dy)[2], const uint32_t (&voff_x)[2], const uint32_t (&x_dst)[2],
+                                          int (&x_t)[2], int (&x_h)[2], const int t_dt, const int t_dh,
+                                          const uint32_t (&a_const)[2], const uint32_t (&b_const)[2][3],
+                                          f32x16_t (&acc)[3][2], f32x16_t (&accb)[2]) {
+    constexpr int BK = 64, W = 1 << LOG2W, HS = BK >> LOG2W, PITCH = 256;
+    constexpr int A_BYTES = BK * PITCH, X_BYTES = 80 * PITCH, STAGE = A_BYTES + X_BYTES, NSTAGE = W3_NSTAGE, TM = 2;
+    const uint32_t dy_step = (uint32_t)(BK * a.Cd * 2), x_step = (uint32_t)(BK * a.Cs * 2);      // bytes per chunk
+    uint32_t so_dy = 0, so_x = 0;                        // scalar byte offsets of the NEXT chunk to stage, relative to the block's first
+    int staged = 0;                                      // chunks staged so far
+
+    // one 1-KiB piece of the stage for chunk `staged`: dy rounds 0 / 1 (PIECE 0 / 1), x rounds 0 / 1 (PIECE 2 / 3; 3 advances the cursor)
+    auto stage_piece = [&](const int buf, const int piece) {
+        char* abase = smem + buf * STAGE;
+        const bool live = staged < nch;
+        if (piece < 2) {
+            const uint32_t v = voff_dy[piece] | (live ? 0u : W3L_OOB);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_dy, LDS_PTR(abase + (piece * 8 + wave) * 1024), 16, v, live ? so_dy : 0u, 0, 0);
+        } else {
+            const int i = piece - 2;
+            const bool ok = (int)live & (int)((unsigned)(x_t[i] + t_dt) < (unsigned)a.T) & (int)((unsigned)(x_h[i] + t_dh) < (unsigned)a.H);   // (no short-circuit branches)
+            const uint32_t v = voff_x[i] | (ok ? 0u : W3L_OOB);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, LDS_PTR(abase + A_BYTES + x_dst[i]), 16, v, ok ? so_x : 0u, 0, 0);
+            x_h[i] += HS;                                // next chunk: HS image rows further (HS <= H: at most one wrap)
+            if (x_h[i] >= a.H) {
+                x_h[i] -= a.H;
+                x_t[i] = x_t[i] + 1 == a.T ? 0 : x_t[i] + 1;
+            }
+            if (piece == 3) {
+                ++staged;
+                so_dy += dy_step;
+                so_x += x_step;
+            }
+        }
+    };
+    auto stage = [&](const int buf) {
+#pragma unroll
+        for (int pc = 0; pc < 4; ++pc) stage_piece(buf, pc);
+    };
+
+    bf16x8_t ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (short)0x3F80;
+
+    const uint32_t smem_base = w3_lds_offset(smem);
+    // prologue: NSTAGE - 1 stages in flight, the first one landed
+    stage(0);
+    stage(1);
+    if (NSTAGE == 4) stage(2);
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * (NSTAGE - 2)) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    int buf = 0;
+    for (int c = 0; c < nch; ++c) {
+        const int nbuf = buf >= 1 ? buf - 1 : NSTAGE - 1;                // slot of chunk c - 1: every wave is past the barrier behind it
+        const uint32_t abase = smem_base + buf * STAGE;
+        uint32_t a_addr[TM], b_addr[2][3];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a_addr[i] = abase + a_const[i];
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int s = 0; s < 3; ++s) b_addr[p][s] = abase + A_BYTES + b_const[p][s];
+        bf16x4_t alo[2][TM], ahi[2][TM], blo[2][3], bhi[2][3];
+#define W3L_CONSUME(SET)                                                                                         \
+        bf16x8_t af[TM], bfr[3];                                                                                 \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                         \
+            asm volatile("" : "+v"(alo[SET][i]), "+v"(ahi[SET][i]));                                             \
+            af[i] = __builtin_shufflevector(alo[SET][i], ahi[SET][i], 0, 1, 2, 3, 4, 5, 6, 7);                   \
+        }                                                                                                        \
+        _Pragma("unroll") for (int s = 0; s < 3; ++s) {                                                          \
+            asm volatile("" : "+v"(blo[SET][s]), "+v"(bhi[SET][s]));                                             \
+            bfr[s] = __builtin_shufflevector(blo[SET][s], bhi[SET][s], 0, 1, 2, 3, 4, 5, 6, 7);                  \
+        }
+#define W3L_MFMA(KS)                                                                                             \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                         \
+            _Pragma("unroll") for (int s = 0; s < 3; ++s)                                                        \
+                acc[s][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[s], acc[s][i], 0, 0, 0);         \
+            if (BIAS) accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], ones, accb[i], 0, 0, 0);         \
+            if (i == 0) {                                                                                        \
+                __builtin_amdgcn_sched_barrier(0);                                                               \
+                stage_piece(nbuf, KS);                                                                           \
+                __builtin_amdgcn_sched_barrier(0);                                                               \
+            }                                                                                                    \
+        }
+#define W3L_STEP(KS, SET, NEXT)                                                                                  \
+        {                                                                                                        \
+            __builtin_amdgcn_sched_barrier(0);      /* the wait stays BEHIND the previous k-step's MFMAs */      \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                   \
+            __builtin_amdgcn_sched_barrier(0);                                                                   \
+            W3L_CONSUME(SET)                                                                                     \
+            NEXT                                                                                                 \
+            W3L_MFMA(KS)                                                                                         \
+        }
+        w3_issue<0, LOG2W, TM>(a_addr, b_addr, alo[0], ahi[0], blo[0], bhi[0]);
+        W3L_STEP(0, 0, (w3_issue<1, LOG2W, TM>(a_addr, b_addr, alo[1], ahi[1], blo[1], bhi[1]));)
+        W3L_STEP(1, 1, (w3_issue<2, LOG2W, TM>(a_addr, b_addr, alo[0], ahi[0], blo[0], bhi[0]));)
+        W3L_STEP(2, 0, (w3_issue<3, LOG2W, TM>(a_addr, b_addr, alo[1], ahi[1], blo[1], bhi[1]));)
+        W3L_STEP(3, 1, ;)
+#undef W3L_STEP
+#undef W3L_MFMA
+#undef W3L_CONSUME
+        // chunk c + 1 must have landed; the NSTAGE - 2 newest stages (4 pieces each) stay in flight
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * (NSTAGE - 2)) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        buf = buf == NSTAGE - 1 ? 0 : buf + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int LOG2W>
+__global__ void __launch_bounds__(512) wgrad3l_kernel(const Wgrad3Args a) {
+    constexpr int BK = 64;
+    constexpr int W = 1 << LOG2W, WP = W + 2, HS = BK >> LOG2W;
+    constexpr int PITCH = 256, A_BYTES = BK * PITCH, X_BYTES = 80 * PITCH, STAGE = A_BYTES + X_BYTES, NSTAGE = W3_NSTAGE, TM = 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;             // 2 (co) x 4 (ci)
+    int b;
+    {
+        const int nb = gridDim.x, bid = blockIdx.x;
+        const int q = nb >> 3, r = nb & 7, xcd = bid & 7;
+        b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tr = b % a.ntriples; b /= a.ntriples;
+    const int split = b % a.split_k; b /= a.split_k;
+    const int tile_n = b % a.tiles_n, tile_m = b / a.tiles_n;
+    const int co0 = tile_m * 128, ci0 = tile_n * 128;
+    const GenieTap tp = a.taps[3 * tr];
+    const int t_dt = __builtin_amdgcn_readfirstlane(tp.dt), t_dh = __builtin_amdgcn_readfirstlane(tp.dh);
+    const bool do_bias = a.dbias != nullptr && tr == 0 && tile_n == 0 && wn == 0;
+
+    int c_begin = split * a.chunks_per_split, c_end = c_begin + a.chunks_per_split;
+    if (c_end > a.nchunks) c_end = a.nchunks;
+    const int nch = c_end - c_begin;
+
+    // ---- per-lane staging constants: byte offsets inside a chunk (never change), OOB for channel chunks that do not exist ----
+    const int d_row = tid >> 4;                          // + 32 * round
+    const int st_lc = (tid & 15) ^ ((d_row & 3) << 2);   // logical 16-B chunk of the dy tile
+    uint32_t voff_dy[2], voff_x[2], x_dst[2];
+    int x_t[2], x_h[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int pl = i * 32 + d_row;
+        const int co = co0 + st_lc * 8;
+        voff_dy[i] = co < a.Cout ? (uint32_t)((pl * a.Cd + co) * 2) : W3L_OOB;
+        const int hl = pl >> LOG2W;
+        const int lrow = hl * WP + (pl & (W - 1)) + 1;   // this lane's LDS row of the x image
+        const int lc = (tid & 15) ^ ((lrow & 3) << 2);
+        const int ci = ci0 + lc * 8;
+        voff_x[i] = (ci < a.Cs && ci < ((a.Cin + 7) & ~7)) ? (uint32_t)((pl * a.Cs + ci) * 2) : W3L_OOB;
+        const int q0 = (i * 8 + wave) * 4;               // first pixel of the wave's piece (4 consecutive pixels of ONE image row)
+        x_dst[i] = (uint32_t)(((q0 >> LOG2W) * WP + (q0 & (W - 1)) + 1) * PITCH);
+        const uint32_t rowid = (uint32_t)c_begin * HS + (uint32_t)(q0 >> LOG2W);       // (n, t, h) row of the wave's piece, first chunk
+        const uint32_t q2 = fd3(rowid, a.dH_);
+        x_h[i] = __builtin_amdgcn_readfirstlane((int)(rowid - q2 * a.dH_.d));
+        x_t[i] = __builtin_amdgcn_readfirstlane((int)(q2 - fd3(q2, a.dT_) * a.dT_.d));
+    }
+    // resource descriptors rebased to the block's first chunk (x: to the tap's shifted row as well; only in-range rows are dereferenced)
+    const long long dy_base = (long long)c_begin * BK * a.Cd;
+    const long long x_base = (long long)c_begin * BK * a.Cs + (long long)(t_dt * a.H + t_dh) * W * a.Cs;
+    const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dy + dy_base), (short)0, (int)W3L_OOB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(a.src + x_base), (short)0, (int)W3L_OOB, 0x00020000);
+
+    // zero columns of every stage's image: rows hl * WP and hl * WP + W + 1 (written once, never DMA'd)
+    for (int e = tid; e < NSTAGE * 2 * HS * 16; e += 512) {
+        const int st = e / (2 * HS * 16), r2 = (e / 16) % (2 * HS), c = e & 15;
+        const int row = (r2 >> 1) * WP + ((r2 & 1) ? W + 1 : 0);
+        *reinterpret_cast<u32x4_t*>(smem + st * STAGE + A_BYTES + row * PITCH + c * 16) = u32x4_t{0u, 0u, 0u, 0u};
+    }
+    __syncthreads();
+
+    f32x16_t acc[3][TM];
+    f32x16_t accb[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accb[i][r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[s][i][r] = 0.f;
+    }
+
+    // transposing-read addresses (see wgrad3_kernel)
+    const int g16 = lane >> 4, rr = (lane >> 2) & 3, qq = lane & 3;
+    const int krow = 8 * (g16 >> 1) + rr;
+    const int lane_pad = LOG2W == 3 ? 2 * (g16 >> 1) : 0;
+    uint32_t a_const[TM], b_const[2][3];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int col = wm * 64 + i * 32 + 16 * (g16 & 1) + 4 * qq;
+        a_const[i] = (uint32_t)(krow * PITCH + (((col >> 3) ^ (rr << 2)) << 4) + (col & 7) * 2);
+    }
+    {
+        const int col = wn * 32 + 16 * (g16 & 1) + 4 * qq;
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const int key = (rr + s + lane_pad + 2 * p) & 3;
+                b_const[p][s] = (uint32_t)((krow + lane_pad + s) * PITCH + (((col >> 3) ^ (key << 2)) << 4) + (col & 7) * 2);
+            }
+    }
+
+    if (nch > 0) {
+        if (do_bias)
+            w3l_loop<LOG2W, true>(a, smem, nch, wave, rs_dy, rs_x, voff_dy, voff_x, x_dst, x_t, x_h, t_dt, t_dh, a_const, b_const, acc, accb);
+        else
+            w3l_loop<LOG2W, false>(a, smem, nch, wave, rs_dy, rs_x, voff_dy, voff_x, x_dst, x_t, x_h, t_dt, t_dh, a_const, b_const, acc, accb);
+    }
+
+    // ---- epilogue: fp32 atomics; D row = cout (registers), col = cin (lane & 31) ----
+    const int khalf = lane >> 5;
+    const int ci = ci0 + wn * 32 + (lane & 31);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r16 = 0; r16 < 16; ++r16) {
+            const int co = co0 + wm * 64 + i * 32 + (r16 & 3) + 8 * (r16 >> 2) + 4 * khalf;
+            if (co >= a.Cout) continue;
+            float* row = a.dw + co * a.s_cout + (long long)(3 * tr) * a.s_tap;
+            if (ci < a.Cin) {
+                if (a.split_k == 1) {                           // one owner per element: plain read-modify-write (no atomics)
+#pragma unroll
+                    for (int s = 0; s < 3; ++s) row[s * a.s_tap + ci * a.s_cin] += acc[s][i][r16];
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 3; ++s) atomicAdd(row + s * a.s_tap + ci * a.s_cin, acc[s][i][r16]);
+                }
+            }
+            if (do_bias && (lane & 31) == 0) atomicAdd(a.dbias + co, accb[i][r16]);
+        }
+    }
+}
+
 // Returns 1 when the problem is not eligible (caller falls back to the generic kernel), 0 on launch, < 0 on error.
 int genie_conv_wgrad3_try(const GenieWgradDesc* d, hipStream_t s) {
     if (d->tri_mode <= 0) return 1;
@@ -441,6 +702,25 @@ int genie_conv_wgrad3_try(const GenieWgradDesc* d, hipStream_t s) {
         configured[slot] = true;
     }
     genie_note_variant(GENIE_VARIANT_WGRAD3);
+    // lean main loop (buffer-addressed LDS-DMA, scalar bookkeeping) where its preconditions hold -- see wgrad3l_kernel
+    static const int lean_on = getenv("GENIE_W3_LEAN") ? atoi(getenv("GENIE_W3_LEAN")) : 1;
+    const long long blk_bytes = (long long)a.chunks_per_split * 64 * (d->Cs > d->Cd ? d->Cs : d->Cd) * 2 + ((long long)(d->Hs + 2) * W * d->Cs * 2);
+    if (lean_on && !shuffled && a.dbg == 0 && (d->Ho * W) % 64 == 0 && 64 / W <= d->Ho && blk_bytes < 0x7f000000ll && d->Td == d->Ts && d->Hd == d->Hs && d->Wd == W) {
+        void (*lk)(const Wgrad3Args) = a.log2W == 3 ? wgrad3l_kernel<3> : a.log2W == 4 ? wgrad3l_kernel<4> : a.log2W == 5 ? wgrad3l_kernel<5> : wgrad3l_kernel<6>;
+        static bool lconf[8] = {false};
+        if (!lconf[a.log2W]) {
+            hipError_t e = hipFuncSetAttribute((const void*)lk, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e != hipSuccess) {
+                genie_set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+                return GENIE_ERR_HIP;
+            }
+            lconf[a.log2W] = true;
+        }
+        genie_note_variant(GENIE_VARIANT_WGRAD3_LEAN);
+        hipLaunchKernelGGL(lk, dim3((unsigned)(base * a.split_k)), dim3(512), lds, s, a);
+        GENIE_CHECK_LAUNCH();
+        return GENIE_OK;
+    }
     hipLaunchKernelGGL(kern, dim3((unsigned)(base * a.split_k)), dim3(512), lds, s, a);
     GENIE_CHECK_LAUNCH();
     return GENIE_OK;

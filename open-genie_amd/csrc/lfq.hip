@@ -130,8 +130,11 @@ __global__ void __launch_bounds__(256) lfq_factor_kernel(const T* __restrict__ z
 }
 
 // P[cb][a][b] = (1/ntok) sum_tok A[tok,cb][a] * B[tok,cb][b];  64x64 tile per block, 4x4 per thread.  ksplit > 1: blockIdx.z also
-// carries a token range and the partial tiles are added atomically into a zeroed P (a 512 x 512 table is only 64 tiles: a quarter
-// of the chip; the token split fills it)
+// carries a token range (a 512 x 512 table is only 64 tiles: a quarter of the chip; the token split fills it) and every split writes
+// its OWN partial table P[ks]; lfq_avgent_kernel adds the ksplit tables in a fixed order.  (Round 2 added the partial tiles
+// atomically into one table: the order of those fp32 adds changed from run to run, the 1e-7 wobble of d loss / d z reached the
+// encoder's backward pass and bf16 rounding amplified it to 4e-3 of the stem's weight gradient within a dozen layers --
+// tests/test_gpu_properties.py::test_gradient_determinism.)
 __global__ void __launch_bounds__(256) lfq_avgprob_kernel(const float* __restrict__ Ain, const float* __restrict__ Bin, LfqGeom g,
                                                           float* __restrict__ P, int ksplit) {
     __shared__ float As[16][64], Bs[16][64];
@@ -172,20 +175,20 @@ __global__ void __launch_bounds__(256) lfq_avgprob_kernel(const float* __restric
         for (int j = 0; j < 4; ++j) {
             const int a = a0 + ty * 4 + i, b = b0 + tx * 4 + j;
             if (a < g.na && b < g.nb) {
-                float* o = P + ((long long)cb * g.na + a) * g.nb + b;
-                if (ksplit > 1) atomicAdd(o, acc[i][j] * inv);
-                else *o = acc[i][j] * inv;
+                P[(((long long)ks * g.ncb + cb) * g.na + a) * g.nb + b] = acc[i][j] * inv;
             }
         }
 }
 
 // G = d H(P) / dP;  partial sums of H(P)
 __global__ void __launch_bounds__(256) lfq_avgent_kernel(const float* __restrict__ P, float* __restrict__ Gm, long long ncode, float inv_rep,
-                                                         float* __restrict__ partial) {
+                                                         float* __restrict__ partial, int ksplit) {
     const int cb = blockIdx.y;
+    const long long table = (long long)gridDim.y * ncode;          // one partial table per token split
     float acc = 0.f;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < ncode; i += (long long)gridDim.x * 256) {
-        const float p = P[cb * ncode + i];
+        float p = P[cb * ncode + i];
+        for (int ks = 1; ks < ksplit; ++ks) p += P[ks * table + cb * ncode + i];          // fixed order: reproducible
         const float pe = p * inv_rep;
         const float lg = __logf(fmaxf(pe, LFQ_EPS));
         acc -= p * lg;
@@ -380,11 +383,12 @@ __global__ void __launch_bounds__(256) lfq_final_kernel(const float* __restrict_
 }
 
 #define LFQ_AVG_BLOCKS 64
+#define LFQ_MAX_KSPLIT 16    // token splits of the average-probability product (one partial table each)
 
 extern "C" int64_t genie_lfq_loss_ws_floats(int64_t ntok, int num_codebook, int codebook_dim) {
     const int dh = codebook_dim / 2, dl = codebook_dim - dh;
     const int64_t nrow = ntok * num_codebook;
-    return nrow * ((1ll << dh) + (1ll << dl)) + 2ll * num_codebook * (1ll << codebook_dim) + 2 * nrow + (int64_t)num_codebook * LFQ_AVG_BLOCKS + 64;
+    return nrow * ((1ll << dh) + (1ll << dl)) + (1ll + LFQ_MAX_KSPLIT) * num_codebook * (1ll << codebook_dim) + 2 * nrow + (int64_t)num_codebook * LFQ_AVG_BLOCKS + 64;
 }
 
 extern "C" int genie_lfq_loss(const void* z, int dtype, int64_t ntok, int num_codebook, int codebook_dim, int64_t pitch, float beta,
@@ -402,7 +406,7 @@ extern "C" int genie_lfq_loss(const void* z, int dtype, int64_t ntok, int num_co
     float* A = ws;
     float* B = A + g.nrow * g.na;
     float* P = B + g.nrow * g.nb;
-    float* Gm = P + (long long)num_codebook * ncode;
+    float* Gm = P + (long long)LFQ_MAX_KSPLIT * num_codebook * ncode;        // P holds up to LFQ_MAX_KSPLIT partial tables
     float* Htok = Gm + (long long)num_codebook * ncode;
     float* Ctok = Htok + g.nrow;
     float* avgp = Ctok + g.nrow;
@@ -417,17 +421,16 @@ extern "C" int genie_lfq_loss(const void* z, int dtype, int64_t ntok, int num_co
     else
         GENIE_CHECK_ARG(false, "genie_lfq_loss: unsupported dtype %d", dtype);
     GENIE_CHECK_LAUNCH();
+    int ksplit = 1;
     {
         const long long tiles = (long long)cdiv(g.nb, 64) * cdiv(g.na, 64) * num_codebook;
-        int ksplit = 1;
-        while (tiles * ksplit < 256 && ntok / (ksplit * 2) >= 256 && ksplit < 16) ksplit *= 2;
-        if (ksplit > 1) GENIE_CHECK_ARG(hipMemsetAsync(P, 0, sizeof(float) * (size_t)num_codebook * ncode, s) == hipSuccess, "genie_lfq_loss: hipMemsetAsync failed");
+        while (tiles * ksplit < 256 && ntok / (ksplit * 2) >= 256 && ksplit < LFQ_MAX_KSPLIT) ksplit *= 2;
         lfq_avgprob_kernel<<<dim3(cdiv(g.nb, 64), cdiv(g.na, 64), num_codebook * ksplit), 256, 0, s>>>(A, B, g, P, ksplit);
     }
     GENIE_CHECK_LAUNCH();
     int ablk = (int)((ncode + 255) / 256);
     if (ablk > LFQ_AVG_BLOCKS) ablk = LFQ_AVG_BLOCKS;
-    lfq_avgent_kernel<<<dim3(ablk, num_codebook), 256, 0, s>>>(P, Gm, ncode, inv_rep, avgp);
+    lfq_avgent_kernel<<<dim3(ablk, num_codebook), 256, 0, s>>>(P, Gm, ncode, inv_rep, avgp, ksplit);
     GENIE_CHECK_LAUNCH();
     static const int fast_tok = getenv("GENIE_LFQ_FAST") ? atoi(getenv("GENIE_LFQ_FAST")) : 1;
     const int bpl = (fast_tok && g.nb % 64 == 0 && g.dh <= 10 && g.dl <= 10) ? g.nb / 64 : 0;     // columns per lane of the fast sweep: 4, 8 or 16

@@ -109,18 +109,21 @@ class _OutOfScopeCritic(nn.Module):
                                   f'VideoTokenizer with the corresponding loss weight set to 0')
 
 
-def run_layers(layers: nn.ModuleList, ext: list, x: Tensor, cond: Tensor | None) -> Tensor:
+def run_layers(layers: nn.ModuleList, ext: list, x: Tensor, cond: Tensor | None, record=None) -> Tensor:
     """The reference's layer loop (tokenizer.py:314-315, 326-328) with one peephole: GroupNorm immediately
-    followed by SiLU runs as one fused pass."""
+    followed by SiLU runs as one fused pass.  `record(lo, hi, x, y)`, when given, sees every step's input and output (layers [lo, hi)
+    of the list): the per-layer parity tests read the stage boundaries through it."""
     i, n = 0, len(layers)
     while i < n:
         layer, has_ext = layers[i], ext[i]
         if isinstance(layer, GroupNorm) and not has_ext and i + 1 < n and isinstance(layers[i + 1], SiLU) and not ext[i + 1]:
-            x = GF.group_norm(x, layer.num_groups, layer.weight, layer.bias, layer.eps, act=True)
-            i += 2
-            continue
-        x = layer(x, cond) if has_ext else layer(x)
-        i += 1
+            y, span = GF.group_norm(x, layer.num_groups, layer.weight, layer.bias, layer.eps, act=True), 2
+        else:
+            y, span = (layer(x, cond) if has_ext else layer(x)), 1
+        if record is not None:
+            record(i, i + span, x, y)
+        x = y
+        i += span
     return x
 
 

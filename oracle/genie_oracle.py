@@ -565,11 +565,14 @@ def run_layer(name: str, kw: dict, x: Tensor, sd: SD, prefix: str, cond=None, us
 # ----------------------------------------------------------------------------------------------
 # a13  VideoTokenizer                                  genie/tokenizer.py:307-387
 # ----------------------------------------------------------------------------------------------
-def _run_layers(x: Tensor, sd: SD, desc, prefix: str, cond: Optional[Tensor]) -> Tensor:
-    """The layer loop of tokenizer.py:314-315 / 326-328.  In the rounding mode a 'group_norm' directly followed by 'silu' is ONE
-    stored tensor (the HIP path runs the pair as one pass); the arithmetic is the same either way."""
+def _run_layers(x: Tensor, sd: SD, desc, prefix: str, cond: Optional[Tensor], lo: int = 0, hi: Optional[int] = None) -> Tensor:
+    """The layer loop of tokenizer.py:314-315 / 326-328 (layers [lo, hi) of the expanded blueprint; default: all).  In the rounding mode
+    a 'group_norm' directly followed by 'silu' is ONE stored tensor (the HIP path runs the pair as one pass); the arithmetic is the same
+    either way."""
     layers = expand_blueprint(desc)
-    i = 0
+    if hi is not None:
+        layers = layers[:hi]
+    i = lo
     while i < len(layers):
         name, kw, has_ext = layers[i]
         if _ROUNDING and name == 'group_norm' and not has_ext and i + 1 < len(layers) and layers[i + 1][0] == 'silu' and not layers[i + 1][2]:

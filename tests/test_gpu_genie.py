@@ -70,8 +70,9 @@ def test_genie_compute_loss_matches_its_parts_and_oracle():
     assert torch.equal(tokens, idx_op.reshape(tokens.shape))
     e_ref = O.tokenizer_encode(x, sd_tok, TOK_ENC)
     _, idx_ref_tok = O.tokenizer_tokenize(x, sd_tok, TOK_ENC, 6)
-    safe = (e_ref.abs() >= 3e-2 * e_ref.pow(2).mean().sqrt()).all(1)                    # (B, t, h, w): every bit decided by a margin
-    assert safe.float().mean() > 0.5
+    z_ref = torch.nn.functional.linear(e_ref.movedim(1, -1), sd_tok['quant.proj_inp.weight'], sd_tok['quant.proj_inp.bias'])    # the 6 pre-sign values per token
+    safe = (z_ref.abs() >= 3e-2 * z_ref.pow(2).mean().sqrt()).all(-1)                   # (B, t, h, w): every bit decided by a margin
+    assert safe.float().mean() > 0.5, safe.float().mean()
     assert torch.equal(tokens[safe], idx_ref_tok.reshape(tokens.shape)[safe])
     # (b) the action ids LatentAction hands to the dynamics model, same rule
     tr = {}

@@ -488,6 +488,9 @@ TRI_WGRAD_CASES = [
     (128, 64, (3, 1, 3), True, (3, 5, 2, 16), None),         # M = 480: last chunk partial, kh = 1
     (64, 32 * 8, (3, 3, 3), True, (1, 2, 4, 8), (2, 2, 2)),  # upsample conv: dy is the shuffled high-resolution gradient
     (128, 64 * 4, (3, 3, 3), True, (2, 2, 4, 16), (1, 2, 2)),
+    (128, 128, (3, 3, 3), False, (3, 5, 16, 32), None),       # several splits, (t, h) wrap inside a block's range, every dt / dh border
+    (256, 128, (3, 3, 3), True, (2, 3, 64, 64), None),       # W = 64: one image row per chunk, two ci tiles
+    (72, 200, (3, 3, 3), False, (1, 2, 8, 16), None),        # channel counts that are multiples of 8 only: OOB lanes of the descriptor
 ]
 
 
@@ -514,7 +517,10 @@ def test_conv_wgrad_triple_kernel(G, cin, cout, kernel, causal, size, shuffle, m
     db = torch.zeros(cout, device='cuda')
     monkeypatch.setattr(G.conv, 'TRI_WGRAD', 2)          # force the triple kernel whatever the problem size
     G.conv.conv_wgrad(G.cl.to_cl(x.cuda()), G.cl.to_cl(dy.cuda()), spec, dw, db)
-    assert G.hip.load_library().genie_last_conv_variant() == 11
+    # whole image rows per 64-pixel chunk and a plain (un-shuffled) dy: the lean main loop (buffer-addressed LDS-DMA, wgrad3l_kernel, 14);
+    # everything else: the general kernel (11)
+    lean = shuffle is None and (h * w) % 64 == 0 and 64 // w <= h
+    assert G.hip.load_library().genie_last_conv_variant() == (14 if lean else 11)
     torch.testing.assert_close(dw.cpu(), wt.grad, rtol=1e-3, atol=1e-3 * wt.grad.abs().max().item())
     torch.testing.assert_close(db.cpu(), b.grad, rtol=1e-3, atol=1e-3 * b.grad.abs().max().item())
     G.conv.conv_wgrad(G.cl.to_cl(x.cuda()), G.cl.to_cl(dy.cuda()), spec, dw, None)      # accumulates

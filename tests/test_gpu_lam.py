@@ -94,7 +94,7 @@ SMALL_DEC = (('space-time_attn', {'n_head': 2, 'd_head': 32, 'transpose': True, 
              ('space-time_attn', {'n_head': 2, 'd_head': 32, 'transpose': True, 'has_ext': True, 'time_attn_kw': {'key_dim': 4}}))
 
 
-def check_lam(tag, enc, dec, d, n_embd, clip, seed, tol_fp32, tol_emul):
+def check_lam(tag, enc, dec, d, n_embd, clip, seed, tol_fp32, tol_emul=None):
     from oracle import genie_oracle as O
     b, t, hh, ww = clip
     m, sd = build_lam(enc, dec, d, (hh, ww), n_embd, seed)
@@ -126,7 +126,9 @@ def check_lam(tag, enc, dec, d, n_embd, clip, seed, tol_fp32, tol_emul):
     # per stage, same inputs: fp32 arithmetic (loose, reported) and the bf16-at-stores emulation (the parity bound)
     errs, edges, idx_o = lam_stages_oracle(h, x, sd, enc, dec, d, None)
     assert torch.equal(h['idxs'].cpu().reshape(idx_o.shape), idx_o)          # operator boundary: bit-exact on the same latent
-    errs_e, edges_e, idx_e = lam_stages_oracle(h, x, sd, enc, dec, d, 'bf16_at_stores')
+    # (the emulating pass is optional: over these 8 blocks it lands where the fp32 comparison does -- 0.79 % vs 0.76 % worst at the
+    # configs[2] size -- and costs another ~80 s of host time there)
+    errs_e, edges_e, idx_e = lam_stages_oracle(h, x, sd, enc, dec, d, 'bf16_at_stores') if tol_emul is not None else (errs, edges, idx_o)
     assert torch.equal(h['idxs'].cpu().reshape(idx_e.shape), idx_e)
     n_params = sum(1 for n, p in m.named_parameters() if p.requires_grad and 'freq' not in n)
     assert len(errs) == len(errs_e) == n_params, (len(errs), len(errs_e), n_params)      # EVERY parameter gradient is compared
@@ -137,16 +139,16 @@ def check_lam(tag, enc, dec, d, n_embd, clip, seed, tol_fp32, tol_emul):
     report(tag, clip=list(clip), n_embd=n_embd, params=len(errs), idx_match_rate=match, bits_flipped_inside_eps=int(flipped.sum()), eps=eps,
            rec_loss_hip=h['rec_loss'].item(), rec_loss_oracle=rec_ref.item(), q_loss_hip=h['q_loss'].item(), q_loss_oracle=q_ref.item(),
            median_rel_rms=med, worst_rel_rms=worst, worst_param=wname, emulated_median_rel_rms=med_e, emulated_worst_rel_rms=worst_e,
-           emulated_worst_param=wname_e, edges_fp32=edges, edges_emulated=edges_e)
+           emulated_worst_param=wname_e, edges_fp32=edges, edges_emulated=edges_e, emulated_pass_run=tol_emul is not None)
     assert worst < tol_fp32, (wname, worst)
-    assert worst_e < tol_emul, (wname_e, worst_e)
+    assert tol_emul is None or worst_e < tol_emul, (wname_e, worst_e)
     assert edges_e['q_loss'] < 1e-4 + 1e-4 * abs(q_ref.item())
     return m, h
 
 
 def test_latent_action_small_all_gradients():
     """A toy R-lam model: indices, losses and every parameter gradient (the r2 test compared one scalar)."""
-    m, h = check_lam('latent_action_small', SMALL_ENC, SMALL_DEC, 4, 64, (2, 4, 16, 16), 11, tol_fp32=0.08, tol_emul=0.03)
+    m, h = check_lam('latent_action_small', SMALL_ENC, SMALL_DEC, 4, 64, (2, 4, 16, 16), 11, tol_fp32=0.05, tol_emul=0.03)
     assert m.sample(h['idxs']).shape == (2, 4, 4)
 
 
@@ -155,4 +157,4 @@ def test_latent_action_configs2_size_parity():
     d_codebook = 8 is kept), one 16 x 64 x 64 clip: S = 4096 spatial attention over 16 frames, causal temporal attention over 4096 pixels,
     the K = 262144 projection, the quantised-action condition of the decoder -- the launches scripts/bench_models.py times."""
     from genie import LATENT_ACT_DEC, LATENT_ACT_ENC
-    check_lam('latent_action_configs2', LATENT_ACT_ENC, LATENT_ACT_DEC, 8, 256, (1, 16, 64, 64), 5, tol_fp32=0.10, tol_emul=0.03)
+    check_lam('latent_action_configs2', LATENT_ACT_ENC, LATENT_ACT_DEC, 8, 256, (1, 16, 64, 64), 5, tol_fp32=0.03)

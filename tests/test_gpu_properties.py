@@ -215,10 +215,12 @@ def test_gradient_determinism(G):
         assert l1 == l2, (det, l1, l2)                          # the forward pass has no atomics: the loss is bit-identical
         spread = {n: ((g1[n] - g2[n]).float().norm() / (g1[n].float().norm() + 1e-30)).item() for n in g1}
         worst = max(spread, key=spread.get)
-        out['deterministic' if det else 'default'] = (spread[worst], worst, sum(1 for v in spread.values() if v == 0), len(spread))
-        assert spread[worst] < 1e-5, (det, worst, spread[worst])
+        top = sorted(spread.items(), key=lambda kv: -kv[1])[:5]
+        out['deterministic' if det else 'default'] = (spread[worst], worst, sum(1 for v in spread.values() if v == 0), len(spread), top)
+        assert spread[worst] < 1e-5, (det, top)
         if det:
             moving = [n for n, v in spread.items() if v != 0 and n.endswith('weight') and g1[n].dim() == 5]
             assert not moving, moving                           # every conv weight gradient bit-identical
     report('gradient_determinism', default_worst_rel=out['default'][0], default_worst_param=out['default'][1], default_bit_identical=out['default'][2],
-           deterministic_worst_rel=out['deterministic'][0], deterministic_bit_identical=out['deterministic'][2], params=out['default'][3])
+           deterministic_worst_rel=out['deterministic'][0], deterministic_bit_identical=out['deterministic'][2], params=out['default'][3],
+           default_top5=out['default'][4], deterministic_top5=out['deterministic'][4])
