@@ -47,42 +47,69 @@ def effective_cpus() -> int:
 
 
 def _cpu_baseline_worker(threads: int, frames: int, q) -> None:
+    import copy
     import statistics
 
     import torch as T
     from genie import MAGVIT2_DEC_DESC, MAGVIT2_ENC_DESC, VideoTokenizer
     from oracle import genie_oracle as O
+    from oracle import ref_import
     T.manual_seed(0)
     T.set_num_threads(threads)
-    m = VideoTokenizer(MAGVIT2_ENC_DESC, MAGVIT2_DEC_DESC, d_codebook=18, gan_loss_weight=0., perc_loss_weight=0.)
-    sd = {k: (v.detach().contiguous().clone().requires_grad_(v.is_floating_point())) for k, v in m.state_dict().items()}
-    del m
-    opt = T.optim.AdamW([v for v in sd.values() if v.requires_grad], lr=1e-3, weight_decay=0.01)
     x = T.randn(1, CLIP[0], frames, CLIP[2], CLIP[3])
+    kind = 'port'
+    if ref_import.reference_available():
+        # the REAL reference modules ("reference modules via the 8c stubs"), whenever /root/reference is present (the build
+        # container; the GPU box has no copy of it): reference VideoTokenizer.encode / .quant / .decode composed into the R-fwd step
+        # (its own forward() needs the VGG16 critic), reference-default AdamW
+        try:
+            ref = ref_import.import_reference()
+            rm = ref.VideoTokenizer(copy.deepcopy(MAGVIT2_ENC_DESC), copy.deepcopy(MAGVIT2_DEC_DESC), d_codebook=18, gan_loss_weight=0., perc_loss_weight=0.).train()
+            ropt = T.optim.AdamW(rm.parameters(), lr=1e-3, weight_decay=0.01)
 
-    def step():
-        t0 = time.perf_counter()
-        opt.zero_grad(set_to_none=True)
-        loss, _, _, _ = O.tokenizer_forward_hotpath(x, sd, MAGVIT2_ENC_DESC, MAGVIT2_DEC_DESC, 18)
-        loss.backward()
-        opt.step()
-        return time.perf_counter() - t0
+            def step():
+                t0 = time.perf_counter()
+                ropt.zero_grad(set_to_none=True)
+                enc = rm.encode(x)
+                (qt, _), ql = rm.quant(enc, transpose=True)
+                loss = T.nn.functional.mse_loss(rm.decode(qt), x) + ql
+                loss.backward()
+                ropt.step()
+                return time.perf_counter() - t0
+            kind = 'reference'
+        except Exception:
+            kind = 'port'
+    if kind == 'port':
+        m = VideoTokenizer(MAGVIT2_ENC_DESC, MAGVIT2_DEC_DESC, d_codebook=18, gan_loss_weight=0., perc_loss_weight=0.)
+        sd = {k: (v.detach().contiguous().clone().requires_grad_(v.is_floating_point())) for k, v in m.state_dict().items()}
+        del m
+        opt = T.optim.AdamW([v for v in sd.values() if v.requires_grad], lr=1e-3, weight_decay=0.01)
+
+        def step():
+            t0 = time.perf_counter()
+            opt.zero_grad(set_to_none=True)
+            loss, _, _, _ = O.tokenizer_forward_hotpath(x, sd, MAGVIT2_ENC_DESC, MAGVIT2_DEC_DESC, 18)
+            loss.backward()
+            opt.step()
+            return time.perf_counter() - t0
 
     first = step()                                          # warm-up 1 (also tells how many more steps the budget allows)
     warm, timed = (2, 3) if first < 14.0 else ((1, 1) if first < 40.0 else (1, 0))
     for _ in range(warm - 1):
         step()
     times = [step() for _ in range(timed)] or [first]
-    q.put((statistics.median(times), warm if timed else 0, len(times), T.get_num_threads()))
+    q.put((statistics.median(times), warm if timed else 0, len(times), T.get_num_threads(), kind))
 
 
 def cpu_baseline(budget_s: float = 170.0):
-    """The oracle (a port of the reference's algorithm, fp32 torch CPU) doing the SAME training step -- fwd + bwd + AdamW of the MAGVIT2
-    tokenizer on one 16x64x64 clip -- on the host cores: BASELINE.md section 3 protocol, 2 warm-up + 3 timed steps, median (fewer
-    when the first (cold) step takes longer than 14 s; 4-frame clips if nothing finishes inside the budget).  Runs in a child process with a
-    hard time budget; threads = the CPUs this process may use (affinity / cgroup quota), capped at 64."""
+    """The CPU path doing the SAME training step -- fwd + bwd + AdamW of the MAGVIT2 tokenizer on one 16x64x64 clip -- on the host cores:
+    the REAL reference modules when /root/reference is present (`kind: "reference"`; the build container), otherwise the oracle's
+    restatement of them (`kind: "port"`; the GPU box, which has no copy of the reference).  BASELINE.md section 3 protocol, 2 warm-up +
+    3 timed steps, median (fewer when the first (cold) step takes longer than 14 s; 4-frame clips if nothing finishes inside the
+    budget).  Runs in a child process with a hard time budget; threads = every CPU this process may use (affinity mask capped by the
+    cgroup quota; the GPU boxes of the pool grant 16 of their 256), at most 128."""
     import multiprocessing as mp
-    threads = min(effective_cpus(), 64)
+    threads = min(effective_cpus(), 128)
     ctx = mp.get_context('spawn')
     for frames in (CLIP[1], 4):
         q = ctx.Queue()
@@ -94,11 +121,24 @@ def cpu_baseline(budget_s: float = 170.0):
             p.join()
             continue
         if p.exitcode == 0:
-            dt, warm, timed, nthr = q.get()
-            return {'value': round(frames / dt, 4), 'unit': 'video-frames/sec', 'cores': nthr, 'kind': 'port',
-                    'sample': f'training step (fwd+bwd+AdamW) of the MAGVIT2 tokenizer on one {frames}x64x64 clip, fp32, torch CPU, {nthr} threads of '
+            dt, warm, timed, nthr, kind = q.get()
+            return {'value': round(frames / dt, 4), 'unit': 'video-frames/sec', 'cores': nthr, 'kind': kind,
+                    'sample': f'training step (fwd+bwd+AdamW) of the MAGVIT2 tokenizer ({"reference modules" if kind == "reference" else "oracle restatement of the reference"}) on one {frames}x64x64 clip, fp32, torch CPU, {nthr} threads of '
                               f'{os.cpu_count()} host CPUs: {warm} warm-up + {timed} timed steps, median {dt:.2f} s/step'}
     return {'value': None, 'unit': 'video-frames/sec', 'cores': threads, 'kind': 'port', 'sample': f'did not finish within {budget_s:.0f} s'}
+
+
+def csrc_sha16() -> str:
+    """Fingerprint of the kernel sources (the GPU box has no .git): profiles/rNN_summary.json records it, so that PMC figures measured
+    on other kernels are never attached to a run."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, 'open-genie_amd', 'csrc')
+    for f in sorted(os.listdir(d)):
+        if f.endswith(('.hip', '.h', '.cpp')):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), 'rb').read())
+    return h.hexdigest()[:16]
 
 
 def side_kernels():
@@ -132,7 +172,10 @@ def main():
     ap.add_argument('--steps', type=int, default=6)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--batch', type=int, default=int(os.environ.get('GENIE_BENCH_BATCH', 64)),
-                    help='clips per GPU per step (64: 69 GB of the 288 GB HBM; same-box sweep 8 / 16 / 32 / 64 / 96 clips: 1520 / 1766 / 1816 / 1863 / 1863 frames/s)')
+                    help='clips per GPU per step (64: 69 GB of the 288 GB HBM; same-box sweep 8 / 16 / 32 / 64 / 96 clips: 1520 / 1766 / 1816 / 1863 / 1863 frames/s).  '
+                         'Weak scaling (the default, `scaling: weak`) keeps this fixed as N grows; for a STRONG-scaling reading of a fixed global batch of 64 '
+                         'run --gpus N --batch 64/N (8 clips per GPU at N = 8: the low-resolution layers and the fixed per-step costs then weigh ~20 %% more)')
+    ap.add_argument('--buckets', type=int, default=int(os.environ.get('GENIE_DP_BUCKETS', 8)), help='N > 1: gradient all-reduce buckets of equal bytes (cut at layer boundaries)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-events', action='store_true')
     ap.add_argument('--all-kernel-events', action='store_true', help='HIP events around EVERY conv launch (full conv_kernels table; costs ~4 %% of the step)')
@@ -175,17 +218,18 @@ def main():
 
     from genie import MAGVIT2_DEC_DESC, MAGVIT2_ENC_DESC, VideoTokenizer, conv as gconv
     from genie import functional as GF
-    from genie.trainer import DataParallel, ParamArena
+    from genie.trainer import DataParallel, ParamArena, sync_replicas
     GF.ASYNC_WGRAD = int(args.async_wgrad)
 
-    torch.manual_seed(0)                                   # identical initial weights on every rank
+    torch.manual_seed(0)
     model = VideoTokenizer(MAGVIT2_ENC_DESC, MAGVIT2_DEC_DESC, d_codebook=18, gan_loss_weight=0., perc_loss_weight=0.).to(dev).train()
     arena = ParamArena(model)
+    sync_replicas(arena, model)                            # every rank starts from rank 0's weights (not from "everybody seeded alike")
     arena.attach_weight_packs(model)                       # bf16 packs ride on the optimiser kernel + one batched transpose
     dp = DataParallel(arena.grads, compress=args.grad_compress, loopback=args.dp_loopback)
     if dp.active:                                          # decoder gradients reduce while the encoder is still in backward
-        cuts = [model.dec_layers[i] for i in (0, 6, 12, 18)] + [model.enc_layers[i] for i in (6, 12)]
-        dp.install_overlap_hooks(arena, model, sorted(cuts, key=lambda mm: arena.offset_of(mm, model) or 0))
+        layers = [m_ for m_ in list(model.enc_layers) + list(model.dec_layers) if any(p_.requires_grad for p_ in m_.parameters())]
+        dp.install_overlap_hooks(arena, model, DataParallel.equal_byte_cuts(arena, model, layers, max(1, args.buckets)))
     B = args.batch
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)      # rank r holds clips r::world of the synthetic stream
     clips = [torch.randn(B, *CLIP, device=dev, generator=gen) for _ in range(2)]
@@ -203,6 +247,7 @@ def main():
     prof = None
     if not args.no_kernel_events:
         prof = gconv.PROFILER = gconv.LaunchProfiler(only_triple=not args.all_kernel_events and not args.dump)
+    dp.trace = dp.active                                   # HIP events around the bucket all-reduces and finish()'s wait (the `comm` object)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -215,6 +260,8 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     gconv.PROFILER = None
+    dp.trace = False
+    comm = dp.comm_report() if dp.active else None
     # The timed region runs every kernel in order on one stream (kernel durations = the kernels' own rates; `roofline` comes from
     # here).  Putting the weight-gradient kernels and the LFQ loss on a side stream (functional.ASYNC_WGRAD = 2) shortens the step by
     # ~4 % but a forward / backward-data kernel's wall time then includes the share of the chip a concurrent weight-gradient kernel
@@ -304,16 +351,28 @@ def main():
             os.makedirs(os.path.dirname(args.dump) or '.', exist_ok=True)
             with open(args.dump, 'w') as f:
                 json.dump(summ, f, indent=1)
+    if comm:
+        # why it scales (or does not): what backward hid of the gradient all-reduce and what it did not, bucket by bucket (rank 0's view)
+        out['comm'] = comm
     if world == 1 and not args.no_kernel_events:
         out.update(side_kernels())
-    prof_summary = next((pp for pp in (os.path.join(ROOT, 'profiles', f) for f in ('r02_summary.json', 'r01_summary.json')) if os.path.exists(pp)), '')
+    # `traffic`: HBM bytes per launch of the dominant kernel from PMC counters.  Counters cannot be collected inside this run (rocprofv3
+    # wraps the process), so the figure comes from the committed PMC passes of THIS command (scripts/profile_bench.sh ->
+    # profiles/rNN_summary.json) -- and only if that profile was taken on the same kernel sources and batch; otherwise it is stale and
+    # stays null (a silently carried-over number is worse than none).
+    prof_summary = next((pp for pp in (os.path.join(ROOT, 'profiles', f) for f in ('r03_summary.json', 'r02_summary.json')) if os.path.exists(pp)), '')
     if 'roofline' in out and prof_summary:
-        try:                                  # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes of this command
+        try:
             ps = json.load(open(prof_summary))
             tr = ps.get('traffic', {}).get(out['roofline']['kernel'])
-            if tr:
+            meta = ps.get('meta', {})
+            fresh = meta.get('csrc_sha16') == csrc_sha16() and int(meta.get('batch', -1)) == B
+            if tr and fresh:
                 out['roofline']['traffic'] = tr['bytes_per_launch']
                 out['roofline']['traffic_source'] = tr['source']
+            elif tr:
+                out['roofline']['traffic_stale'] = {'bytes_per_launch': tr['bytes_per_launch'], 'profile': os.path.basename(prof_summary),
+                                                    'why': f"profile taken at batch {meta.get('batch')} / kernel sources {meta.get('csrc_sha16')}, this run: batch {B} / {csrc_sha16()}"}
         except Exception:
             pass
     if world == 1 and not args.no_cpu_baseline:

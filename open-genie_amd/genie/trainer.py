@@ -221,6 +221,11 @@ class DataParallel:
         self.bytes_reduced = 0                           # payload bytes handed to all_reduce so far
         self.fired: List[int] = []                       # bucket indices in the order their reduction was issued (this step)
         self._hooks: list = []
+        # optional timing of the overlap (bench.py --gpus N): per step, HIP events at every bucket's issue point (compute stream), around
+        # its all-reduce (comm stream) and around finish()'s wait -- read back by comm_report() after a synchronise
+        self.trace = False
+        self._events: list = []                          # per step: {'issue': {i: ev}, 'comm': {i: (ev0, ev1)}, 'wait': (ev0, ev1)}
+        self._cur: Optional[dict] = None
 
     def _all_reduce_mean(self, chunk: Tensor, lo: int) -> None:
         if self.compress == 'bf16':
@@ -243,12 +248,26 @@ class DataParallel:
         chunk = self.grads[lo:hi]
         if self.comm_stream is not None:
             from . import functional as GF
+            tr = self._trace_step() if self.trace else None
+            if tr is not None:
+                ev = torch.cuda.Event(enable_timing=True); ev.record(torch.cuda.current_stream())
+                tr['issue'][lo] = ev
             self.comm_stream.wait_stream(torch.cuda.current_stream())       # behind every kernel enqueued so far ...
             GF.join_wgrad(self.comm_stream)                                 # ... including weight gradients on their side stream
             with torch.cuda.stream(self.comm_stream):
+                if tr is not None:
+                    e0 = torch.cuda.Event(enable_timing=True); e0.record(self.comm_stream)
                 self._all_reduce_mean(chunk, lo)
+                if tr is not None:
+                    e1 = torch.cuda.Event(enable_timing=True); e1.record(self.comm_stream)
+                    tr['comm'][lo] = (e0, e1)
         else:
             self._all_reduce_mean(chunk, lo)
+
+    def _trace_step(self) -> dict:
+        if self._cur is None:
+            self._cur = {'issue': {}, 'comm': {}, 'wait': None}
+        return self._cur
 
     def bucket_ready(self, index: int) -> None:
         """Gradients of bucket `index` (and of every later bucket) are fully enqueued."""
@@ -262,11 +281,49 @@ class DataParallel:
         """Reduce whatever is left and make the compute stream wait for the reductions (call before the optimiser)."""
         self.bucket_ready(0)
         if self.comm_stream is not None and self.active:
+            if self.trace:
+                tr = self._trace_step()
+                w0 = torch.cuda.Event(enable_timing=True); w0.record(torch.cuda.current_stream())      # = end of backward on the compute stream
             torch.cuda.current_stream().wait_stream(self.comm_stream)
+            if self.trace:
+                w1 = torch.cuda.Event(enable_timing=True); w1.record(torch.cuda.current_stream())
+                tr['wait'] = (w0, w1)
+                self._events.append(tr)
+                self._cur = None
         self._done = [False] * len(self.buckets)
         self.last_fired, self.fired = self.fired, []
         if hasattr(self, 'armed'):
             self.last_armed, self.armed = self.armed, []
+
+    def comm_report(self) -> dict:
+        """Mean over the traced steps (call after torch.cuda.synchronize()): per bucket its payload, how long before the END of
+        backward its all-reduce was issued and how long the collective took; `exposed_ms` = what the compute stream spent waiting for
+        the comm stream in finish() -- the communication that backward did NOT hide.  Makes a scaling run say why it scales."""
+        if not self._events:
+            return {}
+        n = len(self._events)
+        per = {}
+        exposed = 0.0
+        for tr in self._events:
+            w0, w1 = tr['wait']
+            exposed += w0.elapsed_time(w1)
+            for lo, ev in tr['issue'].items():
+                d = per.setdefault(lo, {'issued_before_backward_end_ms': 0.0, 'allreduce_ms': 0.0})
+                d['issued_before_backward_end_ms'] += ev.elapsed_time(w0)
+                e0, e1 = tr['comm'][lo]
+                d['allreduce_ms'] += e0.elapsed_time(e1)
+        el = 2 if self.compress == 'bf16' else 4
+        buckets = []
+        for (lo, hi) in self.buckets:
+            d = per.get(lo, {})
+            buckets.append({'elements': hi - lo, 'payload_MB': round((hi - lo) * el / 1e6, 1),
+                            'issued_before_backward_end_ms': round(d.get('issued_before_backward_end_ms', 0.0) / n, 3),
+                            'allreduce_ms': round(d.get('allreduce_ms', 0.0) / n, 3)})
+        tot = sum(b['allreduce_ms'] for b in buckets)
+        return {'steps_traced': n, 'exposed_ms_per_step': round(exposed / n, 3), 'allreduce_ms_per_step': round(tot, 3),
+                'hidden_fraction': round(1.0 - (exposed / n) / tot, 4) if tot > 0 else None,
+                'bus_GBps': round(sum(b['payload_MB'] for b in buckets) * 1e-3 * 2 * (self.world - 1) / max(self.world, 1) / (tot * 1e-3), 1) if tot > 0 else None,
+                'buckets': buckets}
 
     def reduce_scalars(self, values: Sequence[Tensor]) -> Tensor:
         """One all-reduce for all logged scalars of a step (mean over ranks)."""
@@ -316,6 +373,23 @@ class DataParallel:
             # A stage whose input carries no gradient (integer tokens) or that is entered through another method than __call__ simply
             # stays un-armed in that step and is reduced by finish() -- late, never early.
             self._hooks.append(self.entry_module(mod).register_forward_pre_hook(pre_hook))
+
+    @staticmethod
+    def equal_byte_cuts(arena: ParamArena, root: nn.Module, candidates: Sequence[nn.Module], nbuckets: int) -> List[nn.Module]:
+        """Pick from `candidates` (modules in forward order, e.g. the layers of enc_layers + dec_layers) the ones whose first parameter
+        lies closest to the k / nbuckets points of the arena: buckets of (nearly) equal BYTES, so that the all-reduces of a step take
+        equal times and the last one -- the only one backward cannot hide -- is as small as the others (bench.py used hard-coded layer
+        indices in round 2)."""
+        offs = [(arena.offset_of(m, root), m) for m in candidates]
+        offs = [(o, m) for o, m in offs if o is not None and 0 < o < arena.numel]
+        picks, used = [], set()
+        for k in range(1, nbuckets):
+            target = arena.numel * k / nbuckets
+            o, m = min(offs, key=lambda om: abs(om[0] - target), default=(None, None))
+            if o is not None and o not in used:
+                used.add(o)
+                picks.append((o, m))
+        return [m for _, m in sorted(picks, key=lambda om: om[0])]
 
     @staticmethod
     def entry_module(mod: nn.Module) -> nn.Module:

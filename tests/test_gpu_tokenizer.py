@@ -196,7 +196,8 @@ def test_magvit2_full_training_step_parity():
     arithmetic -- loss 3 %, per-parameter relative-RMS gradient error < 20 %, median < 6 % (what bf16 STORAGE of activations and
     gradients through 40 residual blocks costs; reported); (2) LAYER BY LAYER against the same oracle rounding to bf16 exactly where the
     HIP path stores (oracle.set_rounding('bf16_at_stores')), each of the 49 layer steps fed the HIP run's own input and output gradient
-    -- every parameter gradient within 1 %, median < 0.3 %, layer outputs within 0.5 %: the parity bound proper.  A 5 % systematic error
+    -- every parameter gradient within 0.3 % (measured 0.06 %), median < 0.05 %, layer outputs / input gradients within 0.3 %: the parity
+    bound proper.  A 5 % systematic error
     in one layer's weight gradient passes (1) and fails (2)."""
     from genie import MAGVIT2_DEC_DESC, MAGVIT2_ENC_DESC, VideoTokenizer
     from genie import functional as GF
@@ -308,9 +309,10 @@ def test_magvit2_full_training_step_parity():
            p95_rel_rms=p95, worst_rel_rms=worst, worst_param=wname, dlatent_rel_rms=dq, lfq_indices_bit_exact=True,
            per_layer_median_rel_rms=med_l, per_layer_p95_rel_rms=p95_l, per_layer_worst_rel_rms=worst_l, per_layer_worst_param=wname_l,
            per_layer_output_worst=fwd_err[wf], per_layer_output_worst_layer=wf, per_layer_dx_worst=dx_err[wd], per_layer_dx_worst_layer=wd, layers=len(rec))
-    assert worst_l < 0.01, (wname_l, worst_l)                                  # every parameter gradient within 1 %
-    assert med_l < 0.003, med_l
-    assert fwd_err[wf] < 0.005 and dx_err[wd] < 0.01, (wf, fwd_err[wf], wd, dx_err[wd])
+    # VERDICT r2 item 2 asked for every parameter gradient within 1 %; measured: worst 6.3e-4, median 1e-5, outputs 7.3e-4, dx 5.5e-4
+    assert worst_l < 0.003, (wname_l, worst_l)
+    assert med_l < 0.0005, med_l
+    assert fwd_err[wf] < 0.003 and dx_err[wd] < 0.003, (wf, fwd_err[wf], wd, dx_err[wd])
 
 
 @pytest.mark.default_grads

@@ -42,6 +42,6 @@ def report(name: str, **values) -> None:
         d = os.path.join(ROOT, 'gpurun_out')
         os.makedirs(d, exist_ok=True)
         with open(os.path.join(d, 'parity_report.jsonl'), 'a') as f:
-            f.write(json.dumps({'test': name, **{k: (round(v, 6) if isinstance(v, float) else v) for k, v in values.items()}}) + '\n')
+            f.write(json.dumps({'test': name, **{k: ((round(v, 6) if abs(v) >= 1e-3 else float(f'{v:.3e}')) if isinstance(v, float) else v) for k, v in values.items()}}) + '\n')
     except OSError:
         pass
