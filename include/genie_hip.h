@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GENIE_ABI_VERSION 7
+#define GENIE_ABI_VERSION 8
 
 #define GENIE_F32 0
 #define GENIE_BF16 1
@@ -182,6 +182,12 @@ typedef struct GenieWgradDesc {
     int32_t pointwise;    /* 1: ONE tap with dt = dh = dw = 0 (a 1x1x1 stride-1 convolution or a Linear layer): with >= 256 channels on
                              both sides and >= 192 output tiles of 256 x 256 (the vocabulary head) the transposing-read GEMM of
                              conv_wgrad_pw.hip takes it; 2: that kernel whatever the tile count */
+    int32_t dy_unshuffled; /* 1 (ABI 8): the conv is a depth-to-space-time upsample conv (shuf_c = final channel count < Cout) but `dy` has ALREADY
+                             been un-shuffled into the conv's own row grid (Td, Hd, Wd) = (To, Ho, Wo), dm* = 1, with sub-pixel-major channels
+                             co' = sub * shuf_c + ch (genie_unshuffle_cl, the tensor the backward-data pass consumes as well).  The gradient
+                             row of co' is the natural weight row (co' % shuf_c) * (Cout / shuf_c) + co' / shuf_c.  Served by the lean
+                             kw-triple kernel only (GENIE_ERR_ARG when its preconditions do not hold: tri_mode != 0, W in {8, 16, 32, 64},
+                             H * W a multiple of 64, Cin, Cout >= 64) */
 } GenieWgradDesc;
 
 int genie_conv_wgrad(const GenieWgradDesc* desc, void* stream);

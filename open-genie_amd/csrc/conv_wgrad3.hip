@@ -610,7 +610,9 @@ __global__ void __launch_bounds__(512) wgrad3l_kernel(const Wgrad3Args a) {
         for (int r16 = 0; r16 < 16; ++r16) {
             const int co = co0 + wm * 64 + i * 32 + (r16 & 3) + 8 * (r16 >> 2) + 4 * khalf;
             if (co >= a.Cout) continue;
-            float* row = a.dw + co * a.s_cout + (long long)(3 * tr) * a.s_tap;
+            // un-shuffled upsample gradient (dy_unshuffled): dy channel co = sub-pixel co / shuf_c, channel co % shuf_c -> natural weight row
+            const int co_nat = a.shuf_f > 1 ? (co % a.shuf_c) * a.shuf_f + co / a.shuf_c : co;
+            float* row = a.dw + co_nat * a.s_cout + (long long)(3 * tr) * a.s_tap;
             if (ci < a.Cin) {
                 if (a.split_k == 1) {                           // one owner per element: plain read-modify-write (no atomics)
 #pragma unroll
@@ -620,7 +622,7 @@ __global__ void __launch_bounds__(512) wgrad3l_kernel(const Wgrad3Args a) {
                     for (int s = 0; s < 3; ++s) atomicAdd(row + s * a.s_tap + ci * a.s_cin, acc[s][i][r16]);
                 }
             }
-            if (do_bias && (lane & 31) == 0) atomicAdd(a.dbias + co, accb[i][r16]);
+            if (do_bias && (lane & 31) == 0) atomicAdd(a.dbias + co_nat, accb[i][r16]);
         }
     }
 }
@@ -628,6 +630,11 @@ __global__ void __launch_bounds__(512) wgrad3l_kernel(const Wgrad3Args a) {
 // Returns 1 when the problem is not eligible (caller falls back to the generic kernel), 0 on launch, < 0 on error.
 int genie_conv_wgrad3_try(const GenieWgradDesc* d, hipStream_t s) {
     if (d->tri_mode <= 0) return 1;
+    if (d->dy_unshuffled && !(d->Td == d->To && d->Hd == d->Ho && d->Wd == d->Wo && d->dmt == 1 && d->dmh == 1 && d->dmw == 1 && d->shuf_c < d->Cout &&
+                              d->Cout % d->shuf_c == 0)) {
+        genie_set_error("genie_conv_wgrad: dy_unshuffled wants dy on the conv's own row grid and shuf_c | Cout");
+        return GENIE_ERR_ARG;
+    }
     if (d->st != 1 || d->sh != 1 || d->sw != 1 || d->To != d->Ts || d->Ho != d->Hs || d->Wo != d->Ws) return 1;
     if (d->ntaps % 3 != 0 || d->ntaps < 3) return 1;
     const int W = d->Wo;
@@ -639,8 +646,8 @@ int genie_conv_wgrad3_try(const GenieWgradDesc* d, hipStream_t s) {
     a.T = d->Ts; a.H = d->Hs; a.W = W; a.Cs = d->Cs; a.Cin = d->Cin;
     a.Td = d->Td; a.Hd = d->Hd; a.Wd = d->Wd; a.Cd = d->Cd; a.Cout = d->Cout;
     a.dmt = d->dmt; a.dmh = d->dmh; a.dmw = d->dmw;
-    const bool shuffled = d->shuf_c < d->Cout;
-    if (shuffled) {
+    const bool shuffled = d->shuf_c < d->Cout && !d->dy_unshuffled;          // dy addressed THROUGH the shuffle (general kernel only)
+    if (d->shuf_c < d->Cout) {
         if (d->shuf_c % 8 != 0 || d->Cout % d->shuf_c != 0) return 1;
         a.shuf_c = d->shuf_c; a.shuf_q = d->shuf_q; a.shuf_r = d->shuf_r; a.shuf_f = d->Cout / d->shuf_c;
     } else {
@@ -720,6 +727,10 @@ int genie_conv_wgrad3_try(const GenieWgradDesc* d, hipStream_t s) {
         hipLaunchKernelGGL(lk, dim3((unsigned)(base * a.split_k)), dim3(512), lds, s, a);
         GENIE_CHECK_LAUNCH();
         return GENIE_OK;
+    }
+    if (d->dy_unshuffled) {
+        genie_set_error("genie_conv_wgrad: dy_unshuffled is served by the lean kw-triple kernel only (H * W %% 64 == 0, 64 / W <= H, block range < 2 GiB)");
+        return GENIE_ERR_ARG;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)(base * a.split_k)), dim3(512), lds, s, a);
     GENIE_CHECK_LAUNCH();

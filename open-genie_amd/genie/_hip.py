@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('GENIE_HIP_LIB', os.path.join(os.path.dirname(_HERE), 'lib', 'libgenie_hip.so'))
 
 GENIE_F32, GENIE_BF16 = 0, 1
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class GenieTap(C.Structure):
@@ -52,7 +52,7 @@ class GenieWgradDesc(C.Structure):
                 ('dot', C.c_int32), ('doh', C.c_int32), ('dow', C.c_int32),
                 ('shuf_c', C.c_int32), ('shuf_q', C.c_int32), ('shuf_r', C.c_int32),
                 ('s_cout', C.c_int64), ('s_tap', C.c_int64), ('s_cin', C.c_int64), ('split_k', C.c_int32), ('tri_mode', C.c_int32),
-                ('pointwise', C.c_int32)]
+                ('pointwise', C.c_int32), ('dy_unshuffled', C.c_int32)]
 
 
 class GeniePackJob(C.Structure):

@@ -546,8 +546,11 @@ def _plain(spec: ConvSpec) -> ConvSpec:
 
 
 def conv_dgrad(dy: Tensor, wpack_bwd: Tensor, spec: ConvSpec, in_size: Triple, resid: Optional[Tensor] = None,
-               gnb: Optional[GnBwdFuse] = None) -> Tensor:
-    """Gradient w.r.t. the conv input.  dy is the CL gradient of the (shuffled) output.  `gnb`: see GnBwdFuse."""
+               gnb: Optional[GnBwdFuse] = None, dy_unshuffled: Optional[Tensor] = None) -> Tensor:
+    """Gradient w.r.t. the conv input.  dy is the CL gradient of the (shuffled) output.  `gnb`: see GnBwdFuse.  `dy_unshuffled`:
+    ``unshuffle_dy(dy, spec)`` when the caller already made it (it shares the tensor with the weight gradient)."""
+    if dy_unshuffled is not None:
+        return conv_dgrad(dy_unshuffled, wpack_bwd, _plain(spec), in_size, resid)
     _check_cl(dy, spec.cfinal, 'conv_dgrad')
     if spec.shuffle is not None and (spec.cfinal % 8 != 0 or (UPCONV_DGRAD_UNSHUFFLE and spec.stride == (1, 1, 1) and spec.kernel[2] == 3
                                                               and spec.cout % 64 == 0 and spec.cin >= 128)):
@@ -623,15 +626,32 @@ def conv_dgrad(dy: Tensor, wpack_bwd: Tensor, spec: ConvSpec, in_size: Triple, r
     return dx
 
 
-def conv_wgrad(x: Tensor, dy: Tensor, spec: ConvSpec, dweight: Tensor, dbias: Optional[Tensor]) -> None:
-    """Accumulate dW (fp32, any strides, shape (cout, cin, kt, kh, kw)) and dbias (fp32 [cout])."""
+def wgrad_unshuffled_ok(spec: ConvSpec, x: Tensor) -> bool:
+    """May the weight gradient of this upsample conv take the UN-SHUFFLED output gradient (the tensor `unshuffle_dy` makes for the
+    backward-data pass) instead of gathering dy through the shuffle?  The preconditions of the lean kw-triple kernel (conv_wgrad3.hip)."""
+    t, h, w = x.shape[2:]
+    return bool(UPCONV_DGRAD_UNSHUFFLE and TRI_WGRAD and spec.shuffle is not None and spec.cfinal % 8 == 0 and spec.stride == (1, 1, 1) and spec.kernel[2] == 3
+                and spec.dilation[2] == 1 and spec.pad_front[2] == 1 and spec.pad_back[2] == 1 and spec.out_size((t, h, w)) == (t, h, w)
+                and w in (8, 16, 32, 64) and (h * w) % 64 == 0 and 64 // w <= h and spec.cin >= 64 and spec.cout >= 64
+                and os.environ.get('GENIE_W3_LEAN', '1') != '0')
+
+
+def unshuffle_dy(dy: Tensor, spec: ConvSpec) -> Tensor:
+    """The output gradient of an upsample conv brought back onto the conv's own row grid, sub-pixel-major channels '(p q r c)': what both
+    backward passes of the conv consume (conv_dgrad(..., dy_unshuffled=...) / conv_wgrad(..., dy_unshuffled=True))."""
+    return _unshuffle(dy, spec, 'pqrc')
+
+
+def conv_wgrad(x: Tensor, dy: Tensor, spec: ConvSpec, dweight: Tensor, dbias: Optional[Tensor], dy_unshuffled: bool = False) -> None:
+    """Accumulate dW (fp32, any strides, shape (cout, cin, kt, kh, kw)) and dbias (fp32 [cout]).  `dy_unshuffled`: `dy` is
+    ``unshuffle_dy(dy, spec)`` of an upsample conv (only where ``wgrad_unshuffled_ok``)."""
     _check_cl(x, spec.cin, 'conv_wgrad(x)')
-    _check_cl(dy, spec.cfinal, 'conv_wgrad(dy)')
+    _check_cl(dy, spec.cout if dy_unshuffled else spec.cfinal, 'conv_wgrad(dy)')
     if spec.shuffle is not None and spec.cfinal % 8 != 0:
         return conv_wgrad(x, _unshuffle(dy, spec, 'cpqr'), _plain(spec), dweight, dbias)
     n, _, t, h, w = x.shape
     to, ho, wo = spec.out_size((t, h, w))
-    P, Q, R = spec.shuffle if spec.shuffle is not None else (1, 1, 1)
+    P, Q, R = spec.shuffle if spec.shuffle is not None and not dy_unshuffled else (1, 1, 1)
     assert tuple(dy.shape[2:]) == (to * P, ho * Q, wo * R)
     assert dweight.dtype == torch.float32 and tuple(dweight.shape) == (spec.cout, spec.cin, *spec.kernel)
     if narrow_wgrad_ok(spec, x, dy):
@@ -650,12 +670,13 @@ def conv_wgrad(x: Tensor, dy: Tensor, spec: ConvSpec, dweight: Tensor, dbias: Op
     d.dmt, d.dmh, d.dmw = P, Q, R
     d.dot = d.doh = d.dow = 0
     if spec.shuffle is not None:
-        d.shuf_c, d.shuf_q, d.shuf_r = spec.cfinal, Q, R
+        d.shuf_c, d.shuf_q, d.shuf_r = spec.cfinal, spec.shuffle[1], spec.shuffle[2]
     else:
         d.shuf_c, d.shuf_q, d.shuf_r = spec.cout, 1, 1
+    d.dy_unshuffled = 1 if dy_unshuffled else 0
     d.s_cout, d.s_tap, d.s_cin = s[0], s[4], s[1]
     d.split_k = 1 if DETERMINISTIC else FORCE_SPLIT_K
-    d.tri_mode = TRI_WGRAD if (TRI_WGRAD and spec.stride == (1, 1, 1) and spec.kernel[2] == 3 and spec.dilation[2] == 1
+    d.tri_mode = (2 if dy_unshuffled else TRI_WGRAD) if (TRI_WGRAD and spec.stride == (1, 1, 1) and spec.kernel[2] == 3 and spec.dilation[2] == 1
                        and spec.pad_front[2] == 1 and spec.pad_back[2] == 1 and (to, ho, wo) == (t, h, w)) else 0
     d.pointwise = WGRAD_PW if _is_pointwise(spec) else 0
     t0 = PROFILER.begin() if PROFILER is not None and not PROFILER.only_triple else None

@@ -64,15 +64,15 @@ def wgrad_stream(device=None):
     return st
 
 
-def _wgrad(x: Tensor, dy: Tensor, spec, gw: Tensor, gb: Optional[Tensor]) -> None:
+def _wgrad(x: Tensor, dy: Tensor, spec, gw: Tensor, gb: Optional[Tensor], dy_unshuffled: bool = False) -> None:
     """conv_wgrad into arena-managed gradients, on the side stream when ASYNC_WGRAD is on."""
     if not ASYNC_WGRAD:
-        conv_wgrad(x, dy, spec, gw, gb)
+        conv_wgrad(x, dy, spec, gw, gb, dy_unshuffled)
         return
     side = wgrad_stream(x.device)
     side.wait_stream(torch.cuda.current_stream())              # x and dy are complete
     with torch.cuda.stream(side):
-        conv_wgrad(x, dy, spec, gw, gb)
+        conv_wgrad(x, dy, spec, gw, gb, dy_unshuffled)
     x.record_stream(side)                                      # the caching allocator must not hand these out again before the kernel ran
     dy.record_stream(side)
     _wgrad_pending.add(side.device.index)
@@ -197,12 +197,15 @@ class _Conv3dFn(torch.autograd.Function):
         op: ConvOp = ctx.op
         dy = to_cl(dy)
         dx = dw = db = None
+        # upsample conv: ONE un-shuffle of the output gradient serves the backward-data pass and the weight gradient (both then run the
+        # plain kw-triple kernels on the conv's own row grid instead of gathering through the depth-to-space shuffle)
+        dyu = _conv.unshuffle_dy(dy, op.spec) if _conv.wgrad_unshuffled_ok(op.spec, x) else None
         if ctx.needs_input_grad[0]:
             _conv_gate()
             if _conv.narrow_dgrad_ok(op.spec, dy):
                 dx = _conv.conv_narrow_in(dy, op.pack_narrow(weight, None, True), op.spec.pad_front[0] - 2, f'dgrad 128->{op.spec.cout} k3 @{tuple(dy.shape[2:])}')
             else:
-                dx = conv_dgrad(dy, op.pack_bwd(weight), op.spec, ctx.in_size)
+                dx = conv_dgrad(dy, op.pack_bwd(weight), op.spec, ctx.in_size, dy_unshuffled=dyu)
         need_w = ctx.needs_input_grad[1]
         need_b = bias is not None and ctx.needs_input_grad[2]
         if need_w or need_b:
@@ -213,11 +216,11 @@ class _Conv3dFn(torch.autograd.Function):
             if wleaf is not None and _direct(wleaf) and wleaf.is_leaf and (wleaf is weight or linear_view) and (bias is None or (bias.is_leaf and _direct(bias))):
                 gw = _grad_buffer(wleaf).view(weight.shape) if wleaf is not weight else _grad_buffer(weight)
                 gb = _grad_buffer(bias) if need_b else None
-                (_wgrad if getattr(wleaf, '_genie_arena', False) else conv_wgrad)(x, dy, op.spec, gw, gb)
+                (_wgrad if getattr(wleaf, '_genie_arena', False) else conv_wgrad)(x, dy if dyu is None else dyu, op.spec, gw, gb, dyu is not None)
             else:
                 dw = torch.zeros(weight.shape, dtype=torch.float32, device=weight.device)
                 db = torch.zeros_like(bias) if need_b else None
-                conv_wgrad(x, dy, op.spec, dw, db)
+                conv_wgrad(x, dy if dyu is None else dyu, op.spec, dw, db, dyu is not None)
         dres = dy if ctx.has_resid and ctx.needs_input_grad[4] else None
         return dx, dw, db, None, dres
 

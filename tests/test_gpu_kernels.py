@@ -527,6 +527,48 @@ def test_conv_wgrad_triple_kernel(G, cin, cout, kernel, causal, size, shuffle, m
     torch.testing.assert_close(dw.cpu(), 2 * wt.grad, rtol=1e-3, atol=2e-3 * wt.grad.abs().max().item())
 
 
+@pytest.mark.parametrize('cin,cf,fac,size', [(128, 64, (1, 2, 2), (2, 2, 4, 16)), (64, 32, (2, 2, 2), (1, 3, 8, 8)), (256, 128, (2, 2, 2), (2, 2, 8, 16)), (72, 24, (1, 2, 2), (1, 2, 2, 32))])
+def test_conv_wgrad_unshuffled_dy(G, cin, cf, fac, size):
+    """Upsample convs in backward: ONE un-shuffle of the output gradient (genie_unshuffle_cl, sub-pixel-major channels) feeds the plain
+    backward-data conv AND the lean kw-triple weight-gradient kernel, which permutes its rows back to the natural '(c p q r)' weight
+    order (GenieWgradDesc.dy_unshuffled); both against autograd of conv + depth-to-space-time rearrange."""
+    from oracle import genie_oracle as O
+    torch.manual_seed(17)
+    n, t, h, w = size
+    P, Q, R = fac
+    cout = cf * P * Q * R
+    x = bf16_round(torch.randn(n, cin, t, h, w)).requires_grad_(True)
+    wt = bf16_round(torch.randn(cout, cin, 3, 3, 3) / (cin * 27) ** 0.5).requires_grad_(True)
+    b = torch.randn(cout, requires_grad=True)
+    ref = O.depth_to_spacetime(O.causal_conv3d(x, wt, b), P, Q)
+    dy = bf16_round(torch.randn_like(ref))
+    ref.backward(dy)
+    spec = G.conv.causal_spec(cin, cout, (3, 3, 3), shuffle=fac)
+    xc, dyc = G.cl.to_cl(x.detach().cuda()), G.cl.to_cl(dy.cuda())
+    assert G.conv.wgrad_unshuffled_ok(spec, xc)
+    dyu = G.conv.unshuffle_dy(dyc, spec)
+    assert tuple(dyu.shape) == (n, cout, t, h, w)
+    dw = torch.zeros(cout, cin, 3, 3, 3, device='cuda').contiguous(memory_format=torch.channels_last_3d)
+    db = torch.zeros(cout, device='cuda')
+    G.conv.conv_wgrad(xc, dyu, spec, dw, db, True)
+    assert G.hip.load_library().genie_last_conv_variant() == 14
+    torch.testing.assert_close(dw.cpu(), wt.grad, rtol=1e-3, atol=1e-3 * wt.grad.abs().max().item())
+    torch.testing.assert_close(db.cpu(), b.grad, rtol=1e-3, atol=1e-3 * b.grad.abs().max().item())
+    dx = G.conv.conv_dgrad(dyc, G.conv.pack_weight_bwd(wt.detach().cuda(), spec), spec, (t, h, w), dy_unshuffled=dyu)
+    assert_close_bf16(dx, x.grad, 'dgrad from the shared un-shuffled gradient')
+    # and through the autograd binding: same numbers as the gather-through-the-shuffle path
+    from genie.module.video import DepthToSpaceTimeUpsample
+    m = DepthToSpaceTimeUpsample(cin, cf, time_factor=P, space_factor=Q, kernel_size=3).cuda()
+    conv = m.go_up[0].conv3d
+    with torch.no_grad():
+        conv.weight.copy_(wt.detach())
+        conv.bias.copy_(b.detach())
+    xg = x.detach().cuda().requires_grad_(True)
+    m(xg).backward(dy.cuda())
+    torch.testing.assert_close(conv.weight.grad.cpu(), wt.grad, rtol=1e-3, atol=1e-3 * wt.grad.abs().max().item())
+    assert_close_bf16(xg.grad, x.grad, 'module backward')
+
+
 @pytest.mark.parametrize('cin,cf,fac,size', [(64, 32, (2, 2, 2), (1, 2, 4, 4)), (128, 64, (1, 2, 2), (2, 2, 3, 5)), (64, 256, (2, 2, 2), (1, 2, 4, 4)),
                                              (64, 3, (1, 4, 4), (1, 2, 4, 4))])
 def test_conv_shuffle_wgrad(G, cin, cf, fac, size):
