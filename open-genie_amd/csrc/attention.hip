@@ -634,292 +634,6 @@ __global__ void __launch_bounds__(64 * NW) attn_fwd_kernel(const AttnArgs a) {
     }
 }
 
-// Forward, software-pipelined (round 3).  Same arithmetic, tiles, LDS layout and epilogue as attn_fwd_kernel above; the difference is the
-// ORDER inside a wave.  There a wave ran QK^T (8 MFMAs) -> softmax (~175 VALU, the matrix pipe idle for this wave) -> PV (8 MFMAs) per
-// 64-key tile, and only co-resident waves of OTHER blocks filled the gaps (SQ counters at S = 4096, 4 x 64: matrix pipe 38 % busy, VALU
-// 37 %, waves stalled or parked 62 % of their cycles -- neither pipe is the limit, the serial chain inside a wave is).  Here the scores of
-// tile t + 1 are ISSUED before the softmax of tile t: MFMAs execute asynchronously, so S(t+1) is computed by the matrix pipe while the
-// wave's own VALU works through softmax(t); PV(t) then queues behind it and runs under the next iteration's issue slots.  Two score
-// tiles are live (32 more VGPRs: 2 waves per SIMD instead of 3), the K tile is needed one iteration earlier (ring of FOUR stages, DMA'd
-// three tiles ahead; LDS 32 / 64 KB at d_head 64).  d_head 32 / 64 only (at 128 two score tiles + 64 O registers do not fit).
-template <int DH, int NW, bool KVSAME>
-__global__ void __launch_bounds__(64 * NW) attn_fwdp_kernel(const AttnArgs a) {
-    constexpr int KT = 64;                       // keys per tile
-    constexpr int ROWB = DH * 2;                 // bytes per LDS row
-    constexpr int CPR = DH / 8;                  // 16-B chunks per row
-    constexpr int TILE = KT * ROWB;
-    constexpr int KS = DH / 16;                  // MFMA k-steps of the QK^T product
-    constexpr int DT = DH / 32;                  // 32-row tiles of O^T
-    constexpr int SLABS = TILE / 1024;           // 1-KiB DMA pieces per tile
-    constexpr int LPW = SLABS / NW;              // pieces per wave per tile
-    constexpr int LPT = KVSAME ? LPW : 2 * LPW;  // glds per wave per stage
-    constexpr int STAGE = KVSAME ? TILE : 2 * TILE;
-    constexpr int NSTAGE = 4;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int qtiles = (a.Sq + 32 * NW - 1) / (32 * NW);
-    const int seq = blockIdx.x / qtiles, qtile = blockIdx.x % qtiles, head = blockIdx.y;
-    const int q0 = qtile * (32 * NW) + wave * 32;
-    const int qi = q0 + (lane & 31);             // this lane's query
-    const int h = lane >> 5;
-    const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page_a);
-
-    auto swz = [&](int row, int chunk) -> int { return attn_swz<CPR>(row, chunk); };
-
-    // Q fragments (B operand): Q[query][16 ks + 8 h .. + 7]
-    bf16x8_t qf[KS];
-    {
-        const bf16_t* qrow = a.q + seq_base(a.qm, seq) + (long long)(qi < a.Sq ? qi : 0) * a.qm.pos_stride + head * DH;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            if (qi < a.Sq) qf[ks] = *reinterpret_cast<const bf16x8_t*>(qrow + ks * 16 + h * 8);
-            else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) qf[ks][e] = 0;
-            }
-        }
-    }
-
-    f32x16_t oacc[DT];
-#pragma unroll
-    for (int d = 0; d < DT; ++d)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
-    float m_run = -1e30f, l_run = 0.f;           // running max of the RAW scores, running sum of exp2(c * (s - m))
-    const float c2 = a.scale * 1.4426950408889634f;
-
-    const long long kbase = seq_base(a.km, seq) + head * DH;
-    const int blk_q_max = qtile * (32 * NW) + 32 * NW - 1;   // causal: no key beyond the block's last query contributes
-    int k_end = a.Sk;
-    if (a.causal && blk_q_max + 1 < k_end) k_end = blk_q_max + 1;
-    const int ntile = (k_end + KT - 1) / KT;
-
-    // per-lane constants of the staging: this wave's pieces of a tile
-    int st_row[LPW], st_lc[LPW];
-#pragma unroll
-    for (int i = 0; i < LPW; ++i) {
-        const int idx = (wave + i * NW) * 64 + lane;         // 16-B unit index inside the tile
-        st_row[i] = idx / CPR;
-        st_lc[i] = swz(st_row[i], idx % CPR);
-    }
-    auto stage = [&](int t, int buf) {
-        char* kt_ = smem + buf * STAGE;
-        const int k0 = t * KT;
-#pragma unroll
-        for (int i = 0; i < LPW; ++i) {
-            const int slab = wave + i * NW;
-            const int key = k0 + st_row[i];
-            const bf16_t* pk = zero;
-            const bf16_t* pv = zero;
-            if (t < ntile && key < a.Sk) {                     // past the last tile: zero page, so every iteration issues LPT glds
-                const long long off = kbase + (long long)key * a.km.pos_stride + st_lc[i] * 8;
-                pk = a.k + off;
-                pv = a.v + off;
-            }
-            __builtin_amdgcn_global_load_lds(GLB_PTR(pk), LDS_PTR(kt_ + slab * 1024), 16, 0, 0);
-            if (!KVSAME) __builtin_amdgcn_global_load_lds(GLB_PTR(pv), LDS_PTR(kt_ + TILE + slab * 1024), 16, 0, 0);
-        }
-    };
-    static_assert(SLABS % NW == 0, "every wave stages the same number of pieces (counted vmcnt)");
-
-    const int g16 = lane >> 4, rr = (lane >> 2) & 3, qq = lane & 3;
-    if (ntile > 0) {
-        stage(0, 0);
-        stage(1, 1);
-        stage(2, 2);
-        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LPT) : "memory");     // tiles 0 and 1 have landed, tile 2 stays in flight
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-    }
-    // loop-invariant LDS offsets (inside a stage) of every fragment read: the tile loop is unrolled over the three ring slots so
-    // that the slot base is an immediate -- per tile the wave issues no address arithmetic at all (the first version spent
-    // 20 VALU instructions per MFMA, most of them here; SQ_INSTS_VALU / SQ_INSTS_MFMA)
-    uint32_t k_off[2][KS], v_off[2][2][DT][2];
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-        const int row = kt * 32 + (lane & 31);
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) k_off[kt][ks] = (uint32_t)(row * ROWB + (swz(row, ks * 2 + h) << 4));
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            const int r0 = kt * 32 + 16 * s2 + 4 * (g16 >> 1) + rr, r1 = r0 + 8;
-#pragma unroll
-            for (int d = 0; d < DT; ++d) {
-                const int col = d * 32 + 16 * (g16 & 1) + 4 * qq;
-                v_off[kt][s2][d][0] = (uint32_t)(r0 * ROWB + (swz(r0, col >> 3) << 4) + (col & 7) * 2);
-                v_off[kt][s2][d][1] = (uint32_t)(r1 * ROWB + (swz(r1, col >> 3) << 4) + (col & 7) * 2);
-            }
-        }
-    }
-    const uint32_t smem_off = attn_lds_offset(smem);
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-            for (int d = 0; d < DT; ++d) { v_off[kt][s2][d][0] += smem_off; v_off[kt][s2][d][1] += smem_off; }
-
-    // S^T = K Q^T of the 64-key tile in ring slot SLOT (two 32-key MFMA tiles)
-    auto qk_tile = [&](auto slot_c, f32x16_t (&sacc)[2]) {
-        constexpr int KBASE = decltype(slot_c)::value * STAGE;
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sacc[kt][r] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks)                       // the two 32-key accumulators alternate: no MFMA waits on its predecessor
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt) {
-                const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(smem + KBASE + k_off[kt][ks]);
-                sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[kt], 0, 0, 0);
-            }
-        __builtin_amdgcn_s_setprio(0);
-    };
-    // one tile: `sacc` holds S(t) (computed one iteration ago), `snext` receives S(t + 1)
-    auto tile_body = [&](auto slot_c, int t, f32x16_t (&sacc)[2], f32x16_t (&snext)[2]) {
-        constexpr int SLOT = decltype(slot_c)::value;
-        constexpr int KBASE = SLOT * STAGE, VBASE = KVSAME ? KBASE : KBASE + TILE;
-        const int k0 = t * KT;
-        stage(t + 3, (SLOT + 3) & 3);                         // slot of tile t - 1 (every wave is past the barrier behind it)
-        // ---- scores of the NEXT tile: issued now, computed by the matrix pipe under this tile's softmax ----
-        if (t + 1 < ntile) qk_tile(std::integral_constant<int, (SLOT + 1) & 3>{}, snext);
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- V^T fragments: requested now, they land under the softmax arithmetic ----
-        bf16x4_t vlo[2][2][DT], vhi[2][2][DT];
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                for (int d = 0; d < DT; ++d) {
-                    vlo[kt][s2][d] = attn_tr16i<VBASE>(v_off[kt][s2][d][0]);
-                    vhi[kt][s2][d] = attn_tr16i<VBASE>(v_off[kt][s2][d][1]);
-                }
-        // ---- masks: only where the tile crosses the end of the keys or (causal) the diagonal of this wave's queries ----
-        const bool edge = (k0 + KT > a.Sk) || (a.causal && k0 + KT - 1 > q0);
-        if (edge) {
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = k0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (key >= a.Sk || (a.causal && key > qi)) sacc[kt][r] = -INFINITY;
-                }
-        }
-        // ---- online softmax in the exp2 domain (lane-local + one cross-half exchange) ----
-        float tmax;
-        {   // 32 -> 1 with three-input maxima (v_max3_f32): 16 instructions instead of 32
-            float m3[11];
-#pragma unroll
-            for (int g = 0; g < 10; ++g) {
-                const int e = 3 * g;
-                m3[g] = fmaxf(fmaxf(sacc[e >> 4][e & 15], sacc[(e + 1) >> 4][(e + 1) & 15]), sacc[(e + 2) >> 4][(e + 2) & 15]);
-            }
-            m3[10] = fmaxf(sacc[1][14], sacc[1][15]);
-            const float a0 = fmaxf(fmaxf(m3[0], m3[1]), m3[2]), a1 = fmaxf(fmaxf(m3[3], m3[4]), m3[5]);
-            const float a2 = fmaxf(fmaxf(m3[6], m3[7]), m3[8]), a3 = fmaxf(m3[9], m3[10]);
-            tmax = fmaxf(fmaxf(fmaxf(a0, a1), a2), a3);
-        }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float m_new = fmaxf(m_run, tmax);
-        if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0) {          // some lane's maximum moved: rescale (exact, alpha = 1 elsewhere)
-            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
-            l_run *= alpha;
-#pragma unroll
-            for (int d = 0; d < DT; ++d)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
-            m_run = m_new;
-        }
-        const float mc = m_run * c2;
-        float psum = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[kt][r], c2, -mc));
-                sacc[kt][r] = p;
-                psum += p;
-            }
-        psum += __shfl_xor(psum, 32, 64);
-        l_run += psum;
-
-        // ---- O^T += V^T P^T ----
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                u32x4_t pw;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) pw[e] = pack_bf16x2(sacc[kt][8 * s2 + 2 * e], sacc[kt][8 * s2 + 2 * e + 1]);
-                const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pw);
-#pragma unroll
-                for (int d = 0; d < DT; ++d) {
-                    asm volatile("" : "+v"(vlo[kt][s2][d]), "+v"(vhi[kt][s2][d]));
-                    const bf16x8_t vf = __builtin_shufflevector(vlo[kt][s2][d], vhi[kt][s2][d], 0, 1, 2, 3, 4, 5, 6, 7);
-                    oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[d], 0, 0, 0);
-                }
-            }
-        }
-        __builtin_amdgcn_s_setprio(0);
-        // tile t + 1 (issued one iteration ago) must have landed; the stage issued above stays in flight
-        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LPT) : "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-    };
-    f32x16_t s_a[2], s_b[2];
-    if (ntile > 0) qk_tile(std::integral_constant<int, 0>{}, s_a);
-    for (int t = 0; t < ntile; t += 4) {
-        tile_body(std::integral_constant<int, 0>{}, t, s_a, s_b);
-        if (t + 1 < ntile) tile_body(std::integral_constant<int, 1>{}, t + 1, s_b, s_a);
-        if (t + 2 < ntile) tile_body(std::integral_constant<int, 2>{}, t + 2, s_a, s_b);
-        if (t + 3 < ntile) tile_body(std::integral_constant<int, 3>{}, t + 3, s_b, s_a);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-
-    // ---- epilogue: O / l (+ resid) through LDS (rows_put_f32); lane holds, for its query, d = 32 dt + (r & 3) + 8 (r >> 2) + 4 h ----
-    __syncthreads();                                 // every wave is done with the ring: its memory now stages the output rows
-    {
-        float* fl = reinterpret_cast<float*>(smem) + wave * 32 * DH;
-        const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
-        const int lr = lane & 31;
-#pragma unroll
-        for (int d = 0; d < DT; ++d)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f32x4_t f;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) f[e] = oacc[d][4 * g + e] * inv;
-                rows_put_f32<DH>(fl, lr, h, d * 4 + g, f);
-            }
-        const long long obase_s = seq_base(a.om, seq) + head * DH;
-        // natural-log LSE of scale * s:  m * scale + ln(l)
-        if (a.lse && h == 0 && qi < a.Sq) a.lse[((obase_s - head * DH + (long long)qi * a.om.pos_stride) / a.C) * a.nhead + head] = m_run * a.scale + __logf(l_run);
-#pragma unroll
-        for (int i = 0; i < CPR / 2; ++i) {
-            const int idx = i * 64 + lane, row = idx / CPR, c = idx % CPR;
-            if (q0 + row >= a.Sq) continue;
-            float f[8];
-            rows_get_f32<DH>(fl, row, c, f);
-            const long long o = obase_s + (long long)(q0 + row) * a.om.pos_stride + c * 8;
-            if (a.oattn) *reinterpret_cast<u32x4_t*>(a.oattn + o) = pack8(f);      // un-residualed output, kept for backward (D = rowsum(dO * O))
-            if (a.resid) {
-                float r[8];
-                unpack8(*reinterpret_cast<const u32x4_t*>(a.resid + o), r);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) f[e] += r[e];
-            }
-            *reinterpret_cast<u32x4_t*>(a.out + o) = pack8(f);
-        }
-    }
-}
-
 // Short self-attention sequences (temporal attention: S = T <= 32 frames of one pixel, attention.py:300-306).  The general
 // kernel gives such a sequence a whole 64-key tile and a 32-query wave: at T = 16 one eighth of its MFMA work is useful and
 // every block pays the ring prologue for a single tile.  Here 32 / TP sequences are packed into the 32 rows a wave owns
@@ -1107,18 +821,12 @@ extern "C" int genie_attention_fwd(const void* q, const void* k, const void* v, 
     const int qtiles = (Sq + 32 * nw - 1) / (32 * nw);
     GENIE_CHECK_ARG((long long)nseq * qtiles < (1ll << 31) && nhead <= 65535, "genie_attention_fwd: grid too large");
     const int tile = 64 * d_head * 2;
-    // software-pipelined form (attn_fwdp_kernel: S(t+1) issued before softmax(t), ring of four stages) for long key ranges at d_head <= 64
-    static const int pipe_on = getenv("GENIE_ATTN_PIPE") ? atoi(getenv("GENIE_ATTN_PIPE")) : 1;
-    const bool pipe = pipe_on && d_head <= 64 && Sk >= 256;
-    int lds = (pipe ? 4 : 3) * (a.kv_same ? tile : 2 * tile);
+    int lds = 3 * (a.kv_same ? tile : 2 * tile);
     if (lds < nw * 32 * d_head * 4) lds = nw * 32 * d_head * 4;      // the epilogue stages NW x 32 fp32 rows in the ring's memory
     dim3 grid((unsigned)(nseq * qtiles), nhead, 1);
 #define GENIE_ATTN_FWD(DHv, NWv)                                                                         \
     do {                                                                                                 \
         auto kf_ = a.kv_same ? attn_fwd_kernel<DHv, NWv, true> : attn_fwd_kernel<DHv, NWv, false>;        \
-        if constexpr (DHv <= 64) {                                                                       \
-            if (pipe) kf_ = a.kv_same ? attn_fwdp_kernel<DHv, NWv, true> : attn_fwdp_kernel<DHv, NWv, false>; \
-        }                                                                                                \
         if (lds > 65536) GENIE_CHECK_ARG(hipFuncSetAttribute((const void*)kf_, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess, "hipFuncSetAttribute failed"); \
         kf_<<<grid, 64 * NWv, lds, s>>>(a);                                                              \
     } while (0)

@@ -35,7 +35,6 @@ struct NarrowInArgs {
     int t_lo;               // frame offset of the first tap plane: -2 for the causal forward, 0 for its backward-data pass
     int ntiles;             // N * T * ceil(H / 4)
     int hblocks;            // ceil(H / 4)
-    int nt;                 // 1: non-temporal output stores (the 128-channel result is a stream nobody re-reads from L2: GENIE_NARROW_NT)
 };
 
 template <int W>
@@ -127,9 +126,7 @@ __global__ void __launch_bounds__(256, 2) conv_narrow_in_kernel(const NarrowInAr
             for (int it = 0; it < 8; ++it) {
                 const int idx = it * 64 + lane, p = idx >> 4, ch = idx & 15;
                 const u32x4_t v = *reinterpret_cast<const u32x4_t*>(st + p * NIN_OPITCH + ch * 16);
-                u32x4_t* o = reinterpret_cast<u32x4_t*>(a.dst + (orow + mt * 32 + p) * a.cd + ch * 8);
-                if (a.nt) __builtin_nontemporal_store(v, o);
-                else *o = v;
+                *reinterpret_cast<u32x4_t*>(a.dst + (orow + mt * 32 + p) * a.cd + ch * 8) = v;
             }
             __builtin_amdgcn_wave_barrier();                       // the next m-tile overwrites the staging rows
         }
@@ -524,7 +521,6 @@ extern "C" int genie_conv_narrow_in(const void* src_cl, int src_pitch, const voi
     a.src = (const bf16_t*)src_cl; a.wpack = (const bf16_t*)wpack; a.dst = (bf16_t*)dst_cl;
     a.N = N; a.T = T; a.H = H; a.W = W; a.cs = src_pitch; a.cd = dst_pitch; a.t_lo = t_lo;
     a.hblocks = (H + NIN_HB - 1) / NIN_HB;
-    { static const int nt = getenv("GENIE_NARROW_NT") ? atoi(getenv("GENIE_NARROW_NT")) : 0; a.nt = nt; }
     const long long tiles = (long long)N * T * a.hblocks;
     GENIE_CHECK_ARG(tiles < (1ll << 31), "genie_conv_narrow_in: too many tiles");
     a.ntiles = (int)tiles;
