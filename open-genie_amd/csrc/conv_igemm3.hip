@@ -283,7 +283,14 @@ __global__ void __launch_bounds__(BM * 2) igemm3_kernel(const Igemm3Args p, cons
 // NWAVE = 8: 2 waves per SIMD, 64 x 64 per wave.  NWAVE = 4 (PRE only): ONE wave per SIMD owning 128 x 64 (TM = 4) -- no contention for
 // the matrix pipe between co-resident waves, 6 fragment reads per 8 MFMAs instead of 4 per 4, four waves at the barrier instead
 // of eight; each thread issues twice the DMA pieces.
-template <bool PRE, bool SPLITK, int NWAVE>
+// LEAN (round 3, same idea as wgrad3l_kernel in conv_wgrad3.hip): the LDS-DMA pieces are BUFFER loads -- wave-uniform descriptors (the
+// image rebased to this tile minus a margin that keeps every tap's offset positive, the weight pack as it is), a per-lane byte offset
+// that never changes and a scalar offset from the step table; a piece whose image row (t + dt, h + dh) is outside the clip, a lane
+// whose pixel / weight row does not exist and a stage past the last step carry offset 0x80000000 >= num_records and the DMA writes
+// zeros.  Replaces ~9 VALU per piece (64-bit address arithmetic, per-lane (t, h) decode, predicates, zero-page select) by one v_or.
+#define IG3_OOB 0x80000000u
+
+template <bool PRE, bool SPLITK, int NWAVE, bool LEAN = false>
 __global__ void __launch_bounds__(64 * NWAVE) igemm3d_kernel(const Igemm3Args p, const GenieTriStep* __restrict__ steps) {
     constexpr int BM = 256, BN = 128, NT = 64 * NWAVE, WN = 2, WM = NWAVE / WN, TM = BM / (WM * 32), TN = 2;
     constexpr int RPR = NT / 8, A_ROUNDS = BM / RPR;     // DMA rounds per image: the 256 REAL pixels (the zero columns are written once, below)
@@ -355,18 +362,52 @@ __global__ void __launch_bounds__(64 * NWAVE) igemm3d_kernel(const Igemm3Args p,
         const int wr = b_ok[j] ? (a.perm_f > 1 ? (n % a.perm_c) * a.perm_f + n / a.perm_c : n) : 0;
         b_ptr[j] = a.wgt + (size_t)wr * a.w_row_stride + lc * 8;
     }
+    // LEAN staging state: descriptors, per-lane byte offsets (OOB where the pixel / weight row does not exist), scalar (t, h) of the
+    // image row that holds the wave's 8-pixel piece
+    const int margin = (3 * H * W + 2 * W) * a.Cs;                          // elements; |a_delta| <= (2 H + 1) W Cs + Cs
+    __amdgpu_buffer_rsrc_t rs_a, rs_b;
+    uint32_t voff_a[A_ROUNDS], voff_b[B_LOADS];
+    int at_s[A_ROUNDS], ah_s[A_ROUNDS];
+    if constexpr (LEAN) {
+        rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)(a.src + ((long long)m0 * a.Cs - margin)), (short)0, (int)IG3_OOB, 0x00020000);
+        rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)a.wgt, (short)0, (int)IG3_OOB, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < A_ROUNDS; ++i) {
+            const int q = i * RPR + (tid >> 3);
+            const int hl = q / W, w = q - hl * W;
+            const int r = hl * WP + w + 1;
+            const int lc = (tid & 7) ^ ((r >> 1) & 7);
+            voff_a[i] = (long long)m0 + q < a.M ? (uint32_t)((q * a.Cs + lc * 8) * 2) : IG3_OOB;
+            const int rowid = row0_id + ((i * NWAVE + wave) * 8) / W;       // image row of the wave's piece
+            at_s[i] = __builtin_amdgcn_readfirstlane((rowid / H) % T);
+            ah_s[i] = __builtin_amdgcn_readfirstlane(rowid % H);
+        }
+#pragma unroll
+        for (int j = 0; j < B_LOADS; ++j) voff_b[j] = b_ok[j] ? (uint32_t)((b_ptr[j] - a.wgt) * 2) : IG3_OOB;
+    }
     auto stage_a = [&](const GenieTriStep& e, bool live, int i, char* abuf) {
-        const int t = (a_th[i] >> 16) + e.dt, h = (a_th[i] & 0xffff) + e.dh;
-        const bool ok = live & ((unsigned)t < (unsigned)T) & ((unsigned)h < (unsigned)H);
-        const bf16_t* q = a.src + (int)(a_base[i] + (unsigned)e.a_delta);
-        q = ok ? q : zero;
-        __builtin_amdgcn_global_load_lds(GLB_PTR(q), LDS_PTR(abuf + a_dst[i]), 16, 0, 0);
+        if constexpr (LEAN) {
+            const bool ok = (int)live & (int)((unsigned)(at_s[i] + e.dt) < (unsigned)T) & (int)((unsigned)(ah_s[i] + e.dh) < (unsigned)H);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, LDS_PTR(abuf + a_dst[i]), 16, voff_a[i] | (ok ? 0u : IG3_OOB),
+                                                     ok ? (uint32_t)((e.a_delta + margin) * 2) : 0u, 0, 0);
+        } else {
+            const int t = (a_th[i] >> 16) + e.dt, h = (a_th[i] & 0xffff) + e.dh;
+            const bool ok = live & ((unsigned)t < (unsigned)T) & ((unsigned)h < (unsigned)H);
+            const bf16_t* q = a.src + (int)(a_base[i] + (unsigned)e.a_delta);
+            q = ok ? q : zero;
+            __builtin_amdgcn_global_load_lds(GLB_PTR(q), LDS_PTR(abuf + a_dst[i]), 16, 0, 0);
+        }
     };
     auto stage_b = [&](int wofs, bool live, char* bbuf) {
 #pragma unroll
         for (int j = 0; j < B_LOADS; ++j) {
-            const bf16_t* q = (live & b_ok[j]) ? b_ptr[j] + wofs : zero;
-            __builtin_amdgcn_global_load_lds(GLB_PTR(q), LDS_PTR(bbuf + (j * NWAVE + wave) * 1024), 16, 0, 0);
+            if constexpr (LEAN) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, LDS_PTR(bbuf + (j * NWAVE + wave) * 1024), 16, voff_b[j] | (live ? 0u : IG3_OOB),
+                                                         live ? (uint32_t)(wofs * 2) : 0u, 0, 0);
+            } else {
+                const bf16_t* q = (live & b_ok[j]) ? b_ptr[j] + wofs : zero;
+                __builtin_amdgcn_global_load_lds(GLB_PTR(q), LDS_PTR(bbuf + (j * NWAVE + wave) * 1024), 16, 0, 0);
+            }
         }
     };
 
@@ -564,7 +605,7 @@ int genie_igemm_splitk_finish(const IgemmArgs& a, hipStream_t s);      // conv_i
 //   complete in group 6i+3, published at barrier 6i+4, pre-read in 6i+5.  WAR: slot (k+3)&3 was last read in half-tile k-1; the
 //   spare image was last read in half-tile 6i-1.
 // ------------------------------------------------------------------------------------------------------------------------------
-template <bool SPLITK>
+template <bool SPLITK, bool LEAN = false>
 __global__ void __launch_bounds__(512) igemm3w_kernel(const Igemm3Args p, const GenieTriStep* __restrict__ steps) {
     constexpr int BM = 256, BN = 256, NWAVE = 8, WN = 2, TM = 2, TN = 4;
     constexpr int RPR = 64, A_ROUNDS = 4;                                    // DMA rounds per image: the 256 REAL pixels (zero columns: below)
@@ -626,18 +667,51 @@ __global__ void __launch_bounds__(512) igemm3w_kernel(const Igemm3Args p, const 
         const int wr = n < a.Ncols ? (a.perm_f > 1 ? (n % a.perm_c) * a.perm_f + n / a.perm_c : n) : -1;
         b_ptr[j] = wr >= 0 ? a.wgt + (size_t)wr * a.w_row_stride + lc * 8 : nullptr;
     }
+    // LEAN staging state (see igemm3d_kernel)
+    const int margin = (3 * H * W + 2 * W) * a.Cs;
+    __amdgpu_buffer_rsrc_t rs_a, rs_b;
+    uint32_t voff_a[A_ROUNDS], voff_b[B_LOADS];
+    int at_s[A_ROUNDS], ah_s[A_ROUNDS];
+    if constexpr (LEAN) {
+        rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)(a.src + ((long long)m0 * a.Cs - margin)), (short)0, (int)IG3_OOB, 0x00020000);
+        rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)a.wgt, (short)0, (int)IG3_OOB, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < A_ROUNDS; ++i) {
+            const int q = i * RPR + (tid >> 3);
+            const int hl = q / W, w = q - hl * W;
+            const int r = hl * WP + w + 1;
+            const int lc = (tid & 7) ^ ((r >> 1) & 7);
+            voff_a[i] = (long long)m0 + q < a.M ? (uint32_t)((q * a.Cs + lc * 8) * 2) : IG3_OOB;
+            const int rowid = row0_id + ((i * NWAVE + wave) * 8) / W;
+            at_s[i] = __builtin_amdgcn_readfirstlane((rowid / H) % T);
+            ah_s[i] = __builtin_amdgcn_readfirstlane(rowid % H);
+        }
+#pragma unroll
+        for (int j = 0; j < B_LOADS; ++j) voff_b[j] = b_ptr[j] ? (uint32_t)((b_ptr[j] - a.wgt) * 2) : IG3_OOB;
+    }
     auto stage_a = [&](const GenieTriStep& e, bool live, int i, char* abuf) {
-        const int t = (a_th[i] >> 16) + e.dt, h = (a_th[i] & 0xffff) + e.dh;
-        const bool ok = live & ((unsigned)t < (unsigned)T) & ((unsigned)h < (unsigned)H);
-        const bf16_t* q = a.src + (int)(a_base[i] + (unsigned)e.a_delta);
-        q = ok ? q : zero;
-        __builtin_amdgcn_global_load_lds(GLB_PTR(q), LDS_PTR(abuf + a_dst[i]), 16, 0, 0);
+        if constexpr (LEAN) {
+            const bool ok = (int)live & (int)((unsigned)(at_s[i] + e.dt) < (unsigned)T) & (int)((unsigned)(ah_s[i] + e.dh) < (unsigned)H);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, LDS_PTR(abuf + a_dst[i]), 16, voff_a[i] | (ok ? 0u : IG3_OOB),
+                                                     ok ? (uint32_t)((e.a_delta + margin) * 2) : 0u, 0, 0);
+        } else {
+            const int t = (a_th[i] >> 16) + e.dt, h = (a_th[i] & 0xffff) + e.dh;
+            const bool ok = live & ((unsigned)t < (unsigned)T) & ((unsigned)h < (unsigned)H);
+            const bf16_t* q = a.src + (int)(a_base[i] + (unsigned)e.a_delta);
+            q = ok ? q : zero;
+            __builtin_amdgcn_global_load_lds(GLB_PTR(q), LDS_PTR(abuf + a_dst[i]), 16, 0, 0);
+        }
     };
     auto stage_b = [&](int wofs, bool live, char* bbuf) {                      // one 32-channel half of a weight tile
 #pragma unroll
         for (int j = 0; j < B_LOADS; ++j) {
-            const bf16_t* q = (live && b_ptr[j]) ? b_ptr[j] + wofs : zero;
-            __builtin_amdgcn_global_load_lds(GLB_PTR(q), LDS_PTR(bbuf + (j * NWAVE + wave) * 1024), 16, 0, 0);
+            if constexpr (LEAN) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, LDS_PTR(bbuf + (j * NWAVE + wave) * 1024), 16, voff_b[j] | (live ? 0u : IG3_OOB),
+                                                         live ? (uint32_t)(wofs * 2) : 0u, 0, 0);
+            } else {
+                const bf16_t* q = (live && b_ptr[j]) ? b_ptr[j] + wofs : zero;
+                __builtin_amdgcn_global_load_lds(GLB_PTR(q), LDS_PTR(bbuf + (j * NWAVE + wave) * 1024), 16, 0, 0);
+            }
         }
     };
 
@@ -767,9 +841,29 @@ __global__ void __launch_bounds__(512) igemm3w_kernel(const Igemm3Args p, const 
     igemm_epilogue<BM, TM, TN>(a, acc, smem, m0, n0, wm, wn, tid, lane);
 }
 
+// The LEAN staging (buffer loads with 32-bit byte offsets) needs the weight pack below 2 GiB; GENIE_TRI_LEAN=0 switches it off (A/B).
+static bool ig3_lean_ok(const Igemm3Args& p) {
+    static const int on = getenv("GENIE_TRI_LEAN") ? atoi(getenv("GENIE_TRI_LEAN")) : 1;
+    return on && p.dbg == 0 && (long long)p.g.Ncols * p.g.w_row_stride * 2 + (1 << 20) < 0x7fffffffll;
+}
+
 template <bool SPLITK>
 static int launch_igemm3w(const Igemm3Args& p, const GenieTriStep* steps, hipStream_t s) {
     constexpr int lds = 2 * (5 * 64 * 128) + 4 * 256 * 64;
+    if (!SPLITK && ig3_lean_ok(p)) {                           // buffer-addressed LDS-DMA form
+        static bool lconf = false;
+        if (!lconf) {
+            hipError_t e = hipFuncSetAttribute((const void*)igemm3w_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e != hipSuccess) {
+                genie_set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+                return GENIE_ERR_HIP;
+            }
+            lconf = true;
+        }
+        hipLaunchKernelGGL((igemm3w_kernel<false, true>), dim3(p.g.tiles_m * p.g.tiles_n, 1), dim3(512), lds, s, p, steps);
+        GENIE_CHECK_LAUNCH();
+        return GENIE_OK;
+    }
     static bool configured = false;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute((const void*)igemm3w_kernel<SPLITK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -1020,6 +1114,22 @@ static int launch_igemm3p(const Igemm3Args& p, const GenieTriStep* steps, hipStr
 template <bool PRE, bool SPLITK, int NWAVE = 8>
 static int launch_igemm3d_t(const Igemm3Args& p, const GenieTriStep* steps, hipStream_t s) {
     constexpr int lds = 2 * (5 * 64 * 128) + 4 * 128 * 128;
+    if constexpr (PRE && !SPLITK && NWAVE == 8) {
+        if (ig3_lean_ok(p) && !p.xcdcol) {                      // buffer-addressed LDS-DMA form of the default schedule
+            static bool lconf = false;
+            if (!lconf) {
+                hipError_t e = hipFuncSetAttribute((const void*)igemm3d_kernel<true, false, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                if (e != hipSuccess) {
+                    genie_set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+                    return GENIE_ERR_HIP;
+                }
+                lconf = true;
+            }
+            hipLaunchKernelGGL((igemm3d_kernel<true, false, 8, true>), dim3(p.g.tiles_m * p.g.tiles_n, 1), dim3(512), lds, s, p, steps);
+            GENIE_CHECK_LAUNCH();
+            return GENIE_OK;
+        }
+    }
     static bool configured = false;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute((const void*)igemm3d_kernel<PRE, SPLITK, NWAVE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
