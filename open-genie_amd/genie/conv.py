@@ -113,9 +113,14 @@ def causal_spec(cin: int, cout: int, kernel: Triple, stride: Triple = (1, 1, 1),
     tp = (kt - 1) * dilation[0] + (1 - stride[0])
     hp = space_pad[0] if space_pad[0] is not None else (kh - 1) // 2
     wp = space_pad[1] if space_pad[1] is not None else (kw - 1) // 2
-    if tp < 0:
-        raise ValueError(f'CausalConv3d: negative causal padding {tp} (kernel {kernel}, stride {stride})')
-    return ConvSpec(cin, cout, tuple(kernel), tuple(stride), tuple(dilation), (tp, hp, wp), (0, hp, wp), shuffle)
+    # tp < 0 (kt = 1 with a time stride of 2): the reference's F.pad with a negative amount CROPS the first -tp frames (video.py:154-164);
+    # the module slices them off (CausalConv3d.forward) and the conv itself runs without time padding
+    return ConvSpec(cin, cout, tuple(kernel), tuple(stride), tuple(dilation), (max(tp, 0), hp, wp), (0, hp, wp), shuffle)
+
+
+def causal_time_crop(kernel: Triple, stride: Triple = (1, 1, 1), dilation: Triple = (1, 1, 1)) -> int:
+    """Frames the reference's negative causal padding removes from the FRONT of the clip: max(0, -((kt - 1) dil_t + 1 - stride_t))."""
+    return max(0, -((kernel[0] - 1) * dilation[0] + (1 - stride[0])))
 
 
 def same_spec(cin: int, cout: int, kernel: Triple) -> ConvSpec:

@@ -231,6 +231,42 @@ def conv3d(x: Tensor, weight: Tensor, bias: Optional[Tensor], op: ConvOp, resid:
     return _Conv3dFn.apply(to_cl(x), weight, bias, op, None if resid is None else to_cl(resid))
 
 
+class _ConvTranspose3dFn(torch.autograd.Function):
+    """ConvTranspose3d as what it is -- the backward-data pass of the convolution with the same weight tensor: forward =
+    ``conv_dgrad``, input gradient = ``conv_forward``, weight gradient = ``conv_wgrad`` with the roles of the two activations swapped.
+    `spec` describes that convolution (cin = the transposed conv's OUTPUT channels, cout = its input channels); `full` is the
+    un-cropped output size."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, weight: Tensor, op: ConvOp, full):
+        _conv_gate()
+        y = conv_dgrad(x, op.pack_bwd(weight), op.spec, tuple(full))
+        ctx.op = op
+        ctx.save_for_backward(x, weight, y.new_empty(0))
+        ctx.full = tuple(full)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        x, weight, _ = ctx.saved_tensors
+        op: ConvOp = ctx.op
+        dy = to_cl(dy)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            _conv_gate()
+            dx = conv_forward(dy, op.pack_fwd(weight), None, op.spec)
+        if ctx.needs_input_grad[1]:
+            dw = torch.zeros(weight.shape, dtype=torch.float32, device=weight.device)
+            conv_wgrad(dy, x, op.spec, dw, None)            # conv input = the transposed conv's output gradient, conv output gradient = its input
+        return dx, dw, None, None
+
+
+def conv_transpose3d(x: Tensor, weight: Tensor, op: ConvOp, full) -> Tensor:
+    """x: (N, Cin, T, H, W); weight: nn.ConvTranspose3d layout (Cin, Cout, kt, kh, kw); returns the UN-CROPPED (N, Cout, *full) CL tensor
+    (no bias)."""
+    return _ConvTranspose3dFn.apply(to_cl(x), weight, op, tuple(full))
+
+
 # ------------------------------------------------------------------------------------------------
 # GroupNorm (+ adaptive scale/shift) (+ SiLU)
 # ------------------------------------------------------------------------------------------------

@@ -16,7 +16,7 @@ from torch import Tensor
 
 from .. import functional as GF
 from ..cl import to_cl
-from ..conv import ConvSpec, causal_spec, same_spec
+from ..conv import ConvSpec, causal_spec, causal_time_crop, same_spec
 from ..utils import default, exists
 
 
@@ -114,8 +114,15 @@ class CausalConv3d(nn.Module):
         spec = causal_spec(in_channels, out_channels, kernel_size, stride, dilation, padding, shuffle=_shuffle)
         self.conv3d = Conv3d(in_channels, out_channels, kernel_size, spec, bias=bias)
         self.in_channels, self.out_channels = in_channels, out_channels
+        # a NEGATIVE causal pad (kt = 1, time stride 2: (kt - 1) dil + 1 - stride = -1) crops leading frames in the reference (F.pad with a
+        # negative amount, video.py:154-164, 189)
+        self.time_crop = causal_time_crop(kernel_size, stride, dilation)
 
     def forward(self, inp: Tensor) -> Tensor:
+        if self.time_crop:
+            if inp.shape[2] <= self.time_crop:
+                raise ValueError(f'CausalConv3d: {inp.shape[2]} frames, the causal padding of this layer removes {self.time_crop}')
+            inp = to_cl(inp)[:, :, self.time_crop:].contiguous(memory_format=torch.channels_last_3d)     # a dense CL copy of the kept frames
         return self.conv3d(inp)
 
     @property
@@ -317,23 +324,98 @@ class DepthToTimeUpsample(Upsample):
 
 
 class CausalConvTranspose3d(nn.Module):
-    """reference video.py:202-277.  Not used by any shipped blueprint; kept constructible so the registry is
-    complete, but the transposed convolution is not implemented on the HIP path yet."""
+    """reference video.py:202-277: ``nn.ConvTranspose3d(padding=(0, kh // 2, kw // 2))`` whose output is cropped to (t T, h H, w W).
+    Parameters are laid out like ``nn.ConvTranspose3d`` (keys ``weight`` (in, out, kt, kh, kw) / ``bias``), so reference checkpoints
+    load.  A transposed convolution IS the backward-data pass of the convolution with the same weight tensor: forward runs the
+    backward-data kernels (one launch per output parity class for strides > 1), backward the forward / weight-gradient kernels."""
 
     def __init__(self, in_channels: int, out_channels: int, kernel_size, stride=(1, 1, 1), dilation=(1, 1, 1), space_pad=None, **kwargs) -> None:
         super().__init__()
+        ks, stride, dilation = _triple(kernel_size), _triple(stride), _triple(dilation)
+        if isinstance(space_pad, int) or space_pad is None:
+            space_pad = (space_pad, space_pad)
+        bias = kwargs.pop('bias', True)
+        if kwargs.pop('groups', 1) != 1 or kwargs.pop('output_padding', 0) not in (0, (0, 0, 0)):
+            raise NotImplementedError('CausalConvTranspose3d: groups / output_padding are not implemented on the HIP path')
+        if kwargs:
+            raise TypeError(f'CausalConvTranspose3d: unexpected arguments {sorted(kwargs)}')
+        hp = default(space_pad[0], ks[1] // 2)
+        wp = default(space_pad[1], ks[2] // 2)
+        w = torch.empty(in_channels, out_channels, *ks)
+        nn.init.kaiming_uniform_(w, a=math.sqrt(5))                 # nn.ConvTranspose3d.reset_parameters
+        self.weight = nn.Parameter(w)
+        if bias:
+            bound = 1 / math.sqrt(out_channels * ks[0] * ks[1] * ks[2])      # fan_in of a transposed conv counts weight.size(1)
+            self.bias = nn.Parameter(torch.empty(out_channels).uniform_(-bound, bound))
+        else:
+            self.register_parameter('bias', None)
         self.in_channels, self.out_channels = in_channels, out_channels
-        self.args = (kernel_size, stride, dilation, space_pad, kwargs)
+        self.kernel_size, self.stride, self.dilation, self.padding = ks, stride, dilation, (0, hp, wp)
+        # the convolution this is the backward-data pass of: (out_channels -> in_channels), same taps / stride / dilation / padding
+        self.spec = ConvSpec(out_channels, in_channels, ks, stride, dilation, self.padding, self.padding, None)
+        self.op = GF.ConvOp(self.spec)
 
     def forward(self, inp: Tensor) -> Tensor:
-        raise NotImplementedError('CausalConvTranspose3d is outside the implemented hot path (SURVEY.md section 2, row 1: unused by any shipped desc)')
+        t, h, w = inp.shape[2:]
+        full = tuple((n - 1) * s - 2 * p + d * (k - 1) + 1 for n, s, p, d, k in zip((t, h, w), self.stride, self.padding, self.dilation, self.kernel_size))
+        out = GF.conv_transpose3d(inp, self.weight, self.op, full)
+        out = out[:, :, :t * self.stride[0], :h * self.stride[1], :w * self.stride[2]]            # video.py:263-267
+        if self.bias is not None:
+            out = out + self.bias.to(out.dtype)[None, :, None, None, None]
+        return to_cl(out)
+
+    @property
+    def inp_dim(self) -> int:
+        return self.in_channels
+
+    @property
+    def out_dim(self) -> int:
+        return self.out_channels
+
+
+class _ConvTransposeWeights(nn.Module):
+    """Parameter holder with ``nn.ConvTranspose3d``'s keys (``weight`` (in, out, kt, kh, kw), ``bias`` (out))."""
+
+    def __init__(self, in_dim: int, out_dim: int, ks, bias: bool = True) -> None:
+        super().__init__()
+        w = torch.empty(in_dim, out_dim, *ks)
+        nn.init.kaiming_uniform_(w, a=math.sqrt(5))
+        self.weight = nn.Parameter(w)
+        if bias:
+            bound = 1 / math.sqrt(out_dim * ks[0] * ks[1] * ks[2])
+            self.bias = nn.Parameter(torch.empty(out_dim).uniform_(-bound, bound))
+        else:
+            self.register_parameter('bias', None)
 
 
 class SpaceTimeUpsample(Upsample):
-    """reference video.py:432-455 (nn.ConvTranspose3d); unused by any shipped blueprint."""
+    """reference video.py:432-455: ``nn.ConvTranspose3d(kernel = stride = (tf, sf, sf))``.  With kernel == stride every input pixel writes
+    its own (tf, sf, sf) block of the output -- a 1x1x1 convolution to Cout * tf * sf * sf channels followed by the depth-to-space-time
+    rearrange '(c p q r)': the shuffle-epilogue conv kernels with the weight read as (out, p, q, r | in).  Keys ``go_up.weight`` /
+    ``go_up.bias`` as in the reference."""
 
     def __init__(self, in_dim: int, out_dim: int, time_factor: int = 2, space_factor: int = 2, **kwargs) -> None:
         super().__init__(time_factor=time_factor, space_factor=space_factor)
+        bias = kwargs.pop('bias', True)
+        if kwargs:
+            raise NotImplementedError(f'SpaceTimeUpsample: ConvTranspose3d options {sorted(kwargs)} are not implemented on the HIP path')
+        f = (time_factor, space_factor, space_factor)
+        self.go_up = _ConvTransposeWeights(in_dim, out_dim, f, bias)
+        self.in_channels, self.out_channels, self.fac = in_dim, out_dim, f
+        self.op = GF.ConvOp(ConvSpec(in_dim, out_dim * f[0] * f[1] * f[2], (1, 1, 1), shuffle=f))
 
     def forward(self, inp: Tensor, **kwargs) -> Tensor:
-        raise NotImplementedError('SpaceTimeUpsample (ConvTranspose3d) is outside the implemented hot path')
+        w = self.go_up.weight                                               # (in, out, p, q, r)
+        rows = self.out_channels * self.fac[0] * self.fac[1] * self.fac[2]
+        w_conv = w.permute(1, 2, 3, 4, 0).reshape(rows, self.in_channels)[:, :, None, None, None]      # row (c p q r), column in
+        b = self.go_up.bias
+        b_conv = None if b is None else b.repeat_interleave(rows // self.out_channels)
+        return GF.conv3d(inp, w_conv, b_conv, self.op)
+
+    @property
+    def inp_dim(self) -> int:
+        return self.in_channels
+
+    @property
+    def out_dim(self) -> int:
+        return self.out_channels

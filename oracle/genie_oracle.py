@@ -150,6 +150,24 @@ def causal_conv3d(x: Tensor, w: Tensor, b: Optional[Tensor], stride=(1, 1, 1), d
     return _st(y if resid is None else y + resid)
 
 
+def causal_conv_transpose3d(x: Tensor, w: Tensor, b: Optional[Tensor], stride=(1, 1, 1), dilation=(1, 1, 1), space_pad=None) -> Tensor:
+    """video.py:202-277: nn.ConvTranspose3d(padding=(0, kh // 2, kw // 2)) (weight (in, out, kt, kh, kw)), output cropped to
+    (t * T, h * H, w * W) (video.py:263-267)."""
+    stride, dilation = _triple(stride), _triple(dilation)
+    if space_pad is None or isinstance(space_pad, int):
+        space_pad = (space_pad, space_pad)
+    hp = space_pad[0] if space_pad[0] is not None else w.shape[3] // 2
+    wp = space_pad[1] if space_pad[1] is not None else w.shape[4] // 2
+    t, h, ww = x.shape[2:]
+    y = F.conv_transpose3d(_gr(x), w, b, stride=stride, padding=(0, hp, wp), dilation=dilation)
+    return _st(y[..., :t * stride[0], :h * stride[1], :ww * stride[2]])
+
+
+def spacetime_upsample(x: Tensor, w: Tensor, b: Optional[Tensor], time_factor: int = 2, space_factor: int = 2) -> Tensor:
+    """video.py:432-455: nn.ConvTranspose3d(kernel = stride = (tf, sf, sf))."""
+    return _st(F.conv_transpose3d(_gr(x), w, b, stride=(time_factor, space_factor, space_factor)))
+
+
 def conv3d_same(x: Tensor, w: Tensor, b: Optional[Tensor], resid: Optional[Tensor] = None, round_dx: bool = True) -> Tensor:
     """nn.Conv3d(k, padding=(k-1)//2) as used by VideoResidualBlock (video.py:580-586, 614-620)
     and the ST-block FFN (attention.py:429-438).  Symmetric zero padding: NOT causal (QUIRK 5)."""

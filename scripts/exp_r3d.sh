@@ -2,7 +2,7 @@
 # round 3, GPU call 5: lean (buffer-addressed) staging in the forward / backward-data kw-triple kernels: correctness, A/B, step
 set -u
 OUT=gpurun_out/r3d; mkdir -p $OUT
-timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_properties.py -q -m gpu -k "conv or linear" 2>&1 | tail -6 > $OUT/pytest_conv.log
+timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_properties.py tests/test_gpu_transpose.py -q -m gpu -k "conv or linear or upsample or causal" 2>&1 | tail -30 > $OUT/pytest_conv.log
 tail -3 $OUT/pytest_conv.log
 for lean in 1 0 1 0; do
   for f in "res 128->128 k3 @16x64x64" "res 256->256 k3 @16x32x32" "res 128->256 k3 @16x32x32"; do

@@ -39,8 +39,13 @@ def test_causal_geometry_matches_reference_formula():
         ref = O.causal_conv3d(x, torch.zeros(4, 4, *k), None, stride=s, dilation=d)
         assert spec.out_size((9, 12, 12)) == tuple(ref.shape[2:])
     assert same_spec(4, 4, (3, 3, 3)).pad_front == (1, 1, 1) == same_spec(4, 4, (3, 3, 3)).pad_back
-    with pytest.raises(ValueError):
-        causal_spec(4, 4, (1, 3, 3), (2, 1, 1))                       # negative causal pad
+    # negative causal pad (kt = 1, time stride 2): the reference crops the first frame (F.pad with -1, video.py:154-164); here the module
+    # slices `causal_time_crop` frames off and the conv runs without time padding -- same output size
+    from genie.conv import causal_time_crop
+    spec = causal_spec(4, 4, (1, 3, 3), (2, 1, 1))
+    assert spec.pad_front[0] == 0 and causal_time_crop((1, 3, 3), (2, 1, 1)) == 1 and causal_time_crop((3, 3, 3), (2, 2, 2)) == 0
+    ref = O.causal_conv3d(torch.zeros(1, 4, 9, 12, 12), torch.zeros(4, 4, 1, 3, 3), None, stride=(2, 1, 1))
+    assert spec.out_size((9 - 1, 12, 12)) == tuple(ref.shape[2:])
 
 
 def test_magvit2_state_dict_layout_matches_reference():

@@ -53,6 +53,26 @@ def test_blur_pool():
     close(O.blur_pool3d(x, 3, 2, 2), m(x))
 
 
+def test_transposed_convs_and_negative_causal_pad():
+    """video.py:202-277 (CausalConvTranspose3d), :432-455 (SpaceTimeUpsample) and the negative causal pad of a kt = 1, time-stride-2
+    CausalConv3d (video.py:154-164: F.pad with -1 crops the first frame)."""
+    V = ref_module('module.video')
+    torch.manual_seed(21)
+    for kw in (dict(kernel_size=3, stride=(2, 2, 2)), dict(kernel_size=(3, 3, 3), stride=(1, 2, 2)), dict(kernel_size=3, stride=(2, 1, 1), dilation=(1, 1, 1)),
+               dict(kernel_size=(2, 3, 3), stride=(2, 2, 2), space_pad=0)):
+        m = V.CausalConvTranspose3d(6, 10, **kw)
+        x = torch.randn(2, 6, 3, 5, 4)
+        close(O.causal_conv_transpose3d(x, m.weight, m.bias, kw.get('stride', (1, 1, 1)), kw.get('dilation', (1, 1, 1)), kw.get('space_pad')), m(x))
+    u = V.SpaceTimeUpsample(6, 5, time_factor=2, space_factor=3)
+    x = torch.randn(2, 6, 3, 4, 4)
+    close(O.spacetime_upsample(x, u.go_up.weight, u.go_up.bias, 2, 3), u(x))
+    c = V.CausalConv3d(6, 7, (1, 3, 3), stride=(2, 1, 1))
+    x = torch.randn(2, 6, 7, 5, 5)
+    want = c(x)
+    assert want.shape[2] == 3                                       # 7 frames: the first is cropped, stride 2 over the remaining 6
+    close(O.causal_conv3d(x, c.conv3d.weight, c.conv3d.bias, stride=(2, 1, 1)), want)
+
+
 def test_up_down():
     V = ref_module('module.video')
     torch.manual_seed(2)
