@@ -360,8 +360,8 @@ class CausalConvTranspose3d(nn.Module):
         full = tuple((n - 1) * s - 2 * p + d * (k - 1) + 1 for n, s, p, d, k in zip((t, h, w), self.stride, self.padding, self.dilation, self.kernel_size))
         out = GF.conv_transpose3d(inp, self.weight, self.op, full)
         out = out[:, :, :t * self.stride[0], :h * self.stride[1], :w * self.stride[2]]            # video.py:263-267
-        if self.bias is not None:
-            out = out + self.bias.to(out.dtype)[None, :, None, None, None]
+        if self.bias is not None:                    # in fp32: one rounding of the sum, and the bias gradient is an fp32 reduction
+            out = out.float() + self.bias[None, :, None, None, None]
         return to_cl(out)
 
     @property

@@ -83,7 +83,30 @@ def import_reference():
     return sys.modules['ref_genie']
 
 
+def _import_extra(path: str) -> None:
+    """Import a reference sub-module that ``genie/__init__`` does not pull in (e.g. ``module.data``): the reference's absolute imports
+    (``from genie.utils import ...``) need ``genie`` to BE the reference while that happens, so the two packages swap places for the
+    duration of the import."""
+    import importlib
+    ours = {k: sys.modules.pop(k) for k in list(sys.modules) if k == 'genie' or k.startswith('genie.')}
+    refs = {k: v for k, v in sys.modules.items() if k == 'ref_genie' or k.startswith('ref_genie.')}
+    for k, v in refs.items():
+        sys.modules[k[4:]] = v
+    sys.path.insert(0, REFERENCE_ROOT)
+    try:
+        importlib.import_module('genie.' + path)
+    finally:
+        sys.path.remove(REFERENCE_ROOT)
+        for k in list(sys.modules):
+            if k == 'genie' or k.startswith('genie.'):
+                sys.modules['ref_' + k] = sys.modules.pop(k)
+        sys.modules.update(ours)
+
+
 def ref_module(path: str):
     """``ref_module('module.video')`` -> the reference's ``genie.module.video``."""
     import_reference()
-    return sys.modules['ref_genie' + ('.' + path if path else '')]
+    key = 'ref_genie' + ('.' + path if path else '')
+    if key not in sys.modules:
+        _import_extra(path)
+    return sys.modules[key]

@@ -105,3 +105,100 @@ def test_data_modules_and_prefetcher(clips):
     yaml.safe_dump({'dataset': {'root': clips, 'num_frames': 4, 'batch_size': 3}}, open(cfg, 'w'))
     dm2 = LightningPlatformer2D.from_config(cfg)
     assert dm2.batch_size == 3 and dm2.num_frames == 4
+
+
+# ----------------------------------------------------------------------------------------------------------------------------------
+# against the REAL reference reader (reference genie/module/data.py:139-234), wherever /root/reference is present
+# ----------------------------------------------------------------------------------------------------------------------------------
+class _FakeCv2:
+    """The five OpenCV names the reference binds (data.py:4-8), served from frame arrays: a '.mp4' here is an .npy dump of BGR uint8
+    frames (T, H, W, 3), optionally followed by a header lie (`<name>.mp4.count` holds the frame count the container CLAIMS -- a
+    damaged clip runs out of frames before that)."""
+    CAP_PROP_FRAME_COUNT, CAP_PROP_POS_FRAMES, COLOR_BGR2RGB = 7, 1, 4
+
+    class VideoCapture:
+        def __init__(self, path):
+            with open(path, 'rb') as f:
+                self.frames = np.load(f)
+            self.claimed = int(open(path + '.count').read()) if os.path.exists(path + '.count') else len(self.frames)
+            self.pos = 0
+
+        def get(self, prop):
+            assert prop == _FakeCv2.CAP_PROP_FRAME_COUNT
+            return float(self.claimed)
+
+        def set(self, prop, value):
+            assert prop == _FakeCv2.CAP_PROP_POS_FRAMES
+            self.pos = int(value)
+
+        def read(self):
+            if self.pos >= len(self.frames):
+                return False, None
+            self.pos += 1
+            return True, self.frames[self.pos - 1]
+
+        def release(self):
+            pass
+
+    @staticmethod
+    def cvtColor(frame, code):
+        assert code == _FakeCv2.COLOR_BGR2RGB
+        return np.ascontiguousarray(frame[..., ::-1])
+
+
+@pytest.fixture()
+def mp4_clips(tmp_path):
+    rng = np.random.default_rng(1)
+    d = tmp_path / 'Coinrun' / 'train'
+    d.mkdir(parents=True)
+    for i, (n, claimed) in enumerate(((12, None), (7, None), (9, 14), (20, None))):
+        with open(d / f'ep{i}.mp4', 'wb') as f:
+            np.save(f, rng.integers(0, 256, size=(n, 6, 10, 3), dtype=np.uint8))
+        if claimed:
+            (d / f'ep{i}.mp4.count').write_text(str(claimed))
+    return str(tmp_path)
+
+
+def test_platformer2d_matches_the_reference_reader(mp4_clips, monkeypatch):
+    """Same clips through the reference's Platformer2D (its cv2 names bound to the array-backed fake above) and through ours (whose
+    OpenCV reader imports the same fake): identical tensors for every padding mode the reference can run, both axis orders, short
+    clips, a damaged clip whose header promises more frames than it has, and seeded random starts (the readers had only
+    been compared with hand-built expectations)."""
+    import random
+    import sys
+
+    from oracle.ref_import import ref_module, reference_available
+    if not reference_available():
+        pytest.skip('/root/reference is not present on this box')
+    from genie.module import data as D
+    R = ref_module('module.data')
+    for name in ('VideoCapture', 'cvtColor', 'COLOR_BGR2RGB', 'CAP_PROP_POS_FRAMES', 'CAP_PROP_FRAME_COUNT'):
+        monkeypatch.setattr(R, name, getattr(_FakeCv2, name))
+    monkeypatch.setitem(sys.modules, 'cv2', _FakeCv2)
+    monkeypatch.setattr(D, 'VIDEO_EXT', ('.mp4',))                      # the '.count' side files are not clips
+    monkeypatch.setattr(R, 'listdir', lambda p: sorted(f for f in os.listdir(p) if f.endswith('.mp4')))
+    checked = 0
+    for padding in ('none', 'repeat', 'zero'):
+        for fmt in ('t c h w', 'c t h w'):
+            for nf in (5, 8, 16):
+                ref = R.Platformer2D(mp4_clips, padding=padding, num_frames=nf, output_format=fmt)
+                ours = D.Platformer2D(mp4_clips, padding=padding, num_frames=nf, output_format=fmt)
+                assert [os.path.basename(f) for f in ref.file_names] == [os.path.basename(f) for f in ours.file_names]
+                for i in range(len(ref)):
+                    a, b = ref[i], ours[i]
+                    assert a.shape == b.shape and a.dtype == b.dtype == torch.float32, (padding, fmt, nf, i, a.shape, b.shape)
+                    assert torch.equal(a, b), (padding, fmt, nf, i)
+                    checked += 1
+    assert checked == 72
+    # random starts: both draw from Python's global generator with the same call
+    ref = R.Platformer2D(mp4_clips, randomize=True, num_frames=6)
+    ours = D.Platformer2D(mp4_clips, randomize=True, num_frames=6)
+    for i in range(len(ref)):
+        random.seed(100 + i); a = ref[i]
+        random.seed(100 + i); b = ours[i]
+        assert torch.equal(a, b)
+    # 'random' padding: the reference calls torch.rand_like on a uint8 frame, which torch rejects; ours pads with a float frame in [0, 1)
+    with pytest.raises(Exception):
+        R.Platformer2D(mp4_clips, padding='random', num_frames=16)[2]
+    v = D.Platformer2D(mp4_clips, padding='random', num_frames=16)[2]
+    assert tuple(v.shape) == (14, 3, 6, 10) and 0 <= v.min() and v.max() <= 1
