@@ -1,6 +1,14 @@
 #!/usr/bin/env python
-"""Training-step timing of the other BASELINE configs on one MI355X (configs[2] LatentAction, configs[3] DynamicsModel, and the
-repaired yaml / REPR tokenizer): ms per step and clips (or latent frames) per second, synthetic inputs resident in HBM."""
+"""Training-step timing of the other BASELINE configs on one MI355X (configs[2] LatentAction, configs[3] DynamicsModel, configs[4] full
+Genie on 32x128x128 clips, and the repaired yaml / REPR tokenizer): ms per step and clips (or latent frames) per second, synthetic inputs
+resident in HBM.  Each line also carries
+
+  conv_kernels -- every conv / GEMM kernel variant of the step (HIP events around each launch): launches, ms per step, TFLOP/s
+  roofline     -- the variant with the largest share of the step, priced against the dense bf16 MFMA peak like bench.py's
+  cpu_baseline -- (`--cpu-baseline`, configs[2] / [3]) the oracle doing the same training step on the host cores, ONE step after one warm-up
+
+  python scripts/bench_models.py [lam] [dyn] [repr] [genie4] [--cpu-baseline]
+The per-kernel rocprofv3 tables of the same runs: scripts/profile_models.sh -> profiles/rNN_models_*_kernel_stats.csv."""
 import json
 import os
 import sys
@@ -12,10 +20,13 @@ import torch
 
 from genie import (LATENT_ACT_DEC, LATENT_ACT_ENC, MAGVIT2_DEC_DESC, MAGVIT2_ENC_DESC, REPR_TOK_DEC, REPR_TOK_ENC, DynamicsModel, Genie, LatentAction,
                    VideoTokenizer)
+from genie import conv as gconv
 from genie.trainer import ParamArena
 
+PEAK = 2500.0
 
-def run(name, model, step_fn, units, steps=4, warm=2):
+
+def run(name, model, step_fn, units, steps=4, warm=2, cpu=None):
     arena = ParamArena(model)
     arena.attach_weight_packs(model)
     for _ in range(warm):
@@ -28,21 +39,63 @@ def run(name, model, step_fn, units, steps=4, warm=2):
     ms = (time.perf_counter() - t0) / steps * 1e3
     out = {'model': name, 'ms_per_step': round(ms, 2), 'units_per_s': round(units / ms * 1e3, 1), 'params': sum(p.numel() for p in model.parameters()),
            'peak_mem_GB': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
+    # second pass with HIP events around every conv / GEMM launch (costs a few % of the step: kept out of the timing above)
+    prof = gconv.PROFILER = gconv.LaunchProfiler(only_triple=False)
+    for _ in range(steps):
+        step_fn().backward(); arena.adamw_step()
+    gconv.PROFILER = None
+    summ = prof.summary()
+    if summ:
+        out['conv_kernels'] = {k: {'launches_per_step': v['launches'] // steps, 'ms_per_step': round(v['ms'] / steps, 3),
+                                   'tflops': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 1) if v['ms'] > 0 else None} for k, v in summ.items()}
+        dom = max(summ, key=lambda k: summ[k]['ms'])
+        d = summ[dom]
+        ach = d['flops'] / (d['ms'] * 1e-3) / 1e12
+        out['roofline'] = {'kernel': dom, 'bound': 'mfma', 'achieved': round(ach, 1), 'peak': PEAK, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK, 4),
+                           'launches_per_step': d['launches'] // steps, 'share_of_step_time': round(d['ms'] / steps / ms, 4),
+                           'conv_share_of_step_time': round(sum(v['ms'] for v in summ.values()) / steps / ms, 4),
+                           'note': 'dominant CONV / GEMM variant; the attention, GroupNorm and LFQ kernels of the step are in the rocprofv3 table of the same run'}
+    if cpu is not None:
+        out['cpu_baseline'] = cpu()
     print(json.dumps(out), flush=True)
     del arena
     torch.cuda.empty_cache(); torch.cuda.reset_peak_memory_stats()
     return out
 
 
+def cpu_step(build, units, what):
+    """One training step of the oracle (fp32 torch CPU, every thread this process may use) after one warm-up step; the unit count of ONE step."""
+    def go():
+        import bench as B_
+        threads = min(B_.effective_cpus(), 128)
+        torch.set_num_threads(threads)
+        step = build()
+        step()
+        t0 = time.perf_counter()
+        step()
+        dt = time.perf_counter() - t0
+        return {'value': round(units / dt, 3), 'unit': what, 'cores': threads, 'kind': 'port',
+                'sample': f'one training step (fwd + bwd, no optimiser) of the oracle restatement after one warm-up step, {dt:.1f} s'}
+    return go
+
+
 def main():
     torch.manual_seed(0)
     res = []
-    which = sys.argv[1:] or ['lam', 'dyn', 'repr']
+    argv = [a for a in sys.argv[1:] if not a.startswith('--')]
+    want_cpu = '--cpu-baseline' in sys.argv
+    which = argv or ['lam', 'dyn', 'repr']
     if 'lam' in which:
         B = 2
         lam = LatentAction(LATENT_ACT_ENC, LATENT_ACT_DEC, d_codebook=8, inp_channels=3, inp_shape=(64, 64), n_embd=256).cuda().train()
         v = torch.randn(B, 3, 16, 64, 64, device='cuda')
-        res.append(run(f'LatentAction (R-lam, n_embd 256, 16x64x64, B={B}) [frames/s]', lam, lambda: lam(v)[1], B * 16))
+        def lam_cpu():
+            from oracle import genie_oracle as O
+            sd = {k: (t.detach().float().cpu().clone().requires_grad_(t.is_floating_point() and 'freq' not in k)) for k, t in lam.state_dict().items()}
+            x = torch.randn(1, 3, 16, 64, 64)
+            return lambda: O.latent_action_forward(x, sd, LATENT_ACT_ENC, LATENT_ACT_DEC, 8, training=True)[1].backward()
+        res.append(run(f'LatentAction (configs[2]: R-lam, n_embd 256, 16x64x64, B={B}) [frames/s]', lam, lambda: lam(v)[1], B * 16,
+                       cpu=cpu_step(lam_cpu, 16, 'video-frames/sec (one 16x64x64 clip)') if want_cpu else None))
         del lam
     if 'dyn' in which:
         B = 4
@@ -51,8 +104,14 @@ def main():
         tok = torch.randint(0, 2 ** 18, (B, 16, 8, 8), device='cuda'); act = torch.randint(0, 8, (B, 16), device='cuda')
         g = torch.Generator().manual_seed(1)
         mask = (torch.rand(B, 16, 8, 8, generator=g) < 0.75)
-        res.append(run(f'DynamicsModel (8 x ST(8x64), V=2^18, (16,8,8) tokens, B={B}) [latent frames/s]', dyn,
-                       lambda: dyn.compute_loss(tok, act, mask=mask), B * 16))
+        def dyn_cpu():
+            from oracle import genie_oracle as O
+            sd = {k: (t.detach().float().cpu().clone().requires_grad_(t.is_floating_point() and 'freq' not in k)) for k, t in dyn.state_dict().items()}
+            tk, ac, mk = tok[:2].cpu(), act[:2].cpu(), mask[:2]
+            return lambda: O.dynamics_loss(tk, ac, mk, sd, desc).backward()
+        res.append(run(f'DynamicsModel (configs[3]: 8 x ST(8x64), V=2^18, (16,8,8) tokens, B={B}) [latent frames/s]', dyn,
+                       lambda: dyn.compute_loss(tok, act, mask=mask), B * 16,
+                       cpu=cpu_step(dyn_cpu, 2 * 16, 'latent frames/sec (two (16,8,8) token grids)') if want_cpu else None))
         del dyn
     if 'repr' in which:
         B = 2
@@ -72,7 +131,8 @@ def main():
                        lambda: gen.compute_loss(v)[0], B * 32, steps=3, warm=1))
         del gen, tokz
     os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
-    json.dump(res, open(os.path.join(ROOT, 'gpurun_out', 'bench_models.json'), 'w'), indent=1)
+    tag = '_'.join(which)
+    json.dump(res, open(os.path.join(ROOT, 'gpurun_out', f'bench_models_{tag}.json'), 'w'), indent=1)
 
 
 if __name__ == '__main__':

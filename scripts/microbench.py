@@ -195,6 +195,10 @@ def bench_hbm(iters, quick=False):
     # plain device copy as the achievable-bandwidth yardstick
     a = torch.empty(1 << 28, dtype=torch.float32, device='cuda'); bb = torch.empty_like(a)
     report('hbm', 'torch copy 1 GiB (yardstick: read + write)', timeit(lambda: bb.copy_(a), iters), bytes_=2.0 * a.numel() * 4)
+    # one-directional yardsticks: the stem conv is a WRITE stream (16.8 MB out per 0.39 MB in), the head conv and the weight gradients READ streams
+    report('hbm', 'torch fill 1 GiB (yardstick: write only)', timeit(lambda: bb.fill_(1.0), iters), bytes_=1.0 * a.numel() * 4)
+    a16 = a.view(torch.bfloat16)
+    report('hbm', 'torch sum 1 GiB bf16 (yardstick: read only)', timeit(lambda: a16.sum(dtype=torch.float32), iters), bytes_=1.0 * a.numel() * 4)
 
 
 # ------------------------------------------------------------------------------------------------

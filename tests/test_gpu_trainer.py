@@ -97,10 +97,12 @@ def _step_grads(build, run, dp_cuts, loopback):
     from genie.trainer import DataParallel, ParamArena
     m = build()
     arena = ParamArena(m)
+    m._arena_for_cuts = arena
     dp = None
     if loopback:
         dp = DataParallel(arena.grads, compress='bf16', loopback=True)
         dp.install_overlap_hooks(arena, m, dp_cuts(m))
+        dp.trace = True                                      # HIP events around every bucket's all-reduce and finish()'s wait (comm_report)
     loss = run(m)
     loss.backward()
     if dp is not None:
@@ -144,6 +146,19 @@ def test_data_parallel_loopback_on_real_models():
             (build_tok, lambda m: m(x)[0], lambda m: [m.enc_layers[2], m.quant, m.dec_layers[1], m.dec_layers[4]]),
             (build_dyn, lambda m: m.compute_loss(tok, act, mask=mask), lambda m: [m.dec_layers[1], m.dec_layers[2], m.head]),
         ]
+        # equal-byte cuts (what bench.py uses): chosen among the layers, in forward order, close to the k / n points of the arena
+        from genie.trainer import DataParallel, ParamArena
+        m0 = build_tok()
+        a0 = ParamArena(m0)
+        layers = [l for l in list(m0.enc_layers) + list(m0.dec_layers) if any(p.requires_grad for p in l.parameters())]
+        picks = DataParallel.equal_byte_cuts(a0, m0, layers, 4)
+        offs = [a0.offset_of(l, m0) for l in picks]
+        assert offs == sorted(offs) and 1 <= len(picks) <= 3 and all(0 < o < a0.numel for o in offs)
+        assert all(min(abs(o - a0.numel * k / 4) for k in (1, 2, 3)) < a0.numel / 4 for o in offs)
+        del m0, a0
+        cases.append((build_tok, lambda m: m(x)[0],
+                      lambda m: DataParallel.equal_byte_cuts(m._arena_for_cuts, m, [l for l in list(m.enc_layers) + list(m.dec_layers)
+                                                                                   if any(p.requires_grad for p in l.parameters())], 4)))
         for build, run, cuts in cases:
             g_ref, _, _ = _step_grads(build, run, cuts, loopback=False)
             g_dp, dp, arena = _step_grads(build, run, cuts, loopback=True)
@@ -151,6 +166,12 @@ def test_data_parallel_loopback_on_real_models():
             assert dp.last_fired == list(range(nb - 1, -1, -1)), dp.last_fired
             assert len(dp.fired_in_backward) >= nb - 1, (dp.fired_in_backward, nb)        # all but the first bucket start during backward
             assert dp.bytes_reduced == arena.numel * 2
+            # the overlap diagnostics bench.py --gpus N prints (`comm`): one entry per bucket, payloads add up, times are sane
+            rep = dp.comm_report()
+            assert rep['steps_traced'] == 1 and len(rep['buckets']) == nb
+            assert sum(b_['elements'] for b_ in rep['buckets']) == arena.numel
+            assert all(b_['allreduce_ms'] > 0 and b_['issued_before_backward_end_ms'] >= 0 for b_ in rep['buckets'])
+            assert rep['exposed_ms_per_step'] >= 0 and rep['allreduce_ms_per_step'] > 0
             assert torch.equal(g_dp, g_dp.to(torch.bfloat16).float()), 'a gradient was written after its bucket had been reduced'
             for name, (off, n) in arena.slots.items():
                 a, b = g_dp[off:off + n], g_ref[off:off + n]
