@@ -156,6 +156,7 @@ int genie_conv_igemm(const GenieConvDesc* desc, void* stream);
 #define GENIE_VARIANT_IGEMM3_WIDE 12     /* igemm3w_kernel: 256 x 256 tile, layers with >= 256 output channels */
 #define GENIE_VARIANT_WGRAD_PW 13        /* wgrad_pw_kernel: pointwise weight gradient, 256 x 256 tile */
 #define GENIE_VARIANT_WGRAD3_LEAN 14     /* wgrad3l_kernel: kw-triple weight gradient, buffer-addressed LDS-DMA + scalar bookkeeping */
+#define GENIE_VARIANT_IGEMM3_H 15        /* igemm3h_kernel: 256 x 128 tile, 32-channel K-tiles, two blocks per CU (<= 128 output columns) */
 int genie_last_conv_variant(void);
 /* GroupNorm work the calling thread's last genie_conv_igemm did in its epilogue: bit 0 = gn_sums, bit 1 = gnb_part. */
 int genie_last_conv_gn_fused(void);

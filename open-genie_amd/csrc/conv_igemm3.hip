@@ -850,6 +850,191 @@ __global__ void __launch_bounds__(512) igemm3w_kernel(const Igemm3Args p, const 
     igemm_epilogue<BM, TM, TN>(a, acc, smem, m0, n0, wm, wn, tid, lane);
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// 256 x 128 tile with 32-channel K-tiles and TWO blocks per CU (round 3): the Cout = 128 layers.  igemm3d_kernel keeps 144 KB of LDS per
+// block, so a CU runs ONE block: its prologue (pipeline fill), its epilogue (64 KB of stores, transposes, the residual read) and every
+// barrier stall have nothing to hide behind, and with K = 27 x 128 the K loop of these layers is half as long as at 256 channels.  Here
+// the K-tile is 32 channels deep (image rows of 64 B: 2 x 20 KB; weight tiles 128 x 64 B in a ring of four 8-KB slots) = 72 KB and the
+// accumulators are 64 registers: two blocks (16 waves) share a CU and cover each other's epilogues and barriers.  One step = (dt, dh,
+// 32-channel block) = three K-tiles (shifts) of two k-steps = 8 MFMAs per wave between barriers.  LEAN staging (buffer loads).
+//   groups per step: s = 0: 2 image pieces of the next step + weight tile k + 3 (3 per wave), s = 1, 2: weight tile k + 3 (1); the wait at
+//   the end of K-tile k leaves group k in flight (vmcnt 3 / 1 / 1); publication one barrier ahead of consumption, WAR as in igemm3d_kernel.
+// Needs W >= 16 (a 1-KiB piece = 16 pixels of ONE image row), 256 % W == 0.
+// ------------------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(512, 4) igemm3h_kernel(const Igemm3Args p, const GenieTriStep* __restrict__ steps) {
+    constexpr int BM = 256, BN = 128, NWAVE = 8, WN = 2, TM = 2, TN = 2;
+    constexpr int A_ROUNDS = 2;                                              // 2 rounds x 8 waves x 16 pixels
+    constexpr int A_BYTES = 320 * 64, B_BYTES = BN * 64;                     // <= 320 image rows (W = 16: 16 x 18 = 288), 8-KB weight tiles
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const IgemmArgs& a = p.g;
+    const int nsub = 2 * p.nsteps;                                           // 32-channel sub-steps
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int W = a.Wo, H = a.Ho, T = a.To, WP = p.WP;
+    const int id = xcd_tile_id(a.tiles_m * a.tiles_n, blockIdx.x);
+    const int tile_n = id % a.tiles_n, tile_m = id / a.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int row0_id = m0 / W;
+
+    // ---- staging state ----
+    const int margin = (3 * H * W + 2 * W) * a.Cs;
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)(a.src + ((long long)m0 * a.Cs - margin)), (short)0, (int)IG3_OOB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)a.wgt, (short)0, (int)IG3_OOB, 0x00020000);
+    uint32_t voff_a[A_ROUNDS], a_dst[A_ROUNDS], voff_b;
+    int at_s[A_ROUNDS], ah_s[A_ROUNDS];
+#pragma unroll
+    for (int i = 0; i < A_ROUNDS; ++i) {
+        const int q0 = (i * NWAVE + wave) * 16;                              // first pixel of the wave's piece: 16 pixels of one image row
+        const int q = q0 + (lane >> 2);
+        const int hl = q / W, w = q - hl * W;
+        const int r = hl * WP + w + 1;                                       // this lane's LDS row
+        const int lc = (lane & 3) ^ ((r >> 2) & 3);
+        voff_a[i] = (long long)m0 + q < a.M ? (uint32_t)((q * a.Cs + lc * 8) * 2) : IG3_OOB;
+        a_dst[i] = (uint32_t)(((q0 / W) * WP + q0 % W + 1) * 64);
+        const int rowid = row0_id + q0 / W;
+        at_s[i] = __builtin_amdgcn_readfirstlane((rowid / H) % T);
+        ah_s[i] = __builtin_amdgcn_readfirstlane(rowid % H);
+    }
+    {
+        const int row = wave * 16 + (lane >> 2);                             // one 1-KiB piece per wave per weight tile: 16 rows x 64 B
+        const int lc = (lane & 3) ^ ((row >> 2) & 3);
+        const int n = n0 + row;
+        const int wr = n < a.Ncols ? (a.perm_f > 1 ? (n % a.perm_c) * a.perm_f + n / a.perm_c : n) : -1;
+        voff_b = wr >= 0 ? (uint32_t)(((size_t)wr * a.w_row_stride + lc * 8) * 2) : IG3_OOB;
+    }
+    // zero columns left and right of every image row, both buffers (written once, never DMA'd)
+    for (int e = tid; e < 2 * 2 * (BM / 16) * 4; e += 512) {                 // (buffer, side, image row, 16-B chunk)
+        const int c = e & 3, hl = (e >> 2) % (BM / 16), side = ((e >> 2) / (BM / 16)) & 1, buf = e / (2 * (BM / 16) * 4);
+        if (hl * W < BM) *reinterpret_cast<u32x4_t*>(smem + buf * A_BYTES + (hl * WP + (side ? W + 1 : 0)) * 64 + c * 16) = u32x4_t{0u, 0u, 0u, 0u};
+    }
+    __syncthreads();
+    // sub-step j = 2 * (table entry) + (32-channel half)
+    auto stage_a = [&](int j, int i, char* abuf) {
+        const bool live = j < nsub;
+        const GenieTriStep e = steps[live ? (j >> 1) : 0];
+        const bool ok = (int)live & (int)((unsigned)(at_s[i] + e.dt) < (unsigned)T) & (int)((unsigned)(ah_s[i] + e.dh) < (unsigned)H);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, LDS_PTR(abuf + a_dst[i]), 16, voff_a[i] | (ok ? 0u : IG3_OOB),
+                                                 ok ? (uint32_t)((e.a_delta + 32 * (j & 1) + margin) * 2) : 0u, 0, 0);
+    };
+    auto stage_b = [&](int j, int s, char* bbuf) {                          // weight tile of (sub-step j, shift s)
+        const bool live = j < nsub;
+        const GenieTriStep e = steps[live ? (j >> 1) : 0];
+        const int wofs = (s == 0 ? e.wofs0 : (s == 1 ? e.wofs1 : e.wofs2)) + 32 * (j & 1);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, LDS_PTR(bbuf + wave * 1024), 16, voff_b | (live ? 0u : IG3_OOB), live ? (uint32_t)(wofs * 2) : 0u, 0, 0);
+    };
+
+    // fragment read offsets: 64-B rows, 16-B chunk (2 ks + khalf) at slot chunk ^ ((row >> 2) & 3)
+    unsigned a_off[3][2][TM], b_off[2][TN];
+    const int khalf = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int pl = wm * (TM * 32) + i * 32 + (lane & 31);
+        const int hl = pl / W;
+        const int row0 = hl * WP + (pl - hl * W);
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int row = row0 + s;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) a_off[s][ks][i] = (unsigned)(row * 64 + (((ks * 2 + khalf) ^ ((row >> 2) & 3)) << 4));
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int row = wn * (TN * 32) + j * 32 + (lane & 31);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) b_off[ks][j] = (unsigned)(row * 64 + (((ks * 2 + khalf) ^ ((row >> 2) & 3)) << 4));
+    }
+
+    f32x16_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    char* const A0 = smem;
+    char* const B0 = smem + 2 * A_BYTES;
+    auto read_frag = [&](const char* abuf, int s, int ks, const char* bbuf, bf16x8_t (&fa)[TM], bf16x8_t (&fb)[TN]) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8_t*>(abuf + a_off[s][ks][i]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const bf16x8_t*>(bbuf + b_off[ks][j]);
+    };
+    auto mfma8 = [&](const bf16x8_t (&fa)[TM], const bf16x8_t (&fb)[TN]) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    };
+    auto raw_barrier = [&]() {
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+
+    // ---- prologue: image 0, weight tiles 0, 1, 2 ----
+#pragma unroll
+    for (int i = 0; i < A_ROUNDS; ++i) stage_a(0, i, A0);
+    stage_b(0, 0, B0);
+    stage_b(0, 1, B0 + B_BYTES);
+    stage_b(0, 2, B0 + 2 * B_BYTES);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    raw_barrier();
+
+    bf16x8_t fa0[TM], fb0[TN];
+    read_frag(A0, 0, 0, B0, fa0, fb0);
+    int k = 0;                                                               // K-tile counter (3 j + s); weight tile k sits in slot k & 3
+    for (int j = 0; j < nsub; ++j, k += 3) {
+        char* const acur = A0 + (j & 1) * A_BYTES;
+        char* const anxt = A0 + ((j + 1) & 1) * A_BYTES;
+#define GENIE_T_KTILE(S, ISSUE, NEXT_A, NEXT_S, WAITN)                                                            \
+        {                                                                                                        \
+            const char* bcur = B0 + ((k + S) & 3) * B_BYTES;                                                     \
+            const char* bnext = B0 + ((k + S + 1) & 3) * B_BYTES;                                                \
+            bf16x8_t fa1[TM], fb1[TN];                                                                           \
+            read_frag(acur, S, 1, bcur, fa1, fb1);                                                               \
+            mfma8(fa0, fb0);                                                                                     \
+            __builtin_amdgcn_sched_barrier(0);                                                                   \
+            ISSUE                                                                                                \
+            __builtin_amdgcn_sched_barrier(0);                                                                   \
+            read_frag(NEXT_A, NEXT_S, 0, bnext, fa0, fb0);                                                       \
+            mfma8(fa1, fb1);                                                                                     \
+            __builtin_amdgcn_sched_barrier(0);                                                                   \
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WAITN) : "memory");                                        \
+            raw_barrier();                                                                                       \
+        }
+        // weight tile k + S + 3 = (sub-step j + 1, shift S)
+        GENIE_T_KTILE(0,
+                      _Pragma("unroll") for (int ar = 0; ar < A_ROUNDS; ++ar) stage_a(j + 1, ar, anxt);
+                      __builtin_amdgcn_sched_barrier(0);
+                      stage_b(j + 1, 0, B0 + ((k + 3) & 3) * B_BYTES);,
+                      acur, 1, 3)
+        GENIE_T_KTILE(1, stage_b(j + 1, 1, B0 + ((k + 4) & 3) * B_BYTES);, acur, 2, 1)
+        GENIE_T_KTILE(2, stage_b(j + 1, 2, B0 + ((k + 5) & 3) * B_BYTES);, anxt, 0, 1)
+#undef GENIE_T_KTILE
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    raw_barrier();
+    igemm_epilogue<BM, TM, TN, false>(a, acc, smem, m0, n0, wm, wn, tid, lane);
+}
+
+static int launch_igemm3h(const Igemm3Args& p, const GenieTriStep* steps, hipStream_t s) {
+    constexpr int lds = 2 * (320 * 64) + 4 * 128 * 64;
+    static bool conf = false;
+    if (!conf) {
+        hipError_t e = hipFuncSetAttribute((const void*)igemm3h_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) {
+            genie_set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return GENIE_ERR_HIP;
+        }
+        conf = true;
+    }
+    hipLaunchKernelGGL(igemm3h_kernel, dim3(p.g.tiles_m * p.g.tiles_n, 1), dim3(512), lds, s, p, steps);
+    GENIE_CHECK_LAUNCH();
+    return GENIE_OK;
+}
+
 // The LEAN staging (buffer loads with 32-bit byte offsets) needs the weight pack below 2 GiB; GENIE_TRI_LEAN=0 switches it off (A/B).
 static bool ig3_lean_ok(const Igemm3Args& p) {
     static const int on = getenv("GENIE_TRI_LEAN") ? atoi(getenv("GENIE_TRI_LEAN")) : 1;
@@ -1258,6 +1443,14 @@ int genie_conv_igemm3_try(const GenieConvDesc* d, IgemmArgs a, hipStream_t s) {
         genie_note_variant(GENIE_VARIANT_IGEMM3_WIDE);
         genie_note_gn_fused(gn_mask);
         return launch_igemm3w<false>(p, d->tri_steps, s);
+    }
+    // two-blocks-per-CU form (igemm3h_kernel) where the layer has <= 128 output columns: GENIE_TRI_H=0 switches it off
+    static const int h_env = getenv("GENIE_TRI_H") ? atoi(getenv("GENIE_TRI_H")) : 1;
+    if (h_env && bm == 256 && split == 1 && a.Nstore <= 128 && W >= 16 && 256 % W == 0 && p.dbg == 0 && (d->tri_flags & (1 | 2 | 64 | 128 | 256 | 512)) == 0 &&
+        !p.g.gn_sums && !p.g.gnb_x && ig3_lean_ok(p) && ((long long)p.g.tiles_m >= 512 || (d->tri_flags & 2048))) {      // bit 11: even with few tiles (tests)
+        genie_note_variant(GENIE_VARIANT_IGEMM3_H);
+        genie_note_gn_fused(0);
+        return launch_igemm3h(p, d->tri_steps, s);
     }
     genie_note_variant(split > 1 ? GENIE_VARIANT_IGEMM3_256_SPLITK : (bm == 256 ? GENIE_VARIANT_IGEMM3_256 : GENIE_VARIANT_IGEMM3_128));
     genie_note_gn_fused(gn_mask);

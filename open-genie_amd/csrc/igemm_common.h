@@ -51,7 +51,7 @@ __device__ __forceinline__ int xcd_tile_id(int nb, int b) {
 // Epilogue shared by the gather-GEMM kernels.  acc[i][j] is the wave's (wm, wn) sub-tile as TM x TN 32x32 MFMA tiles
 // (row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5), col = lane & 31); BMROWS = rows of the block tile (<= blockDim.x);
 // smem: >= BMROWS ints of LDS that nobody reads any more (the caller has passed its last barrier).
-template <int BMROWS, int TM, int TN>
+template <int BMROWS, int TM, int TN, bool GN = true>
 __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16_t (&acc)[TM][TN], char* smem, int m0, int n0, int wm, int wn,
                                                int tid, int lane) {
     const int khalf = lane >> 5;
@@ -75,7 +75,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16_t (&ac
         // columns -> 8-byte stores instead of 2-byte ones (4x fewer store instructions)
         const int jq = lane & 3;
         // GroupNorm fusion (see IgemmArgs): the tile lies inside sample gn_n, row tile gn_blk of it
-        const bool gn_fwd = BMROWS == 256 && a.gn_sums != nullptr, gn_bwd = BMROWS == 256 && a.gnb_x != nullptr;   // block-uniform; 256-row tiles only
+        const bool gn_fwd = GN && BMROWS == 256 && a.gn_sums != nullptr, gn_bwd = GN && BMROWS == 256 && a.gnb_x != nullptr;   // block-uniform; 256-row tiles only
         int gn_n = 0, gn_blk = 0;
         float gmu = 0.f, grs = 0.f, fs = 0.f, fss = 0.f;
         if (gn_fwd || gn_bwd) {

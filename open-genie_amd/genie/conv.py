@@ -63,7 +63,7 @@ PROFILER: Optional[LaunchProfiler] = None
 
 VARIANT_NAMES = {0: 'igemm_kernel<128,generic>', 1: 'igemm_kernel<128,smallc>', 2: 'igemm_kernel<32,generic>', 3: 'igemm_kernel<32,smallc>',
                  4: 'igemm3_kernel<128>', 5: 'igemm3_kernel<256>', 6: 'gemm_pw_kernel', 7: 'igemm3_kernel<256,splitk>', 8: 'wgrad_kernel<128,128>', 9: 'wgrad_kernel<128,32>',
-                 10: 'wgrad_kernel<32,128>', 11: 'wgrad3_kernel', 12: 'igemm3_kernel<256x256>', 13: 'wgrad_pw_kernel<256x256>', 14: 'wgrad3l_kernel'}
+                 10: 'wgrad_kernel<32,128>', 11: 'wgrad3_kernel', 12: 'igemm3_kernel<256x256>', 13: 'wgrad_pw_kernel<256x256>', 14: 'wgrad3l_kernel', 15: 'igemm3_kernel<256,k32>'}
 
 
 def _variant(kind: str, spec: 'ConvSpec', ncols: int, small_c: bool) -> str:

@@ -49,7 +49,7 @@ for sub, counter in (('fetch', 'FETCH_SIZE'), ('write', 'WRITE_SIZE')):
 # /opt/skills/guides/MI355X_MICROARCH.md (HBM section) prescribes for gfx950: the counters are in KB; FETCH_SIZE reports half of
 # the bytes of 16-B/lane streaming reads (x2); WRITE_SIZE is used as reported (calibrated here on the AdamW kernel: 16 B/param
 # read, 16 B/param written incl. the gradient clear -> FETCH x 2 = 6.0 GB, WRITE = 6.0 GB for 375.6 M parameters).
-NAMES = {'igemm3w_kernel<false': 'igemm3_kernel<256x256>', 'igemm3dl_kernel': 'igemm3_kernel<256>', 'igemm3d_kernel<true, false': 'igemm3_kernel<256>', 'igemm3d_kernel<true, true': 'igemm3_kernel<256,splitk>', 'igemm3_kernel<128': 'igemm3_kernel<128>', 'wgrad3l_kernel': 'wgrad3l_kernel', 'wgrad3_kernel': 'wgrad3_kernel',
+NAMES = {'igemm3w_kernel<false': 'igemm3_kernel<256x256>', 'igemm3dl_kernel': 'igemm3_kernel<256>', 'igemm3h_kernel': 'igemm3_kernel<256,k32>', 'igemm3d_kernel<true, false': 'igemm3_kernel<256>', 'igemm3d_kernel<true, true': 'igemm3_kernel<256,splitk>', 'igemm3_kernel<128': 'igemm3_kernel<128>', 'wgrad3l_kernel': 'wgrad3l_kernel', 'wgrad3_kernel': 'wgrad3_kernel',
          'igemm_kernel<128, 2, 2, false>': 'igemm_kernel<128,generic>', 'wgrad_kernel<128, 128': 'wgrad_kernel<128,128>',
          'adamw_kernel': 'adamw_kernel'}
 traffic = {}

@@ -765,6 +765,50 @@ def test_conv_triple_wide_kernel(G, cin, cout, kernel, causal, size, resid, monk
         assert_close_bf16(dx, xr.grad, 'wide triple dgrad')
 
 
+K32_CASES = [
+    # cin, cout, kernel, causal, size, residual epilogue
+    (128, 128, (3, 3, 3), False, (2, 4, 16, 32), False),      # 16 row tiles, 4 sub-steps per (dt, dh)
+    (128, 128, (3, 3, 3), True, (1, 3, 64, 64), True),        # W = 64: 4 image rows per tile; causal taps dt = -2..0; residual epilogue
+    (64, 96, (3, 3, 3), False, (1, 2, 16, 16), False),        # one channel block, 96 columns (partial column tile)
+    (192, 128, (3, 1, 3), True, (3, 3, 4, 16), False),        # M = 576: last tile partial; kh = 1
+    (256, 64, (3, 3, 3), False, (2, 2, 8, 64), True),         # 8 sub-steps per (dt, dh), 64 columns
+    (64, 128, (1, 3, 3), False, (5, 1, 16, 16), False),       # one frame per clip: every dt tap is zero padding of a clip border
+]
+
+
+@pytest.mark.parametrize('cin,cout,kernel,causal,size,resid', K32_CASES)
+def test_conv_triple_k32_kernel(G, cin, cout, kernel, causal, size, resid, monkeypatch):
+    """igemm3h_kernel (256 x 128 tile, 32-channel K-tiles, two blocks per CU, buffer-addressed staging: the Cout <= 128 layers): forward
+    (with and without the residual epilogue) and backward-data against the oracle; the library must report variant 15."""
+    monkeypatch.setattr(G.conv, 'TRI_BM', 256)
+    monkeypatch.setattr(G.conv, 'TRI_FLAGS', 2048)
+    torch.manual_seed(29)
+    n, t, h, w = size
+    x = bf16_round(torch.randn(n, cin, t, h, w))
+    wt = bf16_round(torch.randn(cout, cin, *kernel) / (cin * kernel[0] * kernel[1] * kernel[2]) ** 0.5)
+    b = torch.randn(cout)
+    xr = x.clone().requires_grad_(True)
+    if causal:
+        from oracle import genie_oracle as O
+        ref = O.causal_conv3d(xr, wt, b, stride=(1, 1, 1))
+        spec = G.conv.causal_spec(cin, cout, kernel)
+    else:
+        ref = F.conv3d(xr, wt, b, padding=tuple((k - 1) // 2 for k in kernel))
+        spec = G.conv.same_spec(cin, cout, kernel)
+    dy = bf16_round(torch.randn_like(ref))
+    ref.backward(dy)
+    wd = wt.cuda()
+    lib = G.hip.load_library()
+    r = bf16_round(torch.randn_like(ref)) if resid else None
+    out = G.conv.conv_forward(G.cl.to_cl(x.cuda()), G.conv.pack_weight_fwd(wd, spec), b.cuda(), spec, resid=None if r is None else G.cl.to_cl(r.cuda()))
+    assert lib.genie_last_conv_variant() == 15, lib.genie_last_conv_variant()
+    assert_close_bf16(out, ref.detach() + (r if resid else 0), 'k32 triple fwd')
+    if cin <= 128 and cout % 64 == 0:                         # backward-data = the same kernel over dy with cin (<= 128) output columns
+        dx = G.conv.conv_dgrad(G.cl.to_cl(dy.cuda()), G.conv.pack_weight_bwd(wd, spec), spec, (t, h, w))
+        assert lib.genie_last_conv_variant() == 15, lib.genie_last_conv_variant()
+        assert_close_bf16(dx, xr.grad, 'k32 triple dgrad')
+
+
 @pytest.mark.parametrize('cout,causal,size', [(3, True, (2, 5, 10, 64)), (3, False, (1, 3, 7, 32)), (2, True, (1, 2, 4, 128)), (1, True, (2, 4, 9, 64)),
                                                (3, True, (8, 16, 64, 64)), (3, True, (1, 16, 64, 64)), (3, True, (32, 3, 8, 32)), (3, True, (1, 1, 3, 96)), (3, False, (1, 9, 6, 32))])
 def test_conv_narrow_out_kernel(G, cout, causal, size):
