@@ -377,9 +377,16 @@ def main():
             pass
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline()
-    print(json.dumps(out))
     if world > 1 or dist.is_initialized():
         dist.destroy_process_group()
+    # RCCL prints its version banner through C stdio; when stdout is a file that buffer is flushed at exit, i.e. AFTER Python's prints:
+    # flush it now so that the JSON line is the LAST line of the output
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == '__main__':

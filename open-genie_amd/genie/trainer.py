@@ -383,6 +383,13 @@ class DataParallel:
         offs = [(arena.offset_of(m, root), m) for m in candidates]
         offs = [(o, m) for o, m in offs if o is not None and 0 < o < arena.numel]
         picks, used = [], set()
+        if offs and nbuckets > 1:
+            # plus one cut right behind the FIRST layers: bucket 0 is the one finish() reduces after backward has ended -- the only
+            # all-reduce nothing hides -- so it should hold as little as possible (the stem and whatever is laid out before it), and
+            # the first equal-byte bucket then starts while backward still has the full-resolution encoder layers to go
+            o, m = min(offs, key=lambda om: om[0])
+            used.add(o)
+            picks.append((o, m))
         for k in range(1, nbuckets):
             target = arena.numel * k / nbuckets
             o, m = min(offs, key=lambda om: abs(om[0] - target), default=(None, None))
