@@ -12,5 +12,5 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- p
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o fetch -- python $ROOT/bench.py --steps 1 --warmup 1 --batch $BATCH --no-cpu-baseline --no-kernel-events > /dev/null 2> $OUT/fetch.log
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o write -- python $ROOT/bench.py --steps 1 --warmup 1 --batch $BATCH --no-cpu-baseline --no-kernel-events > /dev/null 2> $OUT/write.log
 cd $ROOT
-python scripts/summarize_profile.py $OUT $TAG
+python scripts/summarize_profile.py $OUT $TAG $BATCH
 ls -R $OUT | head -40

@@ -7,6 +7,7 @@ import sys
 from collections import defaultdict
 
 out, tag = sys.argv[1], sys.argv[2]
+batch = int(sys.argv[3]) if len(sys.argv) > 3 else None
 
 
 def find(sub, pattern):
@@ -81,6 +82,13 @@ if stats and os.path.exists(bur):
         summary['duration_agreement'] = {'error': repr(e)}
 summary.pop('FETCH_SIZE_all', None)
 summary.pop('WRITE_SIZE_all', None)
+# what the PMC figures belong to: bench.py attaches `traffic` to a run only when its kernel sources and batch are THESE (else `traffic_stale`)
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+try:
+    import bench
+    summary['meta'] = {'csrc_sha16': bench.csrc_sha16(), 'batch': batch, 'command': 'scripts/profile_bench.sh'}
+except Exception as e:
+    summary['meta'] = {'error': repr(e), 'batch': batch}
 
 with open(os.path.join(out, f'{tag}_summary.json'), 'w') as f:
     json.dump(summary, f, indent=1)
