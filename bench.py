@@ -141,7 +141,7 @@ def csrc_sha16() -> str:
     return h.hexdigest()[:16]
 
 
-def side_kernels():
+def side_kernels(batch: int = 64):
     """The other two quantities BASELINE.json's metric names, measured at kernel level with HIP events on resident synthetic inputs
     (a few ms in total): MFMA utilisation of the space-time attention kernels on the two long-sequence shapes of SURVEY.md 8a
     (a10), and HBM GB/s (algorithmic bytes) of the bandwidth-bound CausalConv3d / GroupNorm family."""
@@ -151,7 +151,8 @@ def side_kernels():
     import io
     with contextlib.redirect_stdout(io.StringIO()):
         mb.bench_attn(10, only=('lam spatial S=4096', 'yaml_tok spatial S=1024'))
-        mb.bench_hbm(10, quick=True)
+        mb.bench_hbm(10, quick=True)                     # B = 8: the round-1 / round-2 protocol (134 MB per tensor, partly cache-resident)
+        mb.bench_hbm(6, quick=True, B=batch)             # the step's own batch: 1.07 GB per 128-channel tensor at 64 clips, pure HBM streams
     att, hbm = {}, {}
     for r in mb.RESULTS:
         if r['section'] == 'attn' and 'attention' in r['name']:
@@ -355,7 +356,7 @@ def main():
         # why it scales (or does not): what backward hid of the gradient all-reduce and what it did not, bucket by bucket (rank 0's view)
         out['comm'] = comm
     if world == 1 and not args.no_kernel_events:
-        out.update(side_kernels())
+        out.update(side_kernels(B))
     # `traffic`: HBM bytes per launch of the dominant kernel from PMC counters.  Counters cannot be collected inside this run (rocprofv3
     # wraps the process), so the figure comes from the committed PMC passes of THIS command (scripts/profile_bench.sh ->
     # profiles/rNN_summary.json) -- and only if that profile was taken on the same kernel sources and batch; otherwise it is stale and

@@ -72,22 +72,44 @@ __global__ void __launch_bounds__(256, 2) conv_narrow_in_kernel(const NarrowInAr
     bf16x4_t ones;
     ones[0] = 0x3F80; ones[1] = 0x3F80; ones[2] = 0; ones[3] = 0;
 
+    // The input image of a tile (frames t + t_lo .. + 2, rows h0 - 1 .. h0 + 4, columns -1 .. W; 8 B per pixel) is REGISTER-staged one tile
+    // ahead: its loads are issued before the current tile's MFMAs / stores and written to LDS at the top of the next iteration.  (Round 2
+    // loaded it at the top of its own tile: every tile began with an exposed global round trip, ~40 % of a tile's time at 64 clips, which
+    // only the second co-resident workgroup covered -- 3.97 TB/s on the 1.1-GB output stream.)
+    constexpr int IMG_LD = (IMG_PIX + 255) / 256;
+    constexpr bool PREFETCH = W <= 64;                             // W = 128: 10 loads per thread would spill (weights hold 112 VGPRs); load at the top
+    u32x2_t ireg[IMG_LD];
+    auto load_image = [&](int tile) {
+        const int hb = tile % a.hblocks;
+        const int t = (tile / a.hblocks) % a.T;
+        const int n = tile / (a.hblocks * a.T);
+        const int h0 = hb * NIN_HB;
+#pragma unroll
+        for (int k = 0; k < IMG_LD; ++k) {
+            const int i = k * 256 + tid;
+            const int c = i % WP, r = (i / WP) % ROWS, f = i / (WP * ROWS);
+            const int tt = t + a.t_lo + f, hh = h0 - 1 + r, ww = c - 1;
+            u32x2_t v = {0u, 0u};
+            if (i < IMG_PIX && (unsigned)tt < (unsigned)a.T && (unsigned)hh < (unsigned)a.H && (unsigned)ww < (unsigned)W)
+                v = *reinterpret_cast<const u32x2_t*>(a.src + ((((long long)n * a.T + tt) * a.H + hh) * W + ww) * a.cs);
+            ireg[k] = v;
+        }
+    };
+    if (PREFETCH && (int)blockIdx.x < a.ntiles) load_image(blockIdx.x);
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
         const int hb = tile % a.hblocks;
         const int t = (tile / a.hblocks) % a.T;
         const int n = tile / (a.hblocks * a.T);
         const int h0 = hb * NIN_HB;
         __syncthreads();                                           // the previous tile's image is no longer read
-        // ---- stage the input image: frames t + t_lo .. + 2, rows h0 - 1 .. h0 + 4, columns -1 .. W ----
-        for (int i = tid; i < IMG_PIX; i += 256) {
-            const int c = i % WP, r = (i / WP) % ROWS, f = i / (WP * ROWS);
-            const int tt = t + a.t_lo + f, hh = h0 - 1 + r, ww = c - 1;
-            u32x2_t v = {0u, 0u};
-            if ((unsigned)tt < (unsigned)a.T && (unsigned)hh < (unsigned)a.H && (unsigned)ww < (unsigned)W)
-                v = *reinterpret_cast<const u32x2_t*>(a.src + ((((long long)n * a.T + tt) * a.H + hh) * W + ww) * a.cs);
-            *reinterpret_cast<u32x2_t*>(img + i * 8) = v;
+        if (!PREFETCH) load_image(tile);
+#pragma unroll
+        for (int k = 0; k < IMG_LD; ++k) {
+            const int i = k * 256 + tid;
+            if (i < IMG_PIX) *reinterpret_cast<u32x2_t*>(img + i * 8) = ireg[k];
         }
         __syncthreads();
+        if (PREFETCH && tile + (int)gridDim.x < a.ntiles) load_image(tile + gridDim.x);      // in flight under this tile's MFMAs and stores
         const int h = h0 + wave;
         if (h >= a.H) continue;                                    // wave-uniform (partial last row block); barriers are at the loop top
         char* const st = stage + wave * 32 * NIN_OPITCH;

@@ -137,10 +137,12 @@ def bench_attn(iters, only=None):
 
 
 # ------------------------------------------------------------------------------------------------
-def bench_hbm(iters, quick=False):
+def bench_hbm(iters, quick=False, B=None):
+    """B: clips per call (default MB_BATCH or 8).  8 clips = 134 MB per 128-channel tensor -- half of it fits the 256-MB last-level cache,
+    which flatters write streams and penalises launches with a fixed tail; bench.py reports B = 8 AND its own batch (64 clips, 1.07 GB)."""
     lib = _hip.load_library()
     P = _hip.ptr
-    B = 8
+    B = int(B if B is not None else os.environ.get('MB_BATCH', 8))
     for (c, t, h, w, g) in ([(128, 16, 64, 64, 1)] if quick else [(128, 16, 64, 64, 1), (256, 16, 32, 32, 1), (512, 4, 8, 8, 1), (128, 16, 64, 64, 8)]):
         x = rand_cl(B, c, t, h, w)
         gamma = torch.ones(c, device='cuda', requires_grad=True); beta = torch.zeros(c, device='cuda', requires_grad=True)
