@@ -71,14 +71,15 @@ def test_genie_compute_loss_matches_its_parts_and_oracle():
     e_ref = O.tokenizer_encode(x, sd_tok, TOK_ENC)
     _, idx_ref_tok = O.tokenizer_tokenize(x, sd_tok, TOK_ENC, 6)
     z_ref = torch.nn.functional.linear(e_ref.movedim(1, -1), sd_tok['quant.proj_inp.weight'], sd_tok['quant.proj_inp.bias'])    # the 6 pre-sign values per token
-    safe = (z_ref.abs() >= 3e-2 * z_ref.pow(2).mean().sqrt()).all(-1)                   # (B, t, h, w): every bit decided by a margin
+    safe = (z_ref.abs() >= 6e-2 * z_ref.pow(2).mean().sqrt()).all(-1)                   # (B, t, h, w): every bit decided by a margin (6 % of the RMS: ~4x the
+    #                                                                                     # bf16-vs-fp32 error of the encoder output)
     assert safe.float().mean() > 0.5, safe.float().mean()
     assert torch.equal(tokens[safe], idx_ref_tok.reshape(tokens.shape)[safe])
     # (b) the action ids LatentAction hands to the dynamics model, same rule
     tr = {}
     with torch.no_grad():
         O.latent_action_forward(x, sd_lam, LAM_ENC, LAM_DEC, 4, training=True, trace=tr)
-    safe_a = (tr['act'].abs() >= 3e-2 * tr['act'].pow(2).mean().sqrt()).all(-1)
+    safe_a = (tr['act'].abs() >= 6e-2 * tr['act'].pow(2).mean().sqrt()).all(-1)
     assert torch.equal(act_hip.cpu().reshape(safe_a.shape)[safe_a], idx_ref.reshape(safe_a.shape)[safe_a])
     # (c) the dynamics logits on the shared token grid and actions, and the gradients of compute_loss's MaskGIT term
     acts = act_hip.cpu().reshape(2, 8)[:, 1::2]
