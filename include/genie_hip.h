@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GENIE_ABI_VERSION 8
+#define GENIE_ABI_VERSION 9
 
 #define GENIE_F32 0
 #define GENIE_BF16 1
@@ -76,7 +76,9 @@ typedef struct GenieTap {
 typedef struct GenieTriStep {
     int32_t a_delta, dt, dh;
     int32_t wofs0, wofs1, wofs2;
-    int32_t pad0, pad1;
+    int32_t rows_per_dt; /* > 0: the table is sorted by dt and every dt value owns this many CONSECUTIVE rows -- a row tile that lies   */
+    int32_t dt_min;      /* inside one frame t then runs only the rows with 0 <= t + dt < T (the others multiply the zero padding);   */
+                         /* dt of row i = dt_min + i / rows_per_dt.  0: no such structure, every row is executed (ABI <= 8 tables)    */
 } GenieTriStep;
 
 typedef struct GenieConvDesc {

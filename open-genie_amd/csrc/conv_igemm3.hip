@@ -49,6 +49,26 @@ __device__ __forceinline__ int tf_remap(int i, int T, int F) {
     return (n * T + t) * F + hb;
 }
 
+// Zero-frame skipping.  With the step table sorted by dt (GenieTriStep.rows_per_dt > 0) a row tile that lies inside ONE frame t needs only
+// the rows whose source frame t + dt exists; the others would stage zeros and multiply them (time padding: 2 of 3 x 16 (frame, dt) pairs of a
+// 16-frame 'same' conv, 3 of a causal one; 1 / 6 at 4 frames).  Trims [steps, steps + nsteps) to that range.
+__device__ __forceinline__ void tri_trim_range(const GenieTriStep* __restrict__ steps, int nsteps, int m0, int bm, long long M, int H, int W, int T,
+                                               int& first, int& count) {
+    const int rpd = __builtin_amdgcn_readfirstlane(steps[0].rows_per_dt), dmin = __builtin_amdgcn_readfirstlane(steps[0].dt_min);
+    const unsigned hw = (unsigned)(H * W);
+    const unsigned last = (long long)m0 + bm - 1 < M ? (unsigned)(m0 + bm - 1) : (unsigned)(M - 1);
+    const unsigned f0 = (unsigned)m0 / hw, f1 = last / hw;
+    const int t = (int)(f0 % (unsigned)T), ndt = rpd > 0 ? nsteps / rpd : 0;
+    int lo = -t - dmin, hi = T - t - dmin;             // dt index range [lo, hi) with 0 <= t + dt < T
+    lo = lo < 0 ? 0 : lo;
+    hi = hi > ndt ? ndt : hi;
+    const bool trim = rpd > 0 && f0 == f1 && hi > lo;
+    // block-uniform by construction; readfirstlane keeps the table pointer in SGPRs (its reads must stay scalar loads: the kernels count
+    // their vector-memory operations)
+    first = __builtin_amdgcn_readfirstlane(trim ? lo * rpd : 0);
+    count = __builtin_amdgcn_readfirstlane(trim ? (hi - lo) * rpd : nsteps);
+}
+
 template <int BM, bool PIPE>
 __global__ void __launch_bounds__(BM * 2) igemm3_kernel(const Igemm3Args p, const GenieTriStep* __restrict__ steps) {
     // `steps` is a separate __restrict__ argument so that the (wave-uniform) table reads become scalar loads
@@ -81,6 +101,11 @@ __global__ void __launch_bounds__(BM * 2) igemm3_kernel(const Igemm3Args p, cons
         tile_m = id / a.tiles_n;
     }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
+    if (a.split_k <= 1) {
+        int first;
+        tri_trim_range(steps, nsteps, m0, BM, a.M, H, W, T, first, nsteps);
+        steps += first;
+    }
     const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page3);
 
     // ---- per-thread staging state: the image rows this lane fills (one per round) ----
@@ -325,6 +350,11 @@ __device__ __forceinline__ void igemm3d_body(const Igemm3Args& p, const GenieTri
         tile_m = tf_remap(id / a.tiles_n, p.tf_T, p.tf_F);
     }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
+    if (!SPLITK) {
+        int first;
+        tri_trim_range(steps, nsteps, m0, BM, a.M, H, W, T, first, nsteps);
+        steps += first;
+    }
     const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page3);
 
     // Image staging as in igemm3w_kernel: only the 256 real pixels are DMA'd (pixel q of image row hl = q / W -> LDS row
@@ -614,7 +644,12 @@ int genie_igemm_splitk_finish(const IgemmArgs& a, hipStream_t s);      // conv_i
 //   complete in group 6i+3, published at barrier 6i+4, pre-read in 6i+5.  WAR: slot (k+3)&3 was last read in half-tile k-1; the
 //   spare image was last read in half-tile 6i-1.
 // ------------------------------------------------------------------------------------------------------------------------------
-template <bool SPLITK, bool LEAN = false>
+// VAR (LEAN only): 0 = production; 2 / 3 / 4 = timing ablations with WRONG results (no DMA in the loop / no MFMA / DMA + barriers only;
+// GENIE_TRI_VAR, profiles/r03_igemm3w_ablation.log).  Two schedule changes were measured on top of VAR 0 and dropped:
+// waves 4..7 issuing their DMA group at the start of the half-tile (-0.7 %), and the fragment reads in first-use order interleaved with the
+// MFMAs by sched_group_barrier instead of the compiler's order, which sinks the pre-read of the next half-tile to just in front of the
+// barrier (+-0): the kernel runs at the chip's POWER cap, not at an issue limit.
+template <bool SPLITK, bool LEAN = false, int VAR = 0>
 __global__ void __launch_bounds__(512) igemm3w_kernel(const Igemm3Args p, const GenieTriStep* __restrict__ steps) {
     constexpr int BM = 256, BN = 256, NWAVE = 8, WN = 2, TM = 2, TN = 4;
     constexpr int RPR = 64, A_ROUNDS = 4;                                    // DMA rounds per image: the 256 REAL pixels (zero columns: below)
@@ -639,6 +674,11 @@ __global__ void __launch_bounds__(512) igemm3w_kernel(const Igemm3Args p, const 
         tile_m = tf_remap(id / a.tiles_n, p.tf_T, p.tf_F);
     }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
+    if (!SPLITK) {
+        int first;
+        tri_trim_range(steps, nsteps, m0, BM, a.M, H, W, T, first, nsteps);
+        steps += first;
+    }
     const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page3);
 
     // Image staging: only the 256 real pixels of the tile are DMA'd (4 rounds of 64 rows); pixel q of image row hl = q / W lands in LDS
@@ -763,6 +803,14 @@ __global__ void __launch_bounds__(512) igemm3w_kernel(const Igemm3Args p, const 
         for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const bf16x8_t*>(bbuf + b_off[ksb][j]);
     };
     auto mfma8 = [&](const bf16x8_t (&fa)[TM], const bf16x8_t (&fb)[TN]) {
+        if constexpr (VAR == 4) return;
+        if constexpr (VAR == 3) {                                            // ablation: the fragments stay live, no matrix work
+#pragma unroll
+            for (int i = 0; i < TM; ++i) asm volatile("" :: "v"(fa[i]));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) asm volatile("" :: "v"(fb[j]));
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -772,7 +820,6 @@ __global__ void __launch_bounds__(512) igemm3w_kernel(const Igemm3Args p, const 
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     };
-
     // ---- prologue: image 0, weight half-tiles 0, 1, 2 ----
     {
         const GenieTriStep e = steps[0];
@@ -801,12 +848,14 @@ __global__ void __launch_bounds__(512) igemm3w_kernel(const Igemm3Args p, const 
             const char* bcur = B0 + ((k + R) & 3) * B_BYTES;                                                     \
             const char* bnext = B0 + ((k + R + 1) & 3) * B_BYTES;                                                \
             bf16x8_t fa1[TM], fb1[TN];                                                                           \
-            read_frag(acur, S, 2 * HH + 1, bcur, 1, fa1, fb1);                                                   \
+            if constexpr (VAR < 4) read_frag(acur, S, 2 * HH + 1, bcur, 1, fa1, fb1);                            \
             mfma8(fa0, fb0);                                                                                     \
             __builtin_amdgcn_sched_barrier(0);                                                                   \
-            ISSUE                                                                                                \
+            if constexpr (VAR != 2) {                                                                            \
+                ISSUE                                                                                            \
+            }                                                                                                    \
             __builtin_amdgcn_sched_barrier(0);                                                                   \
-            read_frag(NEXT_A, NEXT_S, NEXT_KS, bnext, 0, fa0, fb0);                                              \
+            if constexpr (VAR < 4) read_frag(NEXT_A, NEXT_S, NEXT_KS, bnext, 0, fa0, fb0);                       \
             mfma8(fa1, fb1);                                                                                     \
             __builtin_amdgcn_sched_barrier(0);                                                                   \
             asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WAITN) : "memory");                                        \
@@ -867,7 +916,7 @@ __global__ void __launch_bounds__(512, 4) igemm3h_kernel(const Igemm3Args p, con
     constexpr int A_BYTES = 320 * 64, B_BYTES = BN * 64;                     // <= 320 image rows (W = 16: 16 x 18 = 288), 8-KB weight tiles
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const IgemmArgs& a = p.g;
-    const int nsub = 2 * p.nsteps;                                           // 32-channel sub-steps
+    int nsteps_h = p.nsteps;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
@@ -875,6 +924,12 @@ __global__ void __launch_bounds__(512, 4) igemm3h_kernel(const Igemm3Args p, con
     const int id = xcd_tile_id(a.tiles_m * a.tiles_n, blockIdx.x);
     const int tile_n = id % a.tiles_n, tile_m = id / a.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
+    {
+        int first;
+        tri_trim_range(steps, nsteps_h, m0, BM, a.M, H, W, T, first, nsteps_h);
+        steps += first;
+    }
+    const int nsub = 2 * nsteps_h;                                           // 32-channel sub-steps
     const int row0_id = m0 / W;
 
     // ---- staging state ----
@@ -1045,16 +1100,26 @@ template <bool SPLITK>
 static int launch_igemm3w(const Igemm3Args& p, const GenieTriStep* steps, hipStream_t s) {
     constexpr int lds = 2 * (5 * 64 * 128) + 4 * 256 * 64;
     if (!SPLITK && ig3_lean_ok(p)) {                           // buffer-addressed LDS-DMA form
+        static const int var = getenv("GENIE_TRI_VAR") ? atoi(getenv("GENIE_TRI_VAR")) : 0;   // 2..4: timing ablations
         static bool lconf = false;
+        const void* fn = var == 2 ? (const void*)igemm3w_kernel<false, true, 2>
+                       : var == 3 ? (const void*)igemm3w_kernel<false, true, 3> : var == 4 ? (const void*)igemm3w_kernel<false, true, 4>
+                       : (const void*)igemm3w_kernel<false, true, 0>;
         if (!lconf) {
-            hipError_t e = hipFuncSetAttribute((const void*)igemm3w_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             if (e != hipSuccess) {
                 genie_set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e));
                 return GENIE_ERR_HIP;
             }
             lconf = true;
         }
-        hipLaunchKernelGGL((igemm3w_kernel<false, true>), dim3(p.g.tiles_m * p.g.tiles_n, 1), dim3(512), lds, s, p, steps);
+        const dim3 grid(p.g.tiles_m * p.g.tiles_n, 1);
+        switch (var) {
+            case 2: hipLaunchKernelGGL((igemm3w_kernel<false, true, 2>), grid, dim3(512), lds, s, p, steps); break;
+            case 3: hipLaunchKernelGGL((igemm3w_kernel<false, true, 3>), grid, dim3(512), lds, s, p, steps); break;
+            case 4: hipLaunchKernelGGL((igemm3w_kernel<false, true, 4>), grid, dim3(512), lds, s, p, steps); break;
+            default: hipLaunchKernelGGL((igemm3w_kernel<false, true, 0>), grid, dim3(512), lds, s, p, steps); break;
+        }
         GENIE_CHECK_LAUNCH();
         return GENIE_OK;
     }

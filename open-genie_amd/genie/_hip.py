@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('GENIE_HIP_LIB', os.path.join(os.path.dirname(_HERE), 'lib', 'libgenie_hip.so'))
 
 GENIE_F32, GENIE_BF16 = 0, 1
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class GenieTap(C.Structure):

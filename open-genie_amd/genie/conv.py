@@ -167,6 +167,9 @@ def set_deterministic(on: bool) -> bool:
     return old
 
 
+TRI_TRIM = os.environ.get('GENIE_TRI_TRIM', '1') not in ('0', '')       # A/B switch: 0 = padding frames are staged and multiplied like any other
+
+
 def tri_rows(taps, hs: int, ws: int, cs: int):
     """Pure host logic of the kw-triple schedule: group a tap list [(dt, dh, dw, wofs, c0, nch)] into one row per
     (dt, dh, 64-channel block): [a_delta, dt, dh, wofs(dw=-1), wofs(dw=0), wofs(dw=+1), 0, 0] (struct GenieTriStep), or None when
@@ -182,6 +185,14 @@ def tri_rows(taps, hs: int, ws: int, cs: int):
             return None
         for cb in range(nch // 64):
             rows.append([((dt * hs + dh) * ws) * cs + c0 + cb * 64, dt, dh, by_dw[-1] + cb * 64, by_dw[0] + cb * 64, by_dw[1] + cb * 64, 0, 0])
+    # rows sorted by dt, every dt owning the same number of consecutive rows: a row tile inside frame t can then skip the rows whose
+    # frame t + dt is padding (GenieTriStep.rows_per_dt / dt_min; 2 of 48 (frame, dt) pairs of a 16-frame 'same' conv, 3 of a causal one)
+    rows.sort(key=lambda r: r[1])
+    dts = [r[1] for r in rows]
+    lo, n = dts[0], dts.count(dts[0])
+    if TRI_TRIM and all(dts[i] == lo + i // n for i in range(len(rows))):
+        for r in rows:
+            r[6], r[7] = n, lo
     return rows
 
 

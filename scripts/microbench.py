@@ -70,7 +70,10 @@ def report(section, name, ms, flops=None, bytes_=None, min_bytes=None, **extra):
 
 def rand_cl(n, c, t, h, w, scale=1.0):
     x = empty_cl(n, c, t, h, w, 'cuda')
-    x.copy_(torch.randn(n, c, t, h, w, device='cuda') * scale)
+    if os.environ.get('MB_ZERO', '') == '1':              # all-zero operands: the same instruction stream at a fraction of the switching
+        x.zero_()                                         # power -- how far the DVFS power cap (not the schedule) holds a kernel back
+    else:
+        x.copy_(torch.randn(n, c, t, h, w, device='cuda') * scale)
     return x
 
 
@@ -225,7 +228,7 @@ def bench_conv(iters):
             continue
         t, h, w = size
         x = rand_cl(B, spec.cin, t, h, w)
-        wt = (torch.randn(spec.cout, spec.cin, *spec.kernel, device='cuda') * 0.05).contiguous(memory_format=torch.channels_last_3d)
+        wt = (torch.randn(spec.cout, spec.cin, *spec.kernel, device='cuda') * (0.0 if os.environ.get('MB_ZERO', '') == '1' else 0.05)).contiguous(memory_format=torch.channels_last_3d)
         wf, wb = pack_weight_fwd(wt, spec), pack_weight_bwd(wt, spec)
         y = conv_forward(x, wf, None, spec)
         dy = y                                   # any CL tensor of the output's shape serves as the gradient
