@@ -345,6 +345,11 @@ int genie_adamw_step(float* p, float* g, float* m, float* v, int64_t numel, floa
  * with in_channels % 8 == 0 that image IS the forward weight pack, so no per-step repacking is needed */
 int genie_adamw_step_mirror(float* p, float* g, float* m, float* v, void* p_bf16, int64_t numel, float lr, float beta1, float beta2,
                             float eps, float weight_decay, int step, float grad_scale, int zero_grad, void* stream);
+/* capture-safe form (hipGraph replay): nothing that changes from step to step is a launch argument.  `state` = 6 device floats:
+ * [0] the step count so far (int32 bits; incremented by the call), [1] learning rate, [2] weight decay (both written by the host, e.g. a
+ * scheduler, between replays), [3..5] scratch for the step's coefficients.  p_bf16 may be NULL (no mirror). */
+int genie_adamw_step_graph(float* p, float* g, float* m, float* v, void* p_bf16, int64_t numel, float* state, float beta1, float beta2,
+                           float eps, float grad_scale, int zero_grad, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Space-time transformer attention (attention.hip).

@@ -364,12 +364,15 @@ extern "C" int genie_mse_bwd(const void* rec, int cpitch, const void* target, in
 // One pass: reads p, g, m, v; writes p, m, v (+ optionally zeroes g: the wgrad kernels accumulate
 // into g with atomics, so "consume and clear" saves a separate memset pass over 1.5 GB).
 // ------------------------------------------------------------------------------------------------
+// `dev` != nullptr (genie_adamw_step_graph): step size, decay and the second-moment correction come from device memory ({lr / bc1,
+// 1 - lr * wd, 1 / sqrt(bc2)}, written by adamw_advance_kernel just before), so a captured launch stays valid from one replay to the next.
 __global__ void __launch_bounds__(256) adamw_kernel(float4* __restrict__ p, float4* __restrict__ g, float4* __restrict__ m,
                                                     float4* __restrict__ v, long long n4, float lr, float beta1, float beta2,
                                                     float eps, float wd, float bc1, float rsqrt_bc2, float gscale,
-                                                    int zero_grad, u32x2_t* __restrict__ mirror) {
-    const float step = lr / bc1;
-    const float decay = 1.f - lr * wd;
+                                                    int zero_grad, u32x2_t* __restrict__ mirror, const float* __restrict__ dev) {
+    const float step = dev ? dev[0] : lr / bc1;
+    const float decay = dev ? dev[1] : 1.f - lr * wd;
+    if (dev) rsqrt_bc2 = dev[2];
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
         float4 pp = p[i], gg = g[i], mm = m[i], vv = v[i];
         float* P = &pp.x; float* G = &gg.x; float* M = &mm.x; float* V = &vv.x;
@@ -401,7 +404,31 @@ static int adamw_launch(float* p, float* g, float* m, float* v, int64_t numel, f
     if (numel == 0) return GENIE_OK;
     const double bc1 = 1.0 - pow((double)beta1, (double)step);
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
-    adamw_kernel<<<ew_grid(numel / 4), 256, 0, (hipStream_t)stream>>>((float4*)p, (float4*)g, (float4*)m, (float4*)v, numel / 4, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)(1.0 / sqrt(bc2)), grad_scale, zero_grad, (u32x2_t*)mirror);
+    adamw_kernel<<<ew_grid(numel / 4), 256, 0, (hipStream_t)stream>>>((float4*)p, (float4*)g, (float4*)m, (float4*)v, numel / 4, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)(1.0 / sqrt(bc2)), grad_scale, zero_grad, (u32x2_t*)mirror, nullptr);
+    GENIE_CHECK_LAUNCH();
+    return GENIE_OK;
+}
+
+// state: [0] step count (int32 bits), [1] lr, [2] weight decay (host-written), [3..5] {lr / bc1, 1 - lr * wd, 1 / sqrt(bc2)} of the step
+__global__ void adamw_advance_kernel(float* __restrict__ state, float beta1, float beta2) {
+    int* cnt = reinterpret_cast<int*>(state);
+    const int step = *cnt + 1;
+    *cnt = step;
+    const float lr = state[1], wd = state[2];
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    state[3] = (float)((double)lr / bc1);
+    state[4] = 1.f - lr * wd;
+    state[5] = (float)(1.0 / sqrt(bc2));
+}
+
+extern "C" int genie_adamw_step_graph(float* p, float* g, float* m, float* v, void* p_bf16, int64_t numel, float* state, float beta1,
+                                      float beta2, float eps, float grad_scale, int zero_grad, void* stream) {
+    GENIE_CHECK_ARG(p && g && m && v && state, "genie_adamw_step_graph: null pointer");
+    GENIE_CHECK_ARG(numel % 4 == 0, "genie_adamw_step_graph: arena numel %lld must be a multiple of 4", (long long)numel);
+    if (numel == 0) return GENIE_OK;
+    adamw_advance_kernel<<<1, 1, 0, (hipStream_t)stream>>>(state, beta1, beta2);
+    GENIE_CHECK_LAUNCH();
+    adamw_kernel<<<ew_grid(numel / 4), 256, 0, (hipStream_t)stream>>>((float4*)p, (float4*)g, (float4*)m, (float4*)v, numel / 4, 0.f, beta1, beta2, eps, 0.f, 1.f, 1.f, grad_scale, zero_grad, (u32x2_t*)p_bf16, state + 3);
     GENIE_CHECK_LAUNCH();
     return GENIE_OK;
 }

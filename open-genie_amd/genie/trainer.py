@@ -97,6 +97,7 @@ class ParamArena:
         self.step_count = 0
         self.mirror: Optional[Tensor] = None          # bf16 image of `params`, kept current by the optimiser kernel
         self._packs = None
+        self._opt_state: Optional[Tensor] = None      # device-side {step, lr, weight decay, coefficients} of the capture-safe AdamW
 
     # ------------------------------------------------------------------------------------------------------------------
     # bf16 weight packs without per-step repacking
@@ -172,14 +173,42 @@ class ParamArena:
         GF.join_wgrad()
         self.grads.zero_()
 
+    def set_graph_hyperparameters(self, lr: float, weight_decay: float) -> None:
+        """Device-side learning rate / weight decay / step count of ``adamw_step(graph_safe=True)``: what a scheduler writes between
+        replays of a captured step (plain tensor writes -- no re-capture)."""
+        if self._opt_state is None:
+            self._opt_state = torch.zeros(8, dtype=torch.float32, device=self.params.device)
+        self._opt_state[:1].view(torch.int32).fill_(int(self.step_count))
+        self._opt_state[1:3].copy_(torch.tensor([float(lr), float(weight_decay)], dtype=torch.float32))
+
+    def mark_updated(self) -> None:
+        """Host bookkeeping after the arena was updated by kernels Python did not launch (a graph replay): bump the parameters'
+        version counters (on-demand weight packs rebuild on their next eager use) and re-key the packs the optimiser kernels keep
+        current themselves."""
+        torch.autograd.graph.increment_version(self._plist)
+        if self._packs is not None:
+            for op, w, fwd, bwdv in self._packs['managed']:
+                key = (w._version, w.data_ptr())
+                op._fwd = (key, fwd)
+                op._bwd = (key, bwdv)
+
     def adamw_step(self, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2,
-                   grad_scale: float = 1.0, zero_grad: bool = True) -> None:
-        """torch.optim.AdamW semantics (the reference's optimiser, tokenizer.py:437-442) in ONE kernel over the arena."""
+                   grad_scale: float = 1.0, zero_grad: bool = True, graph_safe: bool = False) -> None:
+        """torch.optim.AdamW semantics (the reference's optimiser, tokenizer.py:437-442) in ONE kernel over the arena.
+        ``graph_safe``: step count, learning rate and weight decay live in device memory (``set_graph_hyperparameters``; `lr` /
+        `weight_decay` here are ignored) so that the launch can be captured in a hipGraph and replayed (genie/graph.py)."""
         self.step_count += 1
         lib = _hip.load_library()
         from . import functional as GF
         GF.join_wgrad()                                   # weight-gradient kernels issued on the side stream (functional.ASYNC_WGRAD)
-        if self.mirror is not None:
+        if graph_safe:
+            if self._opt_state is None:
+                raise RuntimeError('adamw_step(graph_safe=True): call set_graph_hyperparameters(lr, weight_decay) first')
+            _hip.check(lib.genie_adamw_step_graph(self.params.data_ptr(), self.grads.data_ptr(), self.exp_avg.data_ptr(),
+                                                  self.exp_avg_sq.data_ptr(), _hip.ptr(self.mirror), self.numel, self._opt_state.data_ptr(),
+                                                  betas[0], betas[1], eps, grad_scale, 1 if zero_grad else 0, _hip.stream_ptr()),
+                       'genie_adamw_step_graph')
+        elif self.mirror is not None:
             _hip.check(lib.genie_adamw_step_mirror(self.params.data_ptr(), self.grads.data_ptr(), self.exp_avg.data_ptr(),
                                                    self.exp_avg_sq.data_ptr(), self.mirror.data_ptr(), self.numel, lr, betas[0], betas[1],
                                                    eps, weight_decay, self.step_count, grad_scale, 1 if zero_grad else 0,

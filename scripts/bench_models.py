@@ -7,7 +7,8 @@ resident in HBM.  Each line also carries
   roofline     -- the variant with the largest share of the step, priced against the dense bf16 MFMA peak like bench.py's
   cpu_baseline -- (`--cpu-baseline`, configs[2] / [3]) the oracle doing the same training step on the host cores, ONE step after one warm-up
 
-  python scripts/bench_models.py [lam] [dyn] [repr] [genie4] [--cpu-baseline]
+  python scripts/bench_models.py [lam] [dyn] [repr] [genie4] [smallbatch] [--cpu-baseline]
+(`smallbatch`: the tokenizer step at 4 / 8 clips and the LatentAction step, eager launches vs one hipGraph replay)
 The per-kernel rocprofv3 tables of the same runs: scripts/profile_models.sh -> profiles/rNN_models_*_kernel_stats.csv."""
 import json
 import os
@@ -130,6 +131,52 @@ def main():
         res.append(run(f'Genie (configs[4]: frozen MAGVIT2 tokenizer + R-lam + dynamics, 32x128x128, B={B}) [frames/s]', gen,
                        lambda: gen.compute_loss(v)[0], B * 32, steps=3, warm=1))
         del gen, tokz
+    if 'smallbatch' in which:
+        # what an 8-GPU STRONG-scaling run sees per GPU: the MAGVIT2 tokenizer step at 4 / 8 clips and the LatentAction
+        # step, issued from Python launch by launch vs one replay of the captured hipGraph (genie/graph.py); `host_issue_ms` = how long
+        # Python needs to issue one eager step when nothing synchronises
+        from genie.graph import GraphedTrainStep
+
+        def eager_vs_graph(name, build, batch, units, loss_fn, steps=6):
+            out = {'model': name}
+            model = build()
+            arena = ParamArena(model); arena.attach_weight_packs(model)
+            def estep():
+                o = loss_fn(model, batch); (o[0] if isinstance(o, (tuple, list)) else o).backward(); arena.adamw_step()
+            for _ in range(3): estep()
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(steps): estep()
+            t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+            out['eager'] = {'ms_per_step': round((t2 - t0) / steps * 1e3, 2), 'host_issue_ms': round((t1 - t0) / steps * 1e3, 2)}
+            del arena, model
+            torch.cuda.empty_cache()
+            model = build()
+            arena = ParamArena(model); arena.attach_weight_packs(model)
+            gs = GraphedTrainStep(model, arena, batch, loss_fn=loss_fn, warmup=2)
+            for _ in range(2): gs(batch)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(steps): gs(batch)
+            t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+            out['graph'] = {'ms_per_step': round((t2 - t0) / steps * 1e3, 2), 'host_issue_ms': round((t1 - t0) / steps * 1e3, 2),
+                            'loss': round(gs.loss.item(), 5)}
+            out['units_per_s'] = {'eager': round(units / out['eager']['ms_per_step'] * 1e3, 1), 'graph': round(units / out['graph']['ms_per_step'] * 1e3, 1)}
+            print(json.dumps(out), flush=True)
+            del gs, arena, model
+            torch.cuda.empty_cache()
+            return out
+
+        def build_tok():
+            torch.manual_seed(0)
+            return VideoTokenizer(MAGVIT2_ENC_DESC, MAGVIT2_DEC_DESC, d_codebook=18, gan_loss_weight=0., perc_loss_weight=0.).cuda().train()
+
+        def build_lam():
+            torch.manual_seed(0)
+            return LatentAction(LATENT_ACT_ENC, LATENT_ACT_DEC, d_codebook=8, inp_channels=3, inp_shape=(64, 64), n_embd=256).cuda().train()
+        for B in (4, 8):
+            v = torch.randn(B, 3, 16, 64, 64, device='cuda')
+            res.append(eager_vs_graph(f'VideoTokenizer MAGVIT2 (configs[1]) at {B} clips per GPU [frames/s]', build_tok, v, B * 16, lambda m, b: m(b)[0]))
+        v = torch.randn(2, 3, 16, 64, 64, device='cuda')
+        res.append(eager_vs_graph('LatentAction (configs[2]) B=2 [frames/s]', build_lam, v, 2 * 16, lambda m, b: m(b)[1]))
     os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
     tag = '_'.join(which)
     json.dump(res, open(os.path.join(ROOT, 'gpurun_out', f'bench_models_{tag}.json'), 'w'), indent=1)

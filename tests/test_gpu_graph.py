@@ -1,0 +1,110 @@
+"""A training step captured in a hipGraph (genie/graph.py): replays must do what the eager step does -- same losses, same parameters --
+with the step count and learning rate of AdamW living in device memory (genie_adamw_step_graph)."""
+import pytest
+import torch
+
+from util import ROOT, report  # noqa: F401  (puts the package on sys.path)
+from test_gpu_trainer import _model
+
+pytestmark = pytest.mark.gpu
+
+
+def _batches(n):
+    g = torch.Generator(device='cuda').manual_seed(7)
+    return [torch.randn(2, 3, 4, 16, 16, device='cuda', generator=g) for _ in range(n)]
+
+
+def test_graph_safe_adamw_equals_the_scalar_argument_form():
+    """genie_adamw_step_graph (coefficients computed on the device from a device-side step counter) == genie_adamw_step_mirror
+    (coefficients computed on the host) on IDENTICAL gradients, three steps.  (Through a model the comparison is meaningless: Adam's
+    first updates are lr * sign(g), so a 1-ulp difference in the step size flips the sign of the next step's near-zero gradients.)"""
+    from genie.trainer import ParamArena
+    gen = torch.Generator(device='cuda').manual_seed(3)
+    grads = None
+    params, mirrors = [], []
+    for graph_safe in (False, True):
+        m = _model()
+        arena = ParamArena(m)
+        arena.attach_weight_packs(m)
+        if grads is None:
+            grads = [torch.randn(arena.numel, device='cuda', generator=gen) * (10.0 ** -i) for i in range(3)]
+        if graph_safe:
+            arena.set_graph_hyperparameters(2e-3, 0.05)
+        for g in grads:
+            arena.grads.copy_(g)
+            arena.adamw_step(lr=2e-3, weight_decay=0.05, graph_safe=graph_safe)
+            assert arena.grads.abs().max().item() == 0.
+        params.append(arena.params.clone())
+        mirrors.append(arena.mirror.clone())
+        if graph_safe:
+            assert int(arena._opt_state[:1].view(torch.int32).item()) == 3 == arena.step_count
+    diff = (params[0] - params[1]).abs().max().item()
+    scale = params[0].abs().max().item()
+    report('graph_safe_adamw', max_abs_diff=diff, max_abs_param=scale)
+    assert diff <= 1e-6 * max(1.0, scale), diff          # the step size is rounded once on the host in one form, once on the device in the other
+    assert (mirrors[0].float() - mirrors[1].float()).abs().max().item() <= 2 ** -7 * scale
+
+
+def test_graphed_train_step_replays_the_eager_step():
+    """GraphedTrainStep (2 eager warm-up steps + 1 captured step on the example, then replays on new batches) against the eager loop
+    over the same batch sequence: loss of every replayed step and the final parameters."""
+    from genie import conv as gconv
+    from genie.graph import GraphedTrainStep
+    from genie.trainer import ParamArena
+    xs = _batches(4)
+    seq = [xs[0], xs[0], xs[0], xs[1], xs[2], xs[3], xs[1]]          # what the graphed run sees: 3 x example, then 4 replays
+    old = gconv.set_deterministic(True)                               # single-owner weight gradients: the two runs are comparable bit for bit
+    try:
+        m = _model()
+        arena = ParamArena(m)
+        arena.attach_weight_packs(m)
+        arena.set_graph_hyperparameters(1e-3, 0.01)
+        eager_losses = []
+        for x in seq:
+            loss, _ = m(x)
+            loss.backward()
+            arena.adamw_step(graph_safe=True)                          # the same kernel form as the captured step
+            eager_losses.append(loss.item())
+        eager_params = arena.params.clone()
+
+        m2 = _model()
+        arena2 = ParamArena(m2)
+        arena2.attach_weight_packs(m2)
+        gs = GraphedTrainStep(m2, arena2, xs[0], lr=1e-3, weight_decay=0.01, warmup=2)
+        assert gs.steps_done == 3 and arena2.step_count == 3
+        graph_losses = [gs.loss.item()]
+        for x in seq[3:]:
+            graph_losses.append(gs(x).item())
+        assert arena2.step_count == len(seq)
+        # eager use after replays sees current weights (on-demand packs rebuilt, managed packs re-keyed)
+        with torch.no_grad():
+            la, lb = m(xs[2])[0].item(), m2(xs[2])[0].item()
+    finally:
+        gconv.set_deterministic(old)
+    dl = max(abs(a - b) for a, b in zip(eager_losses[2:], graph_losses))
+    dp = (eager_params - arena2.params).abs().max().item()
+    rel = ((eager_params - arena2.params).norm() / eager_params.norm()).item()
+    report('graphed_train_step', max_loss_diff=dl, max_param_diff=dp, rel_l2_param_diff=rel, eval_loss_diff=abs(la - lb), losses=len(graph_losses))
+    # identical kernels in identical order on identical data: expected bit-identical; the bounds leave room for one atomic-order
+    # difference in a near-zero gradient (Adam turns that into an O(lr) step of that one element)
+    assert dl <= 1e-5 * max(1.0, abs(eager_losses[-1])), (eager_losses, graph_losses)
+    assert rel <= 1e-5 and dp <= 1e-2, (rel, dp)
+    assert abs(la - lb) <= 1e-4 * max(1.0, abs(la))
+
+
+def test_graphed_step_learning_rate_is_a_device_value():
+    """set_lr between replays changes the update without a re-capture: lr = 0 leaves the parameters untouched (weight decay 0)."""
+    from genie.graph import GraphedTrainStep
+    from genie.trainer import ParamArena
+    xs = _batches(2)
+    m = _model()
+    arena = ParamArena(m)
+    arena.attach_weight_packs(m)
+    gs = GraphedTrainStep(m, arena, xs[0], lr=1e-3, weight_decay=0.0, warmup=1)
+    before = arena.params.clone()
+    gs.set_lr(0.0)
+    gs(xs[1])
+    assert torch.equal(before, arena.params)
+    gs.set_lr(1e-3)
+    gs(xs[1])
+    assert not torch.equal(before, arena.params)
