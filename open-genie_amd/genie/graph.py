@@ -23,8 +23,9 @@ class GraphedTrainStep:
     def __init__(self, model: torch.nn.Module, arena: ParamArena, example: Tensor, loss_fn: Optional[Callable] = None, lr: float = 1e-3,
                  betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2, warmup: int = 2) -> None:
         """`example`: a batch of the shape every step will have (its values are used by the `warmup` eager steps and by the capture
-        step -- all of them REAL optimiser steps on `example`).  `loss_fn(model, batch)` returns the loss (or a tuple whose first element
-        is the loss); default ``model(batch)``."""
+        step -- all of them REAL optimiser steps on `example`; ``warmup=0`` when the caller has already trained eagerly for a step or
+        two, as ``Trainer.fit(graph=True)`` does).  `loss_fn(model, batch)` returns the loss (or a tuple whose first element is the
+        loss); default ``model(batch)``."""
         from . import functional as GF
         if not example.is_cuda:
             raise ValueError('GraphedTrainStep needs CUDA tensors (no CPU path)')
@@ -47,7 +48,7 @@ class GraphedTrainStep:
         side = torch.cuda.Stream(device=example.device)
         side.wait_stream(torch.cuda.current_stream(example.device))
         with torch.cuda.stream(side):                       # warm-up off the default stream, as graph capture wants it
-            for _ in range(max(1, warmup)):
+            for _ in range(max(0, warmup)):                 # 0: the caller has already run this step eagerly (tables, packs and scratch exist)
                 step()
                 self.steps_done += 1
         torch.cuda.current_stream(example.device).wait_stream(side)

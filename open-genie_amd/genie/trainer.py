@@ -15,6 +15,7 @@ module is the MI355X-first equivalent of that loop:
 """
 from __future__ import annotations
 
+import contextlib
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -469,7 +470,11 @@ class Trainer:
     per GPU is launched by ``torch.distributed.run``; arithmetic is bf16 with fp32 masters; ``save_last`` is always on)."""
 
     def __init__(self, max_epochs: int = 1, max_steps: int = -1, log_every_n_steps: int = 16, val_check_interval: int | None = None,
-                 limit_val_batches: int | None = None, default_root_dir: str = 'runs', grad_compress: Optional[str] = None, **ignored) -> None:
+                 limit_val_batches: int | None = None, default_root_dir: str = 'runs', grad_compress: Optional[str] = None,
+                 graph: bool = False, **ignored) -> None:
+        # graph: after two eager steps the training step (forward, backward, AdamW) is captured in a hipGraph and replayed per batch
+        # (genie/graph.py; single-GPU runs, batches of the captured shape -- anything else takes the eager path)
+        self.graph = bool(graph)
         self.max_epochs, self.max_steps = max_epochs, (max_steps if max_steps and max_steps > 0 else None)
         self.log_every_n_steps, self.val_check_interval, self.limit_val_batches = max(1, log_every_n_steps), val_check_interval, limit_val_batches
         self.default_root_dir, self.grad_compress, self.ignored = default_root_dir, grad_compress, dict(ignored)
@@ -568,6 +573,27 @@ class Trainer:
                 dp.install_overlap_hooks(arena, model, stages[1:])
         done = self.max_steps is not None and self.global_step >= self.max_steps
         epoch = start_epoch
+        use_graph = self.graph and not dp.active
+        gstep, eager_steps = None, 0
+        side = None
+        if use_graph:
+            arena.set_graph_hyperparameters(hp['lr'], hp['weight_decay'])
+            # everything before the capture runs on a NON-default stream: autograd remembers the stream every parameter's gradient was
+            # last accumulated on and synchronises with it during backward -- with the legacy default stream that is illegal inside a capture
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+            epoch = self._epochs(model, datamodule, dp, arena, hp, start_epoch, skip, done, use_graph)
+        if side is not None:
+            torch.cuda.current_stream(dev).wait_stream(side)
+        self._log(model, dp, 'train')
+        self.save_last(model, arena, hp, epoch)
+        return self
+
+    def _epochs(self, model, datamodule, dp, arena, hp, start_epoch: int, skip: int, done: bool, use_graph: bool) -> int:
+        from .module.data import DevicePrefetcher
+        gstep, eager_steps = None, 0
+        epoch = start_epoch
         for epoch in range(start_epoch, self.max_epochs if not done else start_epoch):
             loader = datamodule.train_dataloader()
             if hasattr(getattr(loader, 'sampler', None), 'set_epoch'):
@@ -577,10 +603,18 @@ class Trainer:
                 if epoch == start_epoch and i < skip:             # resumed mid-epoch: these batches were consumed before the checkpoint
                     self._batches_done = i + 1
                     continue
-                loss = model.training_step(batch, i)
-                loss.backward()
-                dp.finish()
-                arena.adamw_step(**hp)
+                if gstep is not None and torch.is_tensor(batch) and batch.shape == gstep.batch.shape and batch.dtype == gstep.batch.dtype:
+                    gstep(batch)                                  # one replay: forward, backward, AdamW
+                elif use_graph and gstep is None and eager_steps >= 2 and torch.is_tensor(batch):
+                    from .graph import GraphedTrainStep
+                    gstep = GraphedTrainStep(model, arena, batch, loss_fn=lambda m, b: m.training_step(b, 0), lr=hp['lr'], betas=hp['betas'],
+                                             eps=hp['eps'], weight_decay=hp['weight_decay'], warmup=0)      # captures AND performs this step
+                else:
+                    loss = model.training_step(batch, i)
+                    loss.backward()
+                    dp.finish()
+                    arena.adamw_step(**hp, graph_safe=use_graph)
+                    eager_steps += 1
                 self.global_step += 1
                 self._batches_done = i + 1
                 if self.global_step % self.log_every_n_steps == 0:
@@ -592,6 +626,4 @@ class Trainer:
                     break
             if done:
                 break
-        self._log(model, dp, 'train')
-        self.save_last(model, arena, hp, epoch)
-        return self
+        return epoch
