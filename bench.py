@@ -141,6 +141,31 @@ def csrc_sha16() -> str:
     return h.hexdigest()[:16]
 
 
+def power_cap_probe(batch: int = 64):
+    """How much of the distance between `roofline.achieved` and the 2.5 PFLOP/s peak is the chip's POWER cap rather than the kernel's
+    schedule: one launch shape of the dominant kernel (256 -> 256 channels, 3x3x3, 16x32x32, the step's batch) timed on random bf16 operands
+    and on all-zero operands -- the identical instruction stream and cycle count, a fraction of the switching power, so the clock stays
+    near its 2.4 GHz ceiling (rocprofv3 GRBM_GUI_ACTIVE of the two: 1.66 vs 2.30 GHz, profiles/r03_power_cap_ab.log)."""
+    from genie import _hip
+    from genie import conv as gconv
+    import scripts.microbench as mb
+    spec = gconv.same_spec(256, 256, (3, 3, 3))
+    out = {'layer': f'256->256 k3 @16x32x32, {batch} clips, forward', 'peak_tflops': BF16_MFMA_PEAK_TFLOPS}
+    fl = 2.0 * batch * 16 * 32 * 32 * 256 * 256 * 27
+    for tag, zero in (('random_operands', False), ('zero_operands', True)):
+        x = mb.empty_cl(batch, 256, 16, 32, 32, 'cuda')
+        x.zero_() if zero else x.copy_(torch.randn(batch, 256, 16, 32, 32, device='cuda'))
+        wt = (torch.randn(256, 256, 3, 3, 3, device='cuda') * (0.0 if zero else 0.05)).contiguous(memory_format=torch.channels_last_3d)
+        wf = gconv.pack_weight_fwd(wt, spec)
+        ms = mb.timeit(lambda: gconv.conv_forward(x, wf, None, spec), 10)
+        out[tag] = {'ms': round(ms, 4), 'tflops': round(fl / ms / 1e9, 1), 'mfma_frac': round(fl / ms / 1e9 / BF16_MFMA_PEAK_TFLOPS, 4)}
+        out['kernel'] = gconv.VARIANT_NAMES.get(_hip.load_library().genie_last_conv_variant())
+        del x, wt, wf
+    out['zero_over_random'] = round(out['zero_operands']['tflops'] / out['random_operands']['tflops'], 3)
+    torch.cuda.empty_cache()
+    return out
+
+
 def side_kernels(batch: int = 64):
     """The other two quantities BASELINE.json's metric names, measured at kernel level with HIP events on resident synthetic inputs
     (a few ms in total): MFMA utilisation of the space-time attention kernels on the two long-sequence shapes of SURVEY.md 8a
@@ -162,7 +187,8 @@ def side_kernels(batch: int = 64):
             if 'hbm_frac_min' in r:                      # against the operation's minimal traffic (1R + 1W forward, 2R + 1W backward)
                 hbm[r['name']].update({'gbps_min': r['gbps_min'], 'hbm_frac_min': r['hbm_frac_min']})
     best = max((v['mfma_frac'] for k, v in att.items() if 'fwd' in k), default=None)
-    return {'st_attention': {'peak_tflops': BF16_MFMA_PEAK_TFLOPS, 'flop_count': 'dense 4 S^2 C per sequence forward, 2.5x that backward',
+    return {'power_cap': power_cap_probe(batch),
+            'st_attention': {'peak_tflops': BF16_MFMA_PEAK_TFLOPS, 'flop_count': 'dense 4 S^2 C per sequence forward, 2.5x that backward',
                              'best_fwd_mfma_frac': best, 'kernels': att},
             'hbm_kernels': {'peak_gbps': 8000.0, 'bytes': 'what the passes of the call move (stated per entry); *_min: the minimal traffic of the operation', 'kernels': hbm}}
 

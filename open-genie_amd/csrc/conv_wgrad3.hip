@@ -49,6 +49,7 @@ struct Wgrad3Args {
     int tiles_m, tiles_n;
     int img_rows, log2W;        // (64 / W) * (W + 2);  W is a power of two in [8, 64]
     int dbg;                    // timing ablations (wrong results): 1 no MFMAs, 2 no fragment reads / MFMAs, 4 no DMA
+    int trim;                   // wgrad3l: skip the chunks of time-padding frames (GENIE_W3_TRIM, default 1)
     FastDiv3 dW_, dH_, dT_;
 };
 
@@ -390,10 +391,14 @@ __device__ __forceinline__ void w3l_loop(const Wgrad3Args& a, char* smem, const 
                                           const uint32_t (&voff_dy)[2], const uint32_t (&voff_x)[2], const uint32_t (&x_dst)[2],
                                           int (&x_t)[2], int (&x_h)[2], const int t_dt, const int t_dh,
                                           const uint32_t (&a_const)[2], const uint32_t (&b_const)[2][3],
-                                          f32x16_t (&acc)[3][2], f32x16_t (&accb)[2]) {
+                                          f32x16_t (&acc)[3][2], f32x16_t (&accb)[2], int clip_left, const int clip_chunks, const int skip_frames) {
     constexpr int BK = 64, W = 1 << LOG2W, HS = BK >> LOG2W, PITCH = 256;
     constexpr int A_BYTES = BK * PITCH, X_BYTES = 80 * PITCH, STAGE = A_BYTES + X_BYTES, NSTAGE = W3_NSTAGE, TM = 2;
     const uint32_t dy_step = (uint32_t)(BK * a.Cd * 2), x_step = (uint32_t)(BK * a.Cs * 2);      // bytes per chunk
+    // zero-frame skipping (skip_frames = |dt| > 0): the block walks only the chunks of frames t with 0 <= t + dt < T -- clip_chunks
+    // consecutive chunks per clip; after the last of them the cursor jumps skip_frames frames ahead (to the first valid frame of the next clip)
+    const uint32_t dy_skip = (uint32_t)skip_frames * (uint32_t)(a.H * a.W) * (uint32_t)(a.Cd * 2);
+    const uint32_t x_skip = (uint32_t)skip_frames * (uint32_t)(a.H * a.W) * (uint32_t)(a.Cs * 2);
     uint32_t so_dy = 0, so_x = 0;                        // scalar byte offsets of the NEXT chunk to stage, relative to the block's first
     int staged = 0;                                      // chunks staged so far
 
@@ -418,6 +423,16 @@ __device__ __forceinline__ void w3l_loop(const Wgrad3Args& a, char* smem, const 
                 ++staged;
                 so_dy += dy_step;
                 so_x += x_step;
+                if (skip_frames > 0 && --clip_left == 0) {           // (scalar: one s_cmp per chunk)
+                    clip_left = clip_chunks;
+                    so_dy += dy_skip;
+                    so_x += x_skip;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        x_t[q] += skip_frames;
+                        if (x_t[q] >= a.T) x_t[q] -= a.T;
+                    }
+                }
             }
         }
     };
@@ -523,7 +538,30 @@ __global__ void __launch_bounds__(512) wgrad3l_kernel(const Wgrad3Args a) {
 
     int c_begin = split * a.chunks_per_split, c_end = c_begin + a.chunks_per_split;
     if (c_end > a.nchunks) c_end = a.nchunks;
-    const int nch = c_end - c_begin;
+    int nch = c_end - c_begin;
+    // Zero-frame skipping: for a tap with dt != 0 the chunks of the |dt| frames per clip whose source frame t + dt is time padding stage
+    // zeros and multiply them.  The block then partitions the VALID chunks (per clip: (T - |dt|) * cpf consecutive ones, starting at frame
+    // max(0, -dt)) instead.  Not for the block that also sums the bias gradient (that sum runs over every pixel).
+    int clip_left = 0, clip_chunks = 0, skip_frames = 0;
+    {
+        const int adt = t_dt < 0 ? -t_dt : t_dt;
+        const int cpf = (a.H * a.W) >> 6;                                    // chunks per frame (H * W is a multiple of 64 here)
+        const bool bias_block = a.dbias != nullptr && tr == 0 && tile_n == 0;
+        if (a.trim && adt > 0 && adt < a.T && !bias_block) {
+            const int nclips = a.nchunks / (a.T * cpf);
+            clip_chunks = (a.T - adt) * cpf;
+            const int nvalid = nclips * clip_chunks;
+            const int per = (nvalid + a.split_k - 1) / a.split_k;
+            int v0 = split * per, v1 = v0 + per;
+            v0 = v0 > nvalid ? nvalid : v0;
+            v1 = v1 > nvalid ? nvalid : v1;
+            const int n0 = v0 / clip_chunks, r0 = v0 - n0 * clip_chunks;
+            c_begin = __builtin_amdgcn_readfirstlane((n0 * a.T + (t_dt < 0 ? adt : 0)) * cpf + r0);
+            nch = __builtin_amdgcn_readfirstlane(v1 - v0);
+            clip_left = __builtin_amdgcn_readfirstlane(clip_chunks - r0);
+            skip_frames = adt;
+        }
+    }
 
     // ---- per-lane staging constants: byte offsets inside a chunk (never change), OOB for channel chunks that do not exist ----
     const int d_row = tid >> 4;                          // + 32 * round
@@ -596,9 +634,10 @@ __global__ void __launch_bounds__(512) wgrad3l_kernel(const Wgrad3Args a) {
 
     if (nch > 0) {
         if (do_bias)
-            w3l_loop<LOG2W, true>(a, smem, nch, wave, rs_dy, rs_x, voff_dy, voff_x, x_dst, x_t, x_h, t_dt, t_dh, a_const, b_const, acc, accb);
+            w3l_loop<LOG2W, true>(a, smem, nch, wave, rs_dy, rs_x, voff_dy, voff_x, x_dst, x_t, x_h, t_dt, t_dh, a_const, b_const, acc, accb, 0, 0, 0);
         else
-            w3l_loop<LOG2W, false>(a, smem, nch, wave, rs_dy, rs_x, voff_dy, voff_x, x_dst, x_t, x_h, t_dt, t_dh, a_const, b_const, acc, accb);
+            w3l_loop<LOG2W, false>(a, smem, nch, wave, rs_dy, rs_x, voff_dy, voff_x, x_dst, x_t, x_h, t_dt, t_dh, a_const, b_const, acc, accb,
+                                   clip_left, clip_chunks, skip_frames);
     }
 
     // ---- epilogue: fp32 atomics; D row = cout (registers), col = cin (lane & 31) ----
@@ -712,7 +751,13 @@ int genie_conv_wgrad3_try(const GenieWgradDesc* d, hipStream_t s) {
     // lean main loop (buffer-addressed LDS-DMA, scalar bookkeeping) where its preconditions hold -- see wgrad3l_kernel
     static const int lean_on = getenv("GENIE_W3_LEAN") ? atoi(getenv("GENIE_W3_LEAN")) : 1;
     const long long blk_bytes = (long long)a.chunks_per_split * 64 * (d->Cs > d->Cd ? d->Cs : d->Cd) * 2 + ((long long)(d->Hs + 2) * W * d->Cs * 2);
+    a.trim = 0;
     if (lean_on && !shuffled && a.dbg == 0 && (d->Ho * W) % 64 == 0 && 64 / W <= d->Ho && blk_bytes < 0x7f000000ll && d->Td == d->Ts && d->Hd == d->Hs && d->Wd == W) {
+        // zero-frame skipping: a block's address range grows by the (<= 2 per clip) padding frames it jumps over
+        static const int trim_on = getenv("GENIE_W3_TRIM") ? atoi(getenv("GENIE_W3_TRIM")) : 1;
+        const long long cpf = (long long)d->Ho * W / 64;
+        const long long span = a.chunks_per_split + (a.chunks_per_split / (cpf * (d->To > 2 ? d->To - 2 : 1)) + 2) * 2 * cpf;
+        a.trim = trim_on && d->To >= 3 && span * 64 * (d->Cs > d->Cd ? d->Cs : d->Cd) * 2 + ((long long)(d->Hs + 2) * W * d->Cs * 2) < 0x7f000000ll;
         void (*lk)(const Wgrad3Args) = a.log2W == 3 ? wgrad3l_kernel<3> : a.log2W == 4 ? wgrad3l_kernel<4> : a.log2W == 5 ? wgrad3l_kernel<5> : wgrad3l_kernel<6>;
         static bool lconf[8] = {false};
         if (!lconf[a.log2W]) {
