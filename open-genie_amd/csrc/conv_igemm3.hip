@@ -1463,7 +1463,9 @@ int genie_conv_igemm3_try(const GenieConvDesc* d, IgemmArgs a, hipStream_t s) {
         }
         if (bm == 0) {
             if (t128 < 256) return 1;                    // few tiles: the generic kernel's split-K fills the chip better
-            bm = (256 % W == 0 && t256 >= 512) ? 256 : 128;
+            // 256-row tiles from one block per CU on (GENIE_TRI_BM256_MIN, was 512 = two rounds): 512 -> 512 @4x8x8 at 64 clips 984 -> 1237 TFLOP/s
+            static const int bm256_min = getenv("GENIE_TRI_BM256_MIN") ? atoi(getenv("GENIE_TRI_BM256_MIN")) : 256;
+            bm = (256 % W == 0 && t256 >= bm256_min) ? 256 : 128;
         }
     }
     if (bm != 128 && bm != 256) {

@@ -11,6 +11,8 @@ bash scripts/profile_bench.sh r03 64 > $OUT/prof.log 2>&1
 tail -3 $OUT/prof.log
 timeout 900 python scripts/bench_models.py lam dyn repr genie4 --cpu-baseline > $OUT/bench_models.log 2>&1
 grep -c '^{' $OUT/bench_models.log
+timeout 600 python scripts/bench_models.py smallbatch > $OUT/smallbatch.log 2>&1
+grep '^{' $OUT/smallbatch.log | cut -c1-330
 bash scripts/profile_models.sh r03 > $OUT/prof_models.log 2>&1
 tail -3 $OUT/prof_models.log
 timeout 600 python scripts/microbench.py attn hbm conv --iters 20 --out $OUT/microbench.json > $OUT/microbench.log 2>&1
