@@ -187,7 +187,8 @@ def side_kernels(batch: int = 64):
             if 'hbm_frac_min' in r:                      # against the operation's minimal traffic (1R + 1W forward, 2R + 1W backward)
                 hbm[r['name']].update({'gbps_min': r['gbps_min'], 'hbm_frac_min': r['hbm_frac_min']})
     best = max((v['mfma_frac'] for k, v in att.items() if 'fwd' in k), default=None)
-    return {'power_cap': power_cap_probe(batch),
+    # (not under the profiler: the probe launches the dominant kernel itself and would mix into its rocprofv3 / PMC averages)
+    return {**({} if os.environ.get('GENIE_BENCH_NO_PROBE') else {'power_cap': power_cap_probe(batch)}),
             'st_attention': {'peak_tflops': BF16_MFMA_PEAK_TFLOPS, 'flop_count': 'dense 4 S^2 C per sequence forward, 2.5x that backward',
                              'best_fwd_mfma_frac': best, 'kernels': att},
             'hbm_kernels': {'peak_gbps': 8000.0, 'bytes': 'what the passes of the call move (stated per entry); *_min: the minimal traffic of the operation', 'kernels': hbm}}
