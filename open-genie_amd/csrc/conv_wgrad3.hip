@@ -49,7 +49,7 @@ struct Wgrad3Args {
     int tiles_m, tiles_n;
     int img_rows, log2W;        // (64 / W) * (W + 2);  W is a power of two in [8, 64]
     int dbg;                    // timing ablations (wrong results): 1 no MFMAs, 2 no fragment reads / MFMAs, 4 no DMA
-    int trim;                   // wgrad3l: skip the chunks of time-padding frames (GENIE_W3_TRIM, default 1)
+    int trim;                   // wgrad3l: skip the chunks of time-padding frames (GENIE_W3_TRIM=1; off by default)
     FastDiv3 dW_, dH_, dT_;
 };
 
@@ -753,8 +753,11 @@ int genie_conv_wgrad3_try(const GenieWgradDesc* d, hipStream_t s) {
     const long long blk_bytes = (long long)a.chunks_per_split * 64 * (d->Cs > d->Cd ? d->Cs : d->Cd) * 2 + ((long long)(d->Hs + 2) * W * d->Cs * 2);
     a.trim = 0;
     if (lean_on && !shuffled && a.dbg == 0 && (d->Ho * W) % 64 == 0 && 64 / W <= d->Ho && blk_bytes < 0x7f000000ll && d->Td == d->Ts && d->Hd == d->Hs && d->Wd == W) {
-        // zero-frame skipping: a block's address range grows by the (<= 2 per clip) padding frames it jumps over
-        static const int trim_on = getenv("GENIE_W3_TRIM") ? atoi(getenv("GENIE_W3_TRIM")) : 1;
+        // zero-frame skipping (GENIE_W3_TRIM=1; OFF by default): a block's address range grows by the (<= 2 per clip) padding frames it
+        // jumps over.  Measured on one box at 64 clips: kernel time unchanged (a launch is one round of blocks and the dt = 0 blocks set the
+        // makespan), step -0.4 %, but FETCH_SIZE per launch 7.26 -> 9.88 GB (128 -> 128 @16x64x64): the dt != 0 blocks no longer walk the
+        // same dy chunks at the same time as their dt = 0 siblings and lose the L2 sharing (profiles/r03_zero_frame_trim_ab.log)
+        static const int trim_on = getenv("GENIE_W3_TRIM") ? atoi(getenv("GENIE_W3_TRIM")) : 0;
         const long long cpf = (long long)d->Ho * W / 64;
         const long long span = a.chunks_per_split + (a.chunks_per_split / (cpf * (d->To > 2 ? d->To - 2 : 1)) + 2) * 2 * cpf;
         a.trim = trim_on && d->To >= 3 && span * 64 * (d->Cs > d->Cd ? d->Cs : d->Cd) * 2 + ((long long)(d->Hs + 2) * W * d->Cs * 2) < 0x7f000000ll;
