@@ -237,6 +237,8 @@ int genie_groupnorm_bwd(const void* x, const void* dy, void* dx, int N, int64_t 
  * gnb_part): one group, no adaptive scale / shift.  fwd: mean / rstd (fp32 [N], written) from the fp64 sums, then the apply pass;
  * bwd: parameter gradients (accumulated) + coefficients from the per-tile partials, then the apply pass.  ws: fp32 scratch of
  * genie_groupnorm_bwd_from_part_ws_floats(N). */
+/* tests: 1 when a clip barrier of the one-pass forward (norm.hip) ever gave up waiting; synchronises the device */
+int genie_gn_fused_error(void);
 int genie_groupnorm_fwd_from_sums(const void* x, void* y, int N, int64_t npix, int C, int cpitch, const float* gamma, const float* beta,
                                   float eps, int act, float* mean, float* rstd, const double* sums, void* stream);
 int64_t genie_groupnorm_bwd_from_part_ws_floats(int N);

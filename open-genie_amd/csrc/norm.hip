@@ -195,6 +195,10 @@ static int gn_chunk_samples(int N, long long bytes_per_sample, int streams) {
     return (int)(n < 1 ? 1 : n);
 }
 
+static int gn_fused_fwd_try(const void* x, void* y, int N, long long npix, int C, int Cp, int G, const float* gamma, const float* beta,
+                            const float* ada_s, const float* ada_b, float eps, int act, float* mean, float* rstd, float* ws, long long ws_floats,
+                            hipStream_t s);      // below: the one-pass forward
+
 extern "C" int genie_groupnorm_fwd(const void* x, void* y, int N, int64_t npix, int C, int cpitch, int G, const float* gamma,
                                    const float* beta, const float* ada_scale, const float* ada_shift, float eps, int act,
                                    float* mean, float* rstd, float* ws, void* stream) {
@@ -203,6 +207,11 @@ extern "C" int genie_groupnorm_fwd(const void* x, void* y, int N, int64_t npix, 
     GENIE_CHECK_ARG(cpitch % 8 == 0 && cpitch >= C, "genie_groupnorm_fwd: bad channel pitch %d for C=%d", cpitch, C);
     if (N == 0 || npix == 0) return GENIE_OK;
     hipStream_t s = (hipStream_t)stream;
+    {
+        const int r = gn_fused_fwd_try(x, y, N, npix, C, cpitch, G, gamma, beta, ada_scale, ada_shift, eps, act, mean, rstd, ws,
+                                       genie_groupnorm_ws_floats(N, C, G), s);
+        if (r <= 0) return r;
+    }
     // Sample chunks: statistics and apply of a chunk run back to back, so the apply pass re-reads the chunk out of the
     // memory-side cache (256 MB Infinity Cache) instead of HBM -- one HBM read + one write per element instead of two reads.
     const int nsub = gn_chunk_samples(N, npix * cpitch * 2ll, 1);
@@ -221,6 +230,258 @@ extern "C" int genie_groupnorm_fwd(const void* x, void* y, int N, int64_t npix, 
         GENIE_CHECK_LAUNCH();
     }
     return GENIE_OK;
+}
+
+// ---- fused forward: statistics and apply in ONE pass over HBM (1 read + 1 write) -------------------------------------------------
+// The two-pass forward above reads x twice (the 1-GB activations of a 64-clip step do not survive in any cache between the passes); it
+// runs at what a device copy reaches on the bytes it moves, so only moving fewer bytes helps.  Here a clip's slice stays ON CHIP between
+// the statistics and the apply -- in REGISTERS: a block of 512 threads loads NI 16-byte chunks per thread (NI x 8 KB contiguous bytes of
+// the clip, all loads in flight at once), sums them, the `bpc` blocks of the clip exchange their per-group partial sums through global
+// memory (the exchange is the barrier among the blocks of ONE clip, see gn_publish / gn_await), every block finishes mean / rstd from the partials in a
+// fixed order (fp64), applies scale / shift / activation to the registers and stores.  The grid is sized to what is RESIDENT at once
+// (hipOccupancy... x CUs): R = resident / bpc clips per round, ceil(N / R) rounds; the blocks of a clip therefore always run together and
+// the spin can only wait for blocks that are executing (a bound on the spin turns a would-be hang into an error flag all the same).
+// Two blocks per CU cover each other's barrier wait.  Needs: 8 channels of a chunk in one group ((C / G) % 8 == 0), chunks per pixel
+// CH = Cp / 8 a power of two <= 64 (thread t owns chunk t % CH for its lifetime), bpc <= resident blocks.  Everything else takes the
+// two-pass path.
+static __device__ int g_gn_fused_err;
+
+struct GnFusedArgs {
+    const bf16_t* x; bf16_t* y;
+    int N, C, Cp, G, CH;
+    long long npix, clip_chunks;         // 16-byte chunks per clip = npix * CH
+    int bpc, R, rounds;                  // blocks per clip, clips per round, rounds
+    const float *gamma, *beta;
+    float eps; int act;
+    float *mean, *rstd;
+    unsigned long long* part;            // [N][bpc][G] (sum, sum of squares) as one 64-bit word; all-ones = not there yet
+};
+
+// The exchange IS the barrier: a block publishes its (sum, sum of squares) of a group as ONE 64-bit device-scope store into its own entry of
+// the clip's table (pre-set to all-ones = NaN bits by a memset in front of the launch); a reader polls the entries it needs until their
+// upper half is no longer the NaN pattern.  No read-modify-write on a shared address (256 arrivals at one counter serialise at the memory
+// side and cost ~60 us per round), no fences (data and flag are the same atomic word; device-scope accesses bypass the per-XCD L2s).
+__device__ __forceinline__ void gn_publish(unsigned long long* entry, float s, float q) {
+    const unsigned long long w = (unsigned long long)__float_as_uint(s) | ((unsigned long long)__float_as_uint(q) << 32);
+    __hip_atomic_store(entry, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void gn_await(const unsigned long long* entry, float& s, float& q) {
+    unsigned long long w;
+    unsigned spins = 0;
+    for (;;) {
+        w = __hip_atomic_load(entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(w >> 32) != 0xFFFFFFFFu) break;
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > (1u << 22)) { atomicExch(&g_gn_fused_err, 1); break; }             // never hang the GPU: flag and carry on
+    }
+    s = __uint_as_float((unsigned)w);
+    q = __uint_as_float((unsigned)(w >> 32));
+}
+
+template <int NI>
+__global__ void __launch_bounds__(512, 4) gn_fused_fwd_kernel(const GnFusedArgs a) {
+    __shared__ float red[512 * 2];
+    __shared__ double dred[16];
+    __shared__ float stat[64 * 2];                       // mean, rstd per group (G <= 64)
+    const int tid = threadIdx.x;
+    const int slot = blockIdx.x / a.bpc, blk = blockIdx.x - slot * a.bpc;
+    const int cc = tid % a.CH;                           // this thread's 16-byte chunk of every pixel it touches
+    const int cpg = a.CH / a.G;                          // chunks per group
+    const int grp = cc / cpg;
+    const long long f0 = (long long)blk * (512 * NI) + tid;     // first chunk of the clip this thread owns; then + 512 per i
+
+    float ga[8], be[8];                                  // this thread's 8 channels (pad channels: 0)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = cc * 8 + j;
+        ga[j] = c < a.C ? (a.gamma ? a.gamma[c] : 1.f) : 0.f;
+        be[j] = c < a.C ? (a.beta ? a.beta[c] : 0.f) : 0.f;
+    }
+    auto load = [&](u32x4_t (&v)[NI], int round) {
+        const int n = round * a.R + slot;
+        const bf16_t* xs = a.x + (long long)n * a.clip_chunks * 8;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const long long f = f0 + 512ll * i;
+            v[i] = f < a.clip_chunks ? *reinterpret_cast<const u32x4_t*>(xs + f * 8) : u32x4_t{0u, 0u, 0u, 0u};
+        }
+    };
+    // stage A of a round: sums of the registers, block partial, publish
+    auto stage_a = [&](u32x4_t (&v)[NI], int round) {
+        const int n = round * a.R + slot;
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            float f8[8];
+            unpack8(v[i], f8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { s += f8[j]; q += f8[j] * f8[j]; }
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) asm volatile("" : "+v"(v[i]));         // keep the PACKED chunks across the exchange, not 8 floats each
+        // block partials per group, fixed order: threads t, t + 64, ... share a chunk index (CH divides 64), so 64 threads fold the
+        // eight waves, then one thread per group folds its chunks
+        red[tid * 2] = s; red[tid * 2 + 1] = q;
+        __syncthreads();
+        if (tid < 64) {
+            float ts = 0.f, tq = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { ts += red[(tid + 64 * k) * 2]; tq += red[(tid + 64 * k) * 2 + 1]; }
+            red[tid * 2] = ts; red[tid * 2 + 1] = tq;    // (slot tid is only read by thread tid above)
+        }
+        __syncthreads();
+        if (tid < a.G) {
+            float ts = 0.f, tq = 0.f;
+            for (int t = 0; t < 64; ++t)
+                if ((t % a.CH) / cpg == tid) { ts += red[t * 2]; tq += red[t * 2 + 1]; }
+            gn_publish(a.part + ((long long)n * a.bpc + blk) * a.G + tid, ts, tq);
+        }
+        __syncthreads();                                 // red is reused
+    };
+    // stage B: wait for the clip's other blocks, statistics, apply, store
+    auto stage_b = [&](u32x4_t (&v)[NI], int round) {
+        const int n = round * a.R + slot;
+        bf16_t* ys = a.y + (long long)n * a.clip_chunks * 8;
+        // group totals from the bpc partials: thread t takes blocks t, t + 512, ... (ONE device-scope round trip for all of them instead of a
+        // chain of them in one wave), folded in a fixed order, fp64 across blocks as in gn_finalize_kernel; waiting for an entry = waiting
+        // for its block
+        for (int g = 0; g < a.G; ++g) {
+            double ds = 0.0, dq = 0.0;
+            for (int b = tid; b < a.bpc; b += 512) {
+                float ps, pq;
+                gn_await(a.part + ((long long)n * a.bpc + b) * a.G + g, ps, pq);
+                ds += (double)ps;
+                dq += (double)pq;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { ds += __shfl_xor(ds, o, 64); dq += __shfl_xor(dq, o, 64); }
+            if ((tid & 63) == 0) { dred[(tid >> 6) * 2] = ds; dred[(tid >> 6) * 2 + 1] = dq; }
+            __syncthreads();
+            if (tid == 0) {
+                double S = 0.0, Q = 0.0;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) { S += dred[w * 2]; Q += dred[w * 2 + 1]; }
+                const double cnt = (double)(a.C / a.G) * (double)a.npix;
+                const double m = S / cnt;
+                double var = Q / cnt - m * m;
+                if (var < 0.0) var = 0.0;
+                const float mf = (float)m, rf = (float)(1.0 / sqrt(var + (double)a.eps));
+                stat[g * 2] = mf; stat[g * 2 + 1] = rf;
+                if (blk == 0) { a.mean[n * a.G + g] = mf; a.rstd[n * a.G + g] = rf; }
+            }
+            __syncthreads();
+        }
+        // coefficients of this thread's 8 channels: z = x * ca + cb  (gamma / beta were loaded once, in front of the rounds: a global load
+        // HERE waits behind the next round's prefetch and the previous round's stores -- eight such waits were 16 us per round)
+        float ca[8], cb[8];
+        {
+            const float mu = stat[grp * 2], rs = stat[grp * 2 + 1];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                ca[j] = rs * ga[j];
+                cb[j] = be[j] - mu * rs * ga[j];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const long long f = f0 + 512ll * i;
+            if (f < a.clip_chunks) {
+                float f8[8];
+                unpack8(v[i], f8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float z = f8[j] * ca[j] + cb[j];
+                    f8[j] = a.act == 1 ? silu_f(z) : (a.act == 2 ? (z > 0.f ? z : 0.01f * z) : z);
+                }
+                *reinterpret_cast<u32x4_t*>(ys + f * 8) = pack8(f8);
+            }
+        }
+        __syncthreads();                                 // red / stat are reused by the next round
+    };
+    // Two register sets, software-pipelined ACROSS the exchange: round r + 1 is loaded, summed and published BEFORE round r waits for its
+    // clip's other blocks -- by the time a block asks for the partials of round r + 1 everybody published them an iteration ago, and the
+    // stores of round r overlap the loads of round r + 2.  (`rounds_slot` is the same for every block of a slot: they leave together.)
+    const int rs = (a.N - slot + a.R - 1) / a.R;
+    u32x4_t va[NI], vb[NI];
+    if (rs > 0) {
+        load(va, 0);
+        if (rs > 1) load(vb, 1);
+        stage_a(va, 0);
+    }
+    for (int r = 0; r < rs; r += 2) {                    // invariant: va = round r with stage A done, vb = round r + 1 loaded
+        if (r + 1 < rs) stage_a(vb, r + 1);
+        stage_b(va, r);
+        if (r + 2 < rs) load(va, r + 2);
+        if (r + 1 < rs) {
+            if (r + 2 < rs) stage_a(va, r + 2);
+            stage_b(vb, r + 1);
+            if (r + 3 < rs) load(vb, r + 3);
+        }
+    }
+}
+
+extern "C" int genie_gn_fused_error(void) {              // tests: did any clip barrier give up?  (synchronises)
+    int v = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_gn_fused_err), sizeof(int)) != hipSuccess) return -1;
+    return v;
+}
+
+// returns 1 when the fused path does not apply (caller runs the two-pass path), 0 on launch, < 0 on error
+static int gn_fused_fwd_try(const void* x, void* y, int N, long long npix, int C, int Cp, int G, const float* gamma, const float* beta,
+                            const float* ada_s, const float* ada_b, float eps, int act, float* mean, float* rstd, float* ws, long long ws_floats,
+                            hipStream_t s) {
+    // OFF by default (GENIE_GN_FUSED=1 enables): measured SLOWER than the two-pass forward -- 0.90 vs 0.64 ms on 64 clips of
+    // 128 x 16x64x64 (0.116 vs 0.080 ms on 8), step 471 vs 463 ms.  One read + one write instead of two reads + one write, but every round
+    // is a chain of latencies (load -> sum -> publish -> device-scope round trip -> statistics -> store) that 2 blocks x 32 KB per CU do
+    // not cover: 14 us per 16.8-MB clip against 6.5 us of transfer.  History of the number: one shared counter per clip 2.5 ms (256
+    // arrivals serialise at the memory side), publish / poll entries 0.86 ms, parameter loads hoisted out of the rounds 1.04 -> ...,
+    // exchange pipelined across rounds 0.90 ms.  DESIGN.md section 8.
+    static const int on = getenv("GENIE_GN_FUSED") ? atoi(getenv("GENIE_GN_FUSED")) : 0;
+    if (!on) return 1;
+    const int CH = Cp / 8;
+    if (C != Cp || C % G != 0 || (C / G) % 8 != 0 || G > 64 || CH > 64 || (CH & (CH - 1)) != 0) return 1;
+    static const int max_g = getenv("GENIE_GN_FUSED_MAXG") ? atoi(getenv("GENIE_GN_FUSED_MAXG")) : 1;      // the exchange walks the groups one after the other: G = 1 (the residual blocks) by default
+    if (G > max_g || ada_s || ada_b) return 1;           // (per-sample adaptive scale / shift: two-pass path)
+    static int resident[2] = {0, 0};                     // blocks of 512 threads resident on the device, per NI instantiation
+    static int ncu = 0;
+    if (!ncu) {
+        hipDeviceProp_t pr;
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return 1;
+        ncu = pr.multiProcessorCount;
+    }
+    const long long chunks = npix * CH;
+    int best_ni = -1, best_bpc = 0, best_R = 0;
+    long long best_used = -1;
+    const int nis[2] = {4, 2};                           // chunks per thread and register set (two sets of 8 spill at 128 registers)
+    for (int k = 0; k < 2; ++k) {
+        if (!resident[k]) {
+            int nb = 0;
+            const void* fn = k == 0 ? (const void*)gn_fused_fwd_kernel<4> : (const void*)gn_fused_fwd_kernel<2>;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 512, 0) != hipSuccess || nb < 1) return 1;
+            resident[k] = nb * ncu;
+        }
+        const long long bpc = (chunks + 512ll * nis[k] - 1) / (512ll * nis[k]);
+        if (bpc > resident[k]) continue;
+        long long R = resident[k] / bpc;
+        if (R > N) R = N;
+        const long long used = R * bpc;
+        if (used > best_used) { best_used = used; best_ni = k; best_bpc = (int)bpc; best_R = (int)R; }
+    }
+    if (best_ni < 0) return 1;
+    const long long need = (long long)N * best_bpc * G * 2 + 64;
+    if (need > ws_floats) return 1;
+    GnFusedArgs a;
+    a.x = (const bf16_t*)x; a.y = (bf16_t*)y; a.N = N; a.C = C; a.Cp = Cp; a.G = G; a.CH = CH; a.npix = npix; a.clip_chunks = chunks;
+    a.bpc = best_bpc; a.R = best_R; a.rounds = (N + best_R - 1) / best_R;
+    a.gamma = gamma; a.beta = beta; a.eps = eps; a.act = act; a.mean = mean; a.rstd = rstd;
+    a.part = reinterpret_cast<unsigned long long*>(ws);
+    if (hipMemsetAsync(a.part, 0xFF, sizeof(unsigned long long) * (size_t)N * best_bpc * G, s) != hipSuccess) return 1;
+    const dim3 grid(best_R * best_bpc);
+    if (best_ni == 0) gn_fused_fwd_kernel<4><<<grid, 512, 0, s>>>(a);
+    else gn_fused_fwd_kernel<2><<<grid, 512, 0, s>>>(a);
+    GENIE_CHECK_LAUNCH();
+    return 0;
 }
 
 // ---- backward -------------------------------------------------------------------------------------

@@ -105,6 +105,7 @@ SIGNATURES = {
     'genie_mse_bwd': (C.c_int, [_P, _I, _P, _I, _PL, _PL, _P, _P, _P]),
     'genie_adamw_step': (C.c_int, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _I, _P]),
     'genie_adamw_step_mirror': (C.c_int, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _I, _P]),
+    'genie_gn_fused_error': (C.c_int, []),
     'genie_adamw_step_graph': (C.c_int, [_P, _P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _I, _P]),
     'genie_pack_transpose_batched': (C.c_int, [_P, _I, _I, _P, _P, _P]),
     'genie_rotary_layernorm_fwd': (C.c_int, [_P, _P, _L, _I, _L, _P, _L, _I, _P, _P, _F, _P, _P]),

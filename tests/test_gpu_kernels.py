@@ -138,6 +138,50 @@ def test_groupnorm_fwd_bwd(G, N, C, G_, thw, ada, act):
         torch.testing.assert_close(got.cpu(), want, rtol=2e-3, atol=2e-3 * want.abs().max().item(), msg=nm)
 
 
+_ONE_PASS_CHECK = r"""
+import sys, torch
+sys.path[:0] = ['tests', '.', 'open-genie_amd']
+from util import assert_close_bf16, bf16_round
+from genie import _hip, cl
+from oracle import genie_oracle as O
+lib = _hip.load_library()
+for N, C, thw, act in ((5, 128, (16, 64, 64), True), (70, 256, (4, 16, 16), False), (9, 512, (4, 8, 8), True)):
+    torch.manual_seed(5)
+    x = bf16_round(torch.randn(N, C, *thw) * 1.5 + 0.3 * torch.arange(N).float().reshape(N, 1, 1, 1, 1))
+    gamma, beta = torch.randn(C), torch.randn(C)
+    with torch.no_grad():
+        ref = O.group_norm(x, 1, gamma, beta)
+        ref = O.silu(ref) if act else ref
+    xc = cl.to_cl(x.cuda()); y = cl.empty_like_cl(xc)
+    npix = thw[0] * thw[1] * thw[2]
+    mean = torch.empty(N, device='cuda'); rstd = torch.empty(N, device='cuda')
+    ws = torch.empty(lib.genie_groupnorm_ws_floats(N, C, 1), device='cuda')
+    g_, b_ = gamma.cuda(), beta.cuda()
+    for _ in range(2):                                   # twice: the exchange table is re-armed per launch
+        _hip.check(lib.genie_groupnorm_fwd(xc.data_ptr(), y.data_ptr(), N, npix, C, cl.pitch_of(xc), 1, g_.data_ptr(), b_.data_ptr(), None, None, 1e-5,
+                                           int(act), mean.data_ptr(), rstd.data_ptr(), ws.data_ptr(), _hip.stream_ptr()), 'gn fwd')
+    assert lib.genie_gn_fused_error() == 0
+    assert_close_bf16(y, ref, 'gn one-pass fwd')
+    xg = x.reshape(N, -1).double()
+    torch.testing.assert_close(mean.cpu().double(), xg.mean(-1), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(rstd.cpu().double(), (xg.var(-1, unbiased=False) + 1e-5).rsqrt(), rtol=1e-4, atol=1e-5)
+print('one-pass ok')
+"""
+
+
+def test_groupnorm_one_pass_forward_behind_its_switch():
+    """The one-pass forward (gn_fused_fwd_kernel, GENIE_GN_FUSED=1; off by default because it measured slower): a clip's slice stays in
+    registers between statistics and apply, the blocks of a clip exchange partial sums through device-scope memory.  Run in a process of its
+    own (the switch is read once): multi-round, partial last round, many clips per round; outputs, mean / rstd, no exchange ever gave up."""
+    import os
+    import subprocess
+    import sys
+    from util import ROOT
+    env = dict(os.environ, GENIE_GN_FUSED='1')
+    r = subprocess.run([sys.executable, '-c', _ONE_PASS_CHECK], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'one-pass ok' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
 CONV_CASES = [
     # cin, cout, kernel, stride, causal, size
     (64, 128, (3, 3, 3), (1, 1, 1), False, (2, 4, 8, 8)),
