@@ -278,7 +278,10 @@ __device__ __forceinline__ void gn_await(const unsigned long long* entry, float&
     q = __uint_as_float((unsigned)(w >> 32));
 }
 
-template <int NI>
+// SETS = 2: two register sets of NI chunks, exchange pipelined across rounds.  SETS = 1: one set of NI chunks (twice the slice per block, so half
+// the blocks per clip and TWO clips in flight); the odd clip slots start half a round late, so that one slot's exchange / arithmetic falls into
+// the other's transfer (0.71 ms; a strict hand-over -- clip n loads when clip n - 1 has published -- is a chain of its own: 0.76 ms).
+template <int NI, int SETS>
 __global__ void __launch_bounds__(512, 4) gn_fused_fwd_kernel(const GnFusedArgs a) {
     __shared__ float red[512 * 2];
     __shared__ double dred[16];
@@ -402,6 +405,19 @@ __global__ void __launch_bounds__(512, 4) gn_fused_fwd_kernel(const GnFusedArgs 
     // clip's other blocks -- by the time a block asks for the partials of round r + 1 everybody published them an iteration ago, and the
     // stores of round r overlap the loads of round r + 2.  (`rounds_slot` is the same for every block of a slot: they leave together.)
     const int rs = (a.N - slot + a.R - 1) / a.R;
+    if constexpr (SETS == 1) {
+        u32x4_t va[NI];
+        if (slot & 1) {                                  // de-phase the odd slots by about half a round (~6 us)
+            __builtin_amdgcn_s_sleep(127);
+            __builtin_amdgcn_s_sleep(127);
+        }
+        for (int r = 0; r < rs; ++r) {
+            load(va, r);
+            stage_a(va, r);
+            stage_b(va, r);
+        }
+        return;
+    }
     u32x4_t va[NI], vb[NI];
     if (rs > 0) {
         load(va, 0);
@@ -430,7 +446,7 @@ extern "C" int genie_gn_fused_error(void) {              // tests: did any clip 
 static int gn_fused_fwd_try(const void* x, void* y, int N, long long npix, int C, int Cp, int G, const float* gamma, const float* beta,
                             const float* ada_s, const float* ada_b, float eps, int act, float* mean, float* rstd, float* ws, long long ws_floats,
                             hipStream_t s) {
-    // OFF by default (GENIE_GN_FUSED=1 enables): measured SLOWER than the two-pass forward -- 0.90 vs 0.64 ms on 64 clips of
+    // OFF by default (GENIE_GN_FUSED=1 / 2 enable the two forms): measured SLOWER than the two-pass forward -- 0.88 / 0.71 vs 0.64 ms on 64 clips of
     // 128 x 16x64x64 (0.116 vs 0.080 ms on 8), step 471 vs 463 ms.  One read + one write instead of two reads + one write, but every round
     // is a chain of latencies (load -> sum -> publish -> device-scope round trip -> statistics -> store) that 2 blocks x 32 KB per CU do
     // not cover: 14 us per 16.8-MB clip against 6.5 us of transfer.  History of the number: one shared counter per clip 2.5 ms (256
@@ -442,7 +458,7 @@ static int gn_fused_fwd_try(const void* x, void* y, int N, long long npix, int C
     if (C != Cp || C % G != 0 || (C / G) % 8 != 0 || G > 64 || CH > 64 || (CH & (CH - 1)) != 0) return 1;
     static const int max_g = getenv("GENIE_GN_FUSED_MAXG") ? atoi(getenv("GENIE_GN_FUSED_MAXG")) : 1;      // the exchange walks the groups one after the other: G = 1 (the residual blocks) by default
     if (G > max_g || ada_s || ada_b) return 1;           // (per-sample adaptive scale / shift: two-pass path)
-    static int resident[2] = {0, 0};                     // blocks of 512 threads resident on the device, per NI instantiation
+    static int resident[4] = {0, 0, 0, 0};               // blocks of 512 threads resident on the device, per instantiation
     static int ncu = 0;
     if (!ncu) {
         hipDeviceProp_t pr;
@@ -453,12 +469,14 @@ static int gn_fused_fwd_try(const void* x, void* y, int N, long long npix, int C
     const long long chunks = npix * CH;
     int best_ni = -1, best_bpc = 0, best_R = 0;
     long long best_used = -1;
-    const int nis[2] = {4, 2};                           // chunks per thread and register set (two sets of 8 spill at 128 registers)
-    for (int k = 0; k < 2; ++k) {
+    // GENIE_GN_FUSED=1: two register sets of 4 / 2 chunks; =2: one set of 8 / 4 chunks, odd clip slots de-phased
+    const int nis[4] = {4, 2, 8, 4};
+    const void* fns[4] = {(const void*)gn_fused_fwd_kernel<4, 2>, (const void*)gn_fused_fwd_kernel<2, 2>, (const void*)gn_fused_fwd_kernel<8, 1>,
+                          (const void*)gn_fused_fwd_kernel<4, 1>};
+    for (int k = (on == 2 ? 2 : 0); k < (on == 2 ? 4 : 2); ++k) {
         if (!resident[k]) {
             int nb = 0;
-            const void* fn = k == 0 ? (const void*)gn_fused_fwd_kernel<4> : (const void*)gn_fused_fwd_kernel<2>;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 512, 0) != hipSuccess || nb < 1) return 1;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fns[k], 512, 0) != hipSuccess || nb < 1) return 1;
             resident[k] = nb * ncu;
         }
         const long long bpc = (chunks + 512ll * nis[k] - 1) / (512ll * nis[k]);
@@ -478,8 +496,12 @@ static int gn_fused_fwd_try(const void* x, void* y, int N, long long npix, int C
     a.part = reinterpret_cast<unsigned long long*>(ws);
     if (hipMemsetAsync(a.part, 0xFF, sizeof(unsigned long long) * (size_t)N * best_bpc * G, s) != hipSuccess) return 1;
     const dim3 grid(best_R * best_bpc);
-    if (best_ni == 0) gn_fused_fwd_kernel<4><<<grid, 512, 0, s>>>(a);
-    else gn_fused_fwd_kernel<2><<<grid, 512, 0, s>>>(a);
+    switch (best_ni) {
+        case 0: gn_fused_fwd_kernel<4, 2><<<grid, 512, 0, s>>>(a); break;
+        case 1: gn_fused_fwd_kernel<2, 2><<<grid, 512, 0, s>>>(a); break;
+        case 2: gn_fused_fwd_kernel<8, 1><<<grid, 512, 0, s>>>(a); break;
+        default: gn_fused_fwd_kernel<4, 1><<<grid, 512, 0, s>>>(a); break;
+    }
     GENIE_CHECK_LAUNCH();
     return 0;
 }

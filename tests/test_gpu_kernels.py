@@ -177,9 +177,10 @@ def test_groupnorm_one_pass_forward_behind_its_switch():
     import subprocess
     import sys
     from util import ROOT
-    env = dict(os.environ, GENIE_GN_FUSED='1')
-    r = subprocess.run([sys.executable, '-c', _ONE_PASS_CHECK], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and 'one-pass ok' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    for mode in ('1', '2'):                              # two register sets with the exchange pipelined / one set, two clips de-phased
+        env = dict(os.environ, GENIE_GN_FUSED=mode)
+        r = subprocess.run([sys.executable, '-c', _ONE_PASS_CHECK], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and 'one-pass ok' in r.stdout, (mode, r.stdout[-2000:] + r.stderr[-4000:])
 
 
 CONV_CASES = [
