@@ -59,10 +59,14 @@ class DynamicsModel(nn.Module):
         logits = self._head(self._trunk(tokens, act_id))
         return logits, logits[:, -1]
 
-    def compute_loss(self, tokens: Tensor, act_id: Tensor, mask: Tensor | None = None, fill: float = 0.) -> Tensor:
+    def compute_loss(self, tokens: Tensor, act_id: Tensor, mask: Tensor | None = None, fill: float = 0., fixed_rows: bool = False) -> Tensor:
+        """`fixed_rows`: the same loss with SHAPES that do not depend on the mask -- the masked rows are moved to the front by a stable
+        device-side sort, the vocabulary head runs over all B*T*h*w rows and the cross-entropy switches the others off.  Costs the head
+        GEMMs of the unmasked rows (a quarter of them on average) and buys a step without host round trips or data-dependent launches,
+        i.e. one that a hipGraph can replay (genie/graph.py; the mask is then an INPUT of the step, drawn by the caller)."""
         b, t, h, w = tokens.shape
         mask = default(mask, torch.distributions.Bernoulli(torch.empty(1).uniform_(0.5, 1).item()).sample((b, t, h, w)).bool())
-        host_mask = mask if mask.device.type == 'cpu' else None
+        host_mask = mask if mask.device.type == 'cpu' and not fixed_rows else None
         mask = mask.to(tokens.device)
         tokens = torch.masked_fill(tokens, mask, fill)
         m = mask.squeeze()
@@ -77,6 +81,17 @@ class DynamicsModel(nn.Module):
         # cross-entropy and their backward on them alone (a Bernoulli(0.5 .. 1) mask drops a quarter of the 2^18-wide rows on average);
         # the fused genie_masked_ce_fwd / _bwd then never materialise the gathered rows' fp32 copy or their softmax.
         # A mask that lives on the host (the default one does) gives the row list without a device round trip.
+        if fixed_rows:
+            flat = m.reshape(-1)
+            total = flat.numel()
+            order = torch.argsort((~flat).to(torch.uint8), stable=True)        # masked rows first, in their original order
+            gt, gh, rp = self._compact_grid(total)
+            rows = order if rp == total else torch.cat([order, order.new_zeros(rp - total)])
+            valid = torch.arange(rp, device=rows.device) < flat.sum()          # (no masked row at all: 0 / 0 = NaN, as F.cross_entropy)
+            x = self._trunk(tokens, act_id.detach())
+            d = x.shape[-1]
+            xc = x.reshape(-1, d).index_select(0, rows).view(1, gt, gh, 256, d)
+            return GF.masked_cross_entropy(self._head(xc), tokens.reshape(-1).index_select(0, rows).view(1, gt, gh, 256), valid)
         flat = (host_mask.squeeze() if host_mask is not None else m).reshape(-1)
         rows = flat.nonzero().squeeze(1).to(tokens.device)
         x = self._trunk(tokens, act_id.detach())

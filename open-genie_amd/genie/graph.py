@@ -9,7 +9,8 @@ What makes the step capturable: every launch goes to the current stream through 
 torch's allocator (the graph's private pool during capture); tap / step tables and weight packs are device tensors cached at first use
 (the warm-up steps); nothing on the path reads a device value on the host; and the only launch arguments that change from step to step --
 AdamW's step count and the learning rate -- live in device memory (``genie_adamw_step_graph``).  Shapes are fixed: a new batch is copied
-into the captured input buffer.  Data-dependent shapes (the DynamicsModel's gather of masked rows) cannot be captured.
+into the captured input buffers.  Data-dependent shapes cannot be captured: the DynamicsModel's default loss gathers the masked rows
+(their number varies); ``compute_loss(..., fixed_rows=True)`` is its shape-stable form, with the mask as an input of the step.
 """
 from typing import Callable, Optional
 
@@ -20,26 +21,30 @@ from .trainer import ParamArena
 
 
 class GraphedTrainStep:
-    def __init__(self, model: torch.nn.Module, arena: ParamArena, example: Tensor, loss_fn: Optional[Callable] = None, lr: float = 1e-3,
+    def __init__(self, model: torch.nn.Module, arena: ParamArena, example, loss_fn: Optional[Callable] = None, lr: float = 1e-3,
                  betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2, warmup: int = 2) -> None:
         """`example`: a batch of the shape every step will have (its values are used by the `warmup` eager steps and by the capture
         step -- all of them REAL optimiser steps on `example`; ``warmup=0`` when the caller has already trained eagerly for a step or
         two, as ``Trainer.fit(graph=True)`` does).  `loss_fn(model, batch)` returns the loss (or a tuple whose first element is the
         loss); default ``model(batch)``."""
         from . import functional as GF
-        if not example.is_cuda:
+        self._single = torch.is_tensor(example)
+        examples = (example,) if self._single else tuple(example)
+        if not examples or not all(torch.is_tensor(e) and e.is_cuda for e in examples):
             raise ValueError('GraphedTrainStep needs CUDA tensors (no CPU path)')
+        example = examples[0]
         if GF.ASYNC_WGRAD:
             raise RuntimeError('GraphedTrainStep: capture the in-order step (functional.ASYNC_WGRAD = 0); the side streams are not part of it')
         self.model, self.arena = model, arena
         self.loss_fn = loss_fn if loss_fn is not None else (lambda m, b: m(b))
         self.betas, self.eps = betas, eps
-        self.batch = example.clone()
+        self.batches = tuple(e.clone() for e in examples)   # the captured input buffers (a batch may be several tensors: tokens, actions, mask)
+        self.batch = self.batches[0]
         arena.set_graph_hyperparameters(lr, weight_decay)
         self.steps_done = 0
 
         def step():
-            out = self.loss_fn(self.model, self.batch)
+            out = self.loss_fn(self.model, self.batch if self._single else self.batches)
             loss = out[0] if isinstance(out, (tuple, list)) else out
             loss.backward()
             arena.adamw_step(betas=self.betas, eps=self.eps, graph_safe=True)
@@ -66,12 +71,17 @@ class GraphedTrainStep:
         if weight_decay is not None:
             st[2:3].fill_(float(weight_decay))
 
-    def __call__(self, batch: Tensor) -> Tensor:
-        """One optimiser step on `batch` (same shape / dtype as the example).  Returns the captured loss tensor (overwritten by the
-        next call)."""
-        if batch.shape != self.batch.shape or batch.dtype != self.batch.dtype:
-            raise ValueError(f'GraphedTrainStep: batch {tuple(batch.shape)} {batch.dtype} != captured {tuple(self.batch.shape)} {self.batch.dtype}')
-        self.batch.copy_(batch, non_blocking=True)
+    def __call__(self, *batch: Tensor) -> Tensor:
+        """One optimiser step on `batch` (the tensors of the example, same shapes / dtypes).  Returns the captured loss tensor (overwritten
+        by the next call)."""
+        if len(batch) == 1 and not torch.is_tensor(batch[0]):
+            batch = tuple(batch[0])
+        if len(batch) != len(self.batches):
+            raise ValueError(f'GraphedTrainStep: {len(batch)} tensors, captured {len(self.batches)}')
+        for src, dst in zip(batch, self.batches):
+            if src.shape != dst.shape or src.dtype != dst.dtype:
+                raise ValueError(f'GraphedTrainStep: batch {tuple(src.shape)} {src.dtype} != captured {tuple(dst.shape)} {dst.dtype}')
+            dst.copy_(src, non_blocking=True)
         self.graph.replay()
         self.arena.step_count += 1
         self.steps_done += 1

@@ -177,6 +177,18 @@ def main():
             res.append(eager_vs_graph(f'VideoTokenizer MAGVIT2 (configs[1]) at {B} clips per GPU [frames/s]', build_tok, v, B * 16, lambda m, b: m(b)[0]))
         v = torch.randn(2, 3, 16, 64, 64, device='cuda')
         res.append(eager_vs_graph('LatentAction (configs[2]) B=2 [frames/s]', build_lam, v, 2 * 16, lambda m, b: m(b)[1]))
+
+        # DynamicsModel (configs[3]): the default loss gathers the masked rows (a data-dependent row count: eager only); fixed_rows=True is
+        # its shape-stable form -- eager vs replayed.  The eager gathered-rows step is the `dyn` entry of this script.
+        def build_dyn():
+            torch.manual_seed(0)
+            return DynamicsModel((('space-time_attn', {'n_rep': 8, 'n_head': 8, 'd_head': 64}),), tok_vocab=2 ** 18, act_vocab=8, embed_dim=512).cuda().train()
+        B = 4
+        gm = torch.Generator(device='cuda').manual_seed(1)
+        batch = (torch.randint(0, 2 ** 18, (B, 16, 8, 8), device='cuda', generator=gm), torch.randint(0, 8, (B, 16), device='cuda', generator=gm),
+                 torch.rand(B, 16, 8, 8, device='cuda', generator=gm) < 0.75)
+        res.append(eager_vs_graph(f'DynamicsModel (configs[3]) B={B}, shape-stable loss (fixed_rows) [latent frames/s]', build_dyn, batch, B * 16,
+                                  lambda m, b: m.compute_loss(b[0], b[1], mask=b[2], fixed_rows=True)))
     os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
     tag = '_'.join(which)
     json.dump(res, open(os.path.join(ROOT, 'gpurun_out', f'bench_models_{tag}.json'), 'w'), indent=1)

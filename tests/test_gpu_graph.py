@@ -141,3 +141,55 @@ def test_trainer_fit_with_graph_matches_eager_fit(tmp_path):
     assert rel <= 1e-4, rel                  # the eager run uses the scalar-argument AdamW, the graph run the device-state form (1 ulp in the step size)
     ck = torch.load(str(tmp_path / 'g1' / 'last.ckpt'), map_location='cpu')
     assert ck['global_step'] == 6 and all(v['step'] == 6 for v in ck['optimizer_states'][0]['state'].values())
+
+
+def test_dynamics_fixed_rows_loss_and_graph_replay():
+    """DynamicsModel.compute_loss(fixed_rows=True) -- masked rows sorted to the front, the head over all rows, the others switched off in
+    the cross-entropy -- gives the loss and the gradients of the gathered-rows form on the same mask (also for an all-False and an all-True
+    mask), and with it the Dynamics step replays as a hipGraph: token / action / mask buffers as inputs, losses equal to the eager loop."""
+    from genie.dynamics import DynamicsModel
+    from genie.graph import GraphedTrainStep
+    from genie.trainer import ParamArena
+    desc = (('space-time_attn', {'n_rep': 2, 'n_head': 2, 'd_head': 32}),)
+
+    def build():
+        torch.manual_seed(11)
+        return DynamicsModel(desc, tok_vocab=256, act_vocab=5, embed_dim=64).cuda().train()
+
+    g = torch.Generator(device='cuda').manual_seed(3)
+    data = [(torch.randint(0, 256, (2, 5, 4, 4), device='cuda', generator=g), torch.randint(0, 5, (2, 5), device='cuda', generator=g),
+             torch.rand(2, 5, 4, 4, device='cuda', generator=g) < 0.7) for _ in range(5)]
+    # the two forms of the loss on one mask
+    m = build()
+    tok, act, mask = data[0]
+    la = m.compute_loss(tok, act, mask=mask)
+    la.backward()
+    ga = {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+    for p in m.parameters():
+        p.grad = None
+    lb = m.compute_loss(tok, act, mask=mask, fixed_rows=True)
+    lb.backward()
+    assert abs(la.item() - lb.item()) <= 1e-6 * abs(la.item())
+    for n, p in m.named_parameters():
+        if n in ga:
+            err = (p.grad - ga[n]).norm().item() / (ga[n].norm().item() + 1e-12)
+            assert err < 1e-3, (n, err)
+    full = m.compute_loss(tok, act, mask=torch.ones_like(mask), fixed_rows=True)
+    assert abs(full.item() - m.compute_loss(tok, act, mask=torch.ones_like(mask)).item()) <= 1e-6 * abs(full.item())
+    assert torch.isnan(m.compute_loss(tok, act, mask=torch.zeros_like(mask), fixed_rows=True))
+    # graph replay against the eager loop (both with the shape-stable loss and the device-state AdamW)
+    loss_fn = lambda mod, b: mod.compute_loss(b[0], b[1], mask=b[2], fixed_rows=True)
+    seq = [data[0]] * 3 + data[1:]
+    me = build()
+    ae = ParamArena(me); ae.attach_weight_packs(me); ae.set_graph_hyperparameters(1e-3, 0.01)
+    eager = []
+    for b in seq:
+        l = loss_fn(me, b); l.backward(); ae.adamw_step(graph_safe=True); eager.append(l.item())
+    mg = build()
+    ag = ParamArena(mg); ag.attach_weight_packs(mg)
+    gs = GraphedTrainStep(mg, ag, data[0], loss_fn=loss_fn, lr=1e-3, weight_decay=0.01, warmup=2)
+    replay = [gs.loss.item()] + [gs(*b).item() for b in data[1:]]
+    dl = max(abs(a - b) for a, b in zip(eager[2:], replay))
+    rel = ((ae.params - ag.params).norm() / ae.params.norm()).item()
+    report('dynamics_graph_replay', max_loss_diff=dl, rel_l2_param_diff=rel, steps=len(replay))
+    assert dl <= 1e-4 * abs(eager[-1]) and rel <= 1e-4, (eager, replay, rel)
