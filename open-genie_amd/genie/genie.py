@@ -115,6 +115,10 @@ class Genie(LightningModule):
         self.log_dict({f'{prefix}_loss': loss, **{f'{prefix}/{k}': v for k, v in aux}}, logger=True, on_step=True, sync_dist=True)
         return loss
 
+    # Trainer(graph=True): no -- the dynamics mask is drawn on the host inside compute_loss (a replay would reuse ONE mask); the shape-stable
+    # DynamicsModel.compute_loss(fixed_rows=True) with the mask as an input is the capturable building block (genie/graph.py)
+    graph_capture_safe = False
+
     def training_step(self, batch: Tensor, batch_idx: int) -> Tensor:
         return self._step(batch, 'train')
 

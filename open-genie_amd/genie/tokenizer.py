@@ -203,6 +203,12 @@ class VideoTokenizer(LightningModule):
     def training_step(self, batch: Tensor, batch_idx: int) -> Tensor:
         return self._step(batch, 'train')
 
+    @property
+    def graph_capture_safe(self) -> bool:
+        """May ``Trainer(graph=True)`` record this model's training step once and replay it?  Yes without the GAN critic (its random frame
+        choice is drawn per step); the rest of the step is shape-stable device work with no host round trip."""
+        return not (self.gan_loss_weight > 0)
+
     def validation_step(self, batch: Tensor, batch_idx: int) -> Tensor:
         return self._step(batch, 'val')
 

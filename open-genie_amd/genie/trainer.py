@@ -574,6 +574,9 @@ class Trainer:
         done = self.max_steps is not None and self.global_step >= self.max_steps
         epoch = start_epoch
         use_graph = self.graph and not dp.active
+        if use_graph and not getattr(model, 'graph_capture_safe', False):
+            raise ValueError(f'Trainer(graph=True): the training step of {type(model).__name__} draws per-step randomness on the host (or does not say '
+                             'otherwise: `graph_capture_safe`); a replayed hipGraph would repeat it.  Train it eagerly.')
         gstep, eager_steps = None, 0
         side = None
         if use_graph:

@@ -141,6 +141,12 @@ def test_trainer_fit_with_graph_matches_eager_fit(tmp_path):
     assert rel <= 1e-4, rel                  # the eager run uses the scalar-argument AdamW, the graph run the device-state form (1 ulp in the step size)
     ck = torch.load(str(tmp_path / 'g1' / 'last.ckpt'), map_location='cpu')
     assert ck['global_step'] == 6 and all(v['step'] == 6 for v in ck['optimizer_states'][0]['state'].values())
+    # a model whose step draws per-step randomness outside the graph's reach is refused, not silently replayed with one draw
+    m = _model()
+    m.gan_loss_weight = 1.0
+    assert not m.graph_capture_safe
+    with pytest.raises(ValueError, match='graph'):
+        Trainer(max_steps=2, default_root_dir=str(tmp_path / 'g2'), graph=True).fit(m, data())
 
 
 def test_dynamics_fixed_rows_loss_and_graph_replay():
