@@ -37,8 +37,12 @@ class Genie(LightningModule):
                  inp_shape: int | Tuple[int, int] = (64, 64), ker_size: int | Tuple[int, int] = 3, n_embd: int = 256, n_codebook: int = 1,
                  lfq_bias: bool = True, lfq_frac_sample: float = 1., lfq_commit_weight: float = 0.25, lfq_entropy_weight: float = 0.1,
                  lfq_diversity_weight: float = 1., dyn_desc: Blueprint = DYNAMICS_DESC, tok_codebook: int | None = None,
-                 act_codebook: int | None = None, embed_dim: int = 512) -> None:
+                 act_codebook: int | None = None, embed_dim: int = 512, device_masks: bool = False) -> None:
         super().__init__()
+        # device_masks (not in the reference): draw the MaskGIT training mask on the DEVICE (rate ~ U(0.5, 1), mask = rand < rate: the
+        # distribution of the reference's Bernoulli(uniform(0.5, 1)) from the device generator instead of the host's) and use the
+        # shape-stable dynamics loss -- the training step then has no host round trip and can be replayed as a hipGraph (Trainer(graph=True))
+        self.device_masks = bool(device_masks)
         self.tokenizer = tokenizer
         for p in self.tokenizer.parameters():                     # pre-trained and frozen (reference genie.py:34 "Pre-trained video tokenizer")
             p.requires_grad_(False)
@@ -106,7 +110,12 @@ class Genie(LightningModule):
         tf = video.shape[2] // tokens.shape[1]                                  # the tokenizer's time compression
         if tf < 1 or tf * tokens.shape[1] != video.shape[2]:
             raise ValueError(f'{video.shape[2]} video frames do not map onto {tokens.shape[1]} latent frames')
-        dyn_loss = self.dynamics_model.compute_loss(tokens, act_id[:, tf - 1::tf].detach())
+        if self.device_masks:
+            rate = torch.empty((), device=tokens.device).uniform_(0.5, 1.)
+            mask = torch.rand(tokens.shape, device=tokens.device) < rate
+            dyn_loss = self.dynamics_model.compute_loss(tokens, act_id[:, tf - 1::tf].detach(), mask=mask, fixed_rows=True)
+        else:
+            dyn_loss = self.dynamics_model.compute_loss(tokens, act_id[:, tf - 1::tf].detach())
         loss = act_loss + dyn_loss
         return loss, (('act_loss', act_loss), ('dyn_loss', dyn_loss), ('act_rec_loss', act_rec_loss), ('act_q_loss', act_q_loss))
 
@@ -115,9 +124,11 @@ class Genie(LightningModule):
         self.log_dict({f'{prefix}_loss': loss, **{f'{prefix}/{k}': v for k, v in aux}}, logger=True, on_step=True, sync_dist=True)
         return loss
 
-    # Trainer(graph=True): no -- the dynamics mask is drawn on the host inside compute_loss (a replay would reuse ONE mask); the shape-stable
-    # DynamicsModel.compute_loss(fixed_rows=True) with the mask as an input is the capturable building block (genie/graph.py)
-    graph_capture_safe = False
+    @property
+    def graph_capture_safe(self) -> bool:
+        """Trainer(graph=True)?  Only with ``device_masks``: the default dynamics mask is drawn on the host inside compute_loss and its
+        masked rows are gathered with a data-dependent count -- a replay would reuse ONE mask."""
+        return self.device_masks
 
     def training_step(self, batch: Tensor, batch_idx: int) -> Tensor:
         return self._step(batch, 'train')

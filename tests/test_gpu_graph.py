@@ -199,3 +199,28 @@ def test_dynamics_fixed_rows_loss_and_graph_replay():
     rel = ((ae.params - ag.params).norm() / ae.params.norm()).item()
     report('dynamics_graph_replay', max_loss_diff=dl, rel_l2_param_diff=rel, steps=len(replay))
     assert dl <= 1e-4 * abs(eager[-1]) and rel <= 1e-4, (eager, replay, rel)
+
+
+def test_genie_step_with_device_masks_replays_and_redraws():
+    """Genie(device_masks=True): the training step (frozen tokenizer -> latent actions -> MaskGIT dynamics loss on a device-drawn mask) is
+    shape-stable and replays as a hipGraph; every replay draws a NEW mask (with the learning rate at 0 the loss still changes from replay
+    to replay), and Trainer(graph=True) accepts the model."""
+    from genie.graph import GraphedTrainStep
+    from genie.trainer import ParamArena
+    from test_gpu_genie import _genie
+    g = _genie()
+    g.device_masks = True
+    g = g.cuda().train()
+    g.tokenizer.eval()
+    assert g.graph_capture_safe
+    video = torch.rand(2, 3, 8, 16, 16, device='cuda')
+    arena = ParamArena(g)
+    arena.attach_weight_packs(g)
+    gs = GraphedTrainStep(g, arena, video, loss_fn=lambda m, b: m.compute_loss(b)[0], lr=1e-3, weight_decay=0.0, warmup=2)
+    assert torch.isfinite(gs.loss).item()
+    gs.set_lr(0.0)
+    before = arena.params.clone()
+    losses = [gs(video).item() for _ in range(4)]
+    assert torch.equal(before, arena.params)
+    assert all(l == l for l in losses) and len(set(losses)) > 1, losses          # same weights, same clip: only the mask can move the loss
+    report('genie_graph_device_masks', losses_at_lr0=[round(l, 5) for l in losses])
