@@ -185,3 +185,25 @@ def test_dynamics_compact_row_grid():
         assert rp == gt * gh * 256 and rp >= r
         assert 1 <= gt < 1024 and 1 <= gh < 1024
         assert rp - r < (256 if r <= 131072 else 512 * 256)
+
+
+def test_graph_capture_declarations():
+    """Which training steps Trainer(graph=True) may record once and replay: the tokenizer without its GAN critic (the critic draws random
+    frames per step); Genie only with device-drawn masks (its default draws the MaskGIT mask on the host and gathers a data-dependent number
+    of rows).  And the step wrapper refuses host tensors -- there is no CPU path to capture."""
+    from genie import Genie, VideoTokenizer
+    from genie.graph import GraphedTrainStep
+    from genie.trainer import ParamArena
+    g = torch.load(os.path.join(GOLD, 'tokenizer_small.pt'), weights_only=False)
+    tok = VideoTokenizer(g['enc_desc'], g['dec_desc'], d_codebook=g['d_codebook'], gan_loss_weight=0., perc_loss_weight=0.)
+    assert tok.graph_capture_safe
+    tok_gan = VideoTokenizer(g['enc_desc'], g['dec_desc'], d_codebook=6, perc_loss_weight=0., disc_kwargs={'inp_size': 16, 'model_dim': 8})
+    assert not tok_gan.graph_capture_safe
+    lam = (('space-time_attn', {'n_head': 2, 'd_head': 32, 'transpose': True}),)
+    dyn = (('space-time_attn', {'n_rep': 1, 'n_head': 2, 'd_head': 32}),)
+    for flag in (False, True):
+        gen = Genie(tok, enc_desc=lam, dec_desc=lam, d_codebook=4, inp_shape=(16, 16), n_embd=64, dyn_desc=dyn, embed_dim=64, device_masks=flag)
+        assert gen.graph_capture_safe is flag
+    fresh = VideoTokenizer(g['enc_desc'], g['dec_desc'], d_codebook=g['d_codebook'], gan_loss_weight=0., perc_loss_weight=0.)   # (Genie froze `tok`)
+    with pytest.raises(ValueError, match='CUDA'):
+        GraphedTrainStep(fresh, ParamArena(fresh), torch.zeros(1, 3, 4, 16, 16))
