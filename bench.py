@@ -246,7 +246,7 @@ def main():
 
     from genie import MAGVIT2_DEC_DESC, MAGVIT2_ENC_DESC, VideoTokenizer, conv as gconv
     from genie import functional as GF
-    from genie.trainer import DataParallel, ParamArena, sync_replicas
+    from genie.trainer import DataParallel, ParamArena, Trainer, sync_replicas
     GF.ASYNC_WGRAD = int(args.async_wgrad)
 
     torch.manual_seed(0)
@@ -256,8 +256,8 @@ def main():
     arena.attach_weight_packs(model)                       # bf16 packs ride on the optimiser kernel + one batched transpose
     dp = DataParallel(arena.grads, compress=args.grad_compress, loopback=args.dp_loopback)
     if dp.active:                                          # decoder gradients reduce while the encoder is still in backward
-        layers = [m_ for m_ in list(model.enc_layers) + list(model.dec_layers) if any(p_.requires_grad for p_ in m_.parameters())]
-        dp.install_overlap_hooks(arena, model, DataParallel.equal_byte_cuts(arena, model, layers, max(1, args.buckets)))
+        # the same cut rule Trainer.fit applies (genie/trainer.py::Trainer.bucket_modules): the bench measures the path users run
+        dp.install_overlap_hooks(arena, model, Trainer.bucket_modules(arena, model, max(1, args.buckets)))
     B = args.batch
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)      # rank r holds clips r::world of the synthetic stream
     clips = [torch.randn(B, *CLIP, device=dev, generator=gen) for _ in range(2)]

@@ -69,7 +69,8 @@ class DynamicsModel(nn.Module):
         host_mask = mask if mask.device.type == 'cpu' and not fixed_rows else None
         mask = mask.to(tokens.device)
         tokens = torch.masked_fill(tokens, mask, fill)
-        m = mask.squeeze()
+        # (fixed_rows: the shape-stable form never needs the reference's squeeze(), so a batch of ONE clip stays capturable)
+        m = mask.reshape(tokens.shape) if fixed_rows else mask.squeeze()
         if m.shape != tokens.shape:
             # batch 1: the reference's mask.squeeze() drops the batch axis and its boolean indexing misbehaves; same code, same fate
             logits, _ = self(tokens, act_id.detach())

@@ -406,6 +406,13 @@ class SpaceTimeUpsample(Upsample):
 
     def forward(self, inp: Tensor, **kwargs) -> Tensor:
         w = self.go_up.weight                                               # (in, out, p, q, r)
+        # the conv kernels see a DERIVED copy of the parameter (fresh tensor every call: version 0, and the caching allocator tends to
+        # hand back the same address), so ConvOp's (version, address) key cannot notice an optimiser step / load_state_dict
+        # (ADVICE r3): key the packs on the PARAMETER and drop them whenever it has changed
+        pkey = (w._version, w.data_ptr())
+        if getattr(self, '_pack_key', None) != pkey:
+            self.op._fwd = self.op._bwd = (None, None)
+            self._pack_key = pkey
         rows = self.out_channels * self.fac[0] * self.fac[1] * self.fac[2]
         w_conv = w.permute(1, 2, 3, 4, 0).reshape(rows, self.in_channels)[:, :, None, None, None]      # row (c p q r), column in
         b = self.go_up.bias

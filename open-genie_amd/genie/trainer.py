@@ -471,15 +471,28 @@ class Trainer:
 
     def __init__(self, max_epochs: int = 1, max_steps: int = -1, log_every_n_steps: int = 16, val_check_interval: int | None = None,
                  limit_val_batches: int | None = None, default_root_dir: str = 'runs', grad_compress: Optional[str] = None,
-                 graph: bool = False, **ignored) -> None:
+                 graph: bool = False, grad_buckets: int = 8, **ignored) -> None:
         # graph: after two eager steps the training step (forward, backward, AdamW) is captured in a hipGraph and replayed per batch
         # (genie/graph.py; single-GPU runs, batches of the captured shape -- anything else takes the eager path)
         self.graph = bool(graph)
+        self.grad_buckets = max(1, int(grad_buckets))
         self.max_epochs, self.max_steps = max_epochs, (max_steps if max_steps and max_steps > 0 else None)
         self.log_every_n_steps, self.val_check_interval, self.limit_val_batches = max(1, log_every_n_steps), val_check_interval, limit_val_batches
         self.default_root_dir, self.grad_compress, self.ignored = default_root_dir, grad_compress, dict(ignored)
         self.global_step = 0
         self.history: List[dict] = []
+
+    @staticmethod
+    def bucket_modules(arena: ParamArena, model, nbuckets: int = 8) -> list:
+        """Where fit() cuts the gradient arena for the overlapped all-reduce: `nbuckets` buckets of (nearly) equal BYTES plus a small first
+        one, chosen among the LAYERS of the model's stages (``DataParallel.equal_byte_cuts``) -- the same rule ``bench.py --gpus N`` uses,
+        so the scaling bench measures the path users run (round 3 cut one bucket per top-level stage here: two or
+        three buckets of very unequal size)."""
+        layers = []
+        for stage in model.forward_order():
+            subs = list(stage) if isinstance(stage, nn.ModuleList) else [stage]
+            layers += [m for m in subs if any(p.requires_grad for p in m.parameters())]
+        return DataParallel.equal_byte_cuts(arena, model, layers, nbuckets)
 
     @staticmethod
     def _adamw_hparams(model) -> dict:
@@ -490,7 +503,9 @@ class Trainer:
         return dict(lr=d['lr'], betas=tuple(d['betas']), eps=d['eps'], weight_decay=d['weight_decay'])
 
     def _log(self, model, dp: 'DataParallel', tag: str) -> dict:
-        logged = getattr(model, '_last_logged', {})
+        # 'train' lines report what the last TRAINING step logged: a validation pass in between overwrites model._last_logged, and a
+        # hipGraph replay never re-enters Python to refresh it -- the replayed step's metrics are the captured tensors
+        logged = (getattr(self, '_train_logged', None) if tag == 'train' else None) or getattr(model, '_last_logged', {})
         keys = sorted(logged)
         vals = dp.reduce_scalars([logged[k] for k in keys]) if keys else torch.zeros(0)
         rec = {'step': self.global_step, 'split': tag, **{k: round(v, 6) for k, v in zip(keys, vals.tolist())}}
@@ -512,10 +527,13 @@ class Trainer:
         self._log(model, dp, 'val')
 
     def save_last(self, model, arena: Optional[ParamArena] = None, hp: Optional[dict] = None, epoch: int = 0) -> str:
-        """``last.ckpt`` in the layout of a Lightning checkpoint (``ModelCheckpoint(save_last=True)`` of the reference's config,
+        """``last.ckpt`` with the top-level keys of a Lightning checkpoint (``ModelCheckpoint(save_last=True)`` of the reference's config,
         config/tokenize.yaml:80-86): ``state_dict``, ``global_step``, ``epoch`` and ``optimizer_states`` -- AdamW's step / exp_avg /
-        exp_avg_sq per parameter (keyed by parameter NAME, so a resume does not depend on the arena layout) -- which is what makes the
-        run resumable (``fit(ckpt_path=...)``).  Tensors are copied to the host one at a time."""
+        exp_avg_sq per parameter -- which is what makes the run resumable HERE (``fit(ckpt_path=...)``).  Interoperability with the
+        reference is limited to ``state_dict`` (``VideoTokenizer.load_state_dict`` / the reference's ``load_from_checkpoint`` with
+        ``strict`` keys): the optimiser state is keyed by parameter NAME (so that a resume does not depend on the arena layout) with a
+        plain-int ``step``, where torch / Lightning key by integer index, and ``hyper_parameters`` / ``pytorch-lightning_version`` are
+        not written -- a Lightning ``Trainer(resume)`` cannot consume the optimiser part.  Tensors go to the host one at a time."""
         import os
         path = os.path.join(self.default_root_dir, 'last.ckpt')
         if not dist.is_initialized() or dist.get_rank() == 0:
@@ -567,10 +585,7 @@ class Trainer:
         self.arena = arena
         dp = DataParallel(arena.grads, compress=self.grad_compress)
         if dp.active and hasattr(model, 'forward_order'):
-            # one bucket per top-level stage that owns parameters; the first stage's bucket is reduced by finish()
-            stages = [m for m in model.forward_order() if any(p.requires_grad for p in m.parameters())]
-            if len(stages) > 1:
-                dp.install_overlap_hooks(arena, model, stages[1:])
+            dp.install_overlap_hooks(arena, model, self.bucket_modules(arena, model, self.grad_buckets))
         done = self.max_steps is not None and self.global_step >= self.max_steps
         epoch = start_epoch
         use_graph = self.graph and not dp.active
@@ -595,8 +610,9 @@ class Trainer:
 
     def _epochs(self, model, datamodule, dp, arena, hp, start_epoch: int, skip: int, done: bool, use_graph: bool) -> int:
         from .module.data import DevicePrefetcher
-        gstep, eager_steps = None, 0
+        gstep, eager_steps, graph_logged = None, 0, None
         epoch = start_epoch
+        self._batches_done = skip          # a resume that is already at max_steps never enters the loop: keep the saved position
         for epoch in range(start_epoch, self.max_epochs if not done else start_epoch):
             loader = datamodule.train_dataloader()
             if hasattr(getattr(loader, 'sampler', None), 'set_epoch'):
@@ -608,16 +624,19 @@ class Trainer:
                     continue
                 if gstep is not None and torch.is_tensor(batch) and batch.shape == gstep.batch.shape and batch.dtype == gstep.batch.dtype:
                     gstep(batch)                                  # one replay: forward, backward, AdamW
+                    self._train_logged = graph_logged             # the tensors the captured training_step logged, rewritten by the replay
                 elif use_graph and gstep is None and eager_steps >= 2 and torch.is_tensor(batch):
                     from .graph import GraphedTrainStep
                     gstep = GraphedTrainStep(model, arena, batch, loss_fn=lambda m, b: m.training_step(b, 0), lr=hp['lr'], betas=hp['betas'],
                                              eps=hp['eps'], weight_decay=hp['weight_decay'], warmup=0)      # captures AND performs this step
+                    graph_logged = self._train_logged = dict(getattr(model, '_last_logged', {}))
                 else:
                     loss = model.training_step(batch, i)
                     loss.backward()
                     dp.finish()
                     arena.adamw_step(**hp, graph_safe=use_graph)
                     eager_steps += 1
+                    self._train_logged = dict(getattr(model, '_last_logged', {}))
                 self.global_step += 1
                 self._batches_done = i + 1
                 if self.global_step % self.log_every_n_steps == 0:

@@ -211,3 +211,33 @@ def test_world_size_2_module_arena_hooks_bf16_compress():
 def test_world_size_2_replica_sync_and_container_stages():
     res = _run(_sync_worker)
     assert res[0][1] == res[1][1]
+
+
+def test_fit_cuts_buckets_like_the_bench():
+    """Trainer.fit and bench.py share ONE cut rule (Trainer.bucket_modules -> DataParallel.equal_byte_cuts over the LAYERS of the model's
+    stages): buckets of nearly equal bytes plus a small first one, in forward order, all of them installable."""
+    import sys
+    for p_ in (ROOT, os.path.join(ROOT, 'open-genie_amd')):
+        if p_ not in sys.path:
+            sys.path.insert(0, p_)
+    from genie.trainer import DataParallel, ParamArena, Trainer
+
+    class Wide(_Toy):
+        def __init__(self):
+            super().__init__(16)
+            self.enc = nn.ModuleList([_Block(16) for _ in range(8)])
+            self.dec = nn.ModuleList([_Block(16) for _ in range(8)])
+
+    torch.manual_seed(0)
+    m = Wide()
+    arena = ParamArena(m)
+    picks = Trainer.bucket_modules(arena, m, 4)
+    layers = list(m.enc) + [m.quant] + list(m.dec) + [m.late]
+    assert all(any(p is l for l in layers) for p in picks) and 2 <= len(picks) <= 4
+    offs = [arena.offset_of(p, m) for p in picks]
+    assert offs == sorted(offs) and offs[0] == min(o for o in (arena.offset_of(l, m) for l in layers) if o)      # small first bucket: what finish() reduces unhidden
+    assert all(min(abs(o - arena.numel * k / 4) for k in (1, 2, 3)) <= arena.numel / 8 for o in offs[1:])
+    dp = DataParallel(arena.grads)
+    dp.install_overlap_hooks(arena, m, picks)                                  # forward order + execution-order arena: accepted
+    assert len(dp.buckets) == len(picks) + 1
+    assert Trainer(grad_buckets=6).grad_buckets == 6

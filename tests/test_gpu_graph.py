@@ -141,6 +141,14 @@ def test_trainer_fit_with_graph_matches_eager_fit(tmp_path):
     assert rel <= 1e-4, rel                  # the eager run uses the scalar-argument AdamW, the graph run the device-state form (1 ulp in the step size)
     ck = torch.load(str(tmp_path / 'g1' / 'last.ckpt'), map_location='cpu')
     assert ck['global_step'] == 6 and all(v['step'] == 6 for v in ck['optimizer_states'][0]['state'].values())
+    # a validation pass between replays overwrites model._last_logged and a replay never re-enters Python to refresh it: 'train' lines must
+    # still report TRAINING metrics (the captured tensors), the final one included
+    m = _model()
+    tv = Trainer(max_steps=6, default_root_dir=str(tmp_path / 'gv'), log_every_n_steps=1, graph=True, val_check_interval=4,
+                 limit_val_batches=1).fit(m, data())
+    recs = [r for r in tv.history if r['split'] == 'train']
+    assert len(recs) >= 7 and all('train_loss' in r and not any(k.startswith('val') for k in r if k not in ('split',)) for r in recs), tv.history
+    assert any(r['split'] == 'val' and 'val_loss' in r for r in tv.history)
     # a model whose step draws per-step randomness outside the graph's reach is refused, not silently replayed with one draw
     m = _model()
     m.gan_loss_weight = 1.0

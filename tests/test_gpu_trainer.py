@@ -1,5 +1,7 @@
 """Training runtime on the MI355X: fused AdamW over the parameter arena against torch.optim.AdamW, and the bf16 weight packs
 that ride on the optimiser kernel (mirror + one batched transpose) against per-conv packing."""
+import os
+
 import pytest
 import torch
 
@@ -221,37 +223,171 @@ def test_async_wgrad_side_stream_matches_in_order_execution():
 
 def test_checkpoint_resume_continues_the_run(tmp_path):
     """last.ckpt carries the weights, AdamW's moments / step counter and the position in the epoch (the reference's
-    ModelCheckpoint(save_last) is resumable): 2 steps + resume + 2 steps == 4 steps straight, up to the atomic-add order of the weight
-    gradients."""
+    ModelCheckpoint(save_last) is resumable, config/tokenize.yaml:80-86): 2 steps + resume + 2 steps == 4 steps straight.
+
+    Two kinds of assertion (the old `rtol 1e-4` on every parameter failed on the driver's box because default-mode
+    weight gradients differ run to run by fp32 atomic order and AdamW's first steps turn a sign flip of a noise-level gradient into
+    +-lr per step):
+      * EXACT: what a resume restores -- parameters, both moments, step counter, bf16 mirror -- equals the state the first run
+        ended with, bit for bit (a load, no arithmetic).  A resume bug shows here.
+      * the continuation runs with ``conv.set_deterministic(True)`` (one K split per tile, single owner: weight gradients bit-identical
+        run to run), and is still only held to the AdamW-aware bound of test_async_wgrad_side_stream_matches_in_order_execution
+        (max <= 2 * steps * lr + eps, mean <= 2e-5) so that no leftover atomic in a reduction can turn it red."""
+    from genie import conv as gconv
     from genie.dataset import LightningSynthetic
-    from genie.trainer import Trainer
+    from genie.trainer import ParamArena, Trainer
 
     def data():
         return LightningSynthetic(num_clips=16, shape=(3, 4, 16, 16), seed=3, batch_size=2, num_workers=0, train_shuffle=False)
 
-    straight = _model()
-    Trainer(max_steps=4, default_root_dir=str(tmp_path / 'a'), log_every_n_steps=100).fit(straight, data())
-    first = _model()
-    Trainer(max_steps=2, default_root_dir=str(tmp_path / 'b'), log_every_n_steps=100).fit(first, data())
-    ck = torch.load(str(tmp_path / 'b' / 'last.ckpt'), map_location='cpu')
-    assert ck['global_step'] == 2 and ck['loops']['batches_done_in_epoch'] == 2
-    st = ck['optimizer_states'][0]['state']
-    assert set(st) == {n for n, p in first.named_parameters() if p.requires_grad}
-    assert all(v['step'] == 2 and v['exp_avg'].abs().sum() >= 0 for v in st.values())
-    resumed = _model()
-    with torch.no_grad():
-        for p in resumed.parameters():
-            p.add_(1.0)                                       # whatever the fresh model holds must be overwritten by the checkpoint
-    tr = Trainer(max_steps=4, default_root_dir=str(tmp_path / 'c'), log_every_n_steps=100).fit(resumed, data(), ckpt_path=str(tmp_path / 'b' / 'last.ckpt'))
-    assert tr.global_step == 4 and tr.arena.step_count == 4
-    for (n, a), (_, b) in zip(straight.named_parameters(), resumed.named_parameters()):
-        torch.testing.assert_close(a.detach(), b.detach(), rtol=1e-4, atol=1e-5, msg=n)
-    # the checkpoint's moments matter: zero them and the continuation leaves the straight run
-    ck2 = torch.load(str(tmp_path / 'b' / 'last.ckpt'), map_location='cpu')
-    for v in ck2['optimizer_states'][0]['state'].values():
-        v['exp_avg'].zero_(); v['exp_avg_sq'].zero_()
-    torch.save(ck2, str(tmp_path / 'b' / 'no_moments.ckpt'))
-    cold = _model()
-    Trainer(max_steps=4, default_root_dir=str(tmp_path / 'd'), log_every_n_steps=100).fit(cold, data(), ckpt_path=str(tmp_path / 'b' / 'no_moments.ckpt'))
-    diff = max((a.detach() - b.detach()).abs().max().item() for a, b in zip(straight.parameters(), cold.parameters()))
-    assert diff > 1e-4, diff
+    lr, steps = 1e-3, 4
+    old_det = gconv.set_deterministic(True)
+    try:
+        straight = _model()
+        Trainer(max_steps=steps, default_root_dir=str(tmp_path / 'a'), log_every_n_steps=100).fit(straight, data())
+        first = _model()
+        tr_first = Trainer(max_steps=2, default_root_dir=str(tmp_path / 'b'), log_every_n_steps=100).fit(first, data())
+        ck = torch.load(str(tmp_path / 'b' / 'last.ckpt'), map_location='cpu')
+        assert ck['global_step'] == 2 and ck['loops']['batches_done_in_epoch'] == 2
+        st = ck['optimizer_states'][0]['state']
+        assert set(st) == {n for n, p in first.named_parameters() if p.requires_grad}
+        assert all(v['step'] == 2 and v['exp_avg'].abs().sum() >= 0 for v in st.values())
+
+        # (1) exact: restore into a model holding garbage, compare with the state the first run ended with
+        probe = _model()
+        with torch.no_grad():
+            for p in probe.parameters():
+                p.add_(1.0)                                   # whatever the fresh model holds must be overwritten by the checkpoint
+        a_probe = ParamArena(probe)
+        Trainer.load_checkpoint(str(tmp_path / 'b' / 'last.ckpt'), probe, a_probe)
+        a_first = tr_first.arena
+        assert a_probe.step_count == a_first.step_count == 2
+        assert a_probe.order_names == a_first.order_names
+        assert torch.equal(a_probe.params, a_first.params), 'resume: parameters differ from the state that was saved'
+        assert torch.equal(a_probe.exp_avg, a_first.exp_avg) and torch.equal(a_probe.exp_avg_sq, a_first.exp_avg_sq), 'resume: AdamW moments'
+        a_probe.attach_weight_packs(probe)
+        assert torch.equal(a_probe.mirror, a_first.mirror), 'resume: bf16 weight mirror'
+        for (n, a), (_, b) in zip(first.named_buffers(), probe.named_buffers()):
+            assert torch.equal(a, b), n
+        del probe, a_probe
+
+        # (2) the continuation
+        resumed = _model()
+        with torch.no_grad():
+            for p in resumed.parameters():
+                p.add_(1.0)
+        tr = Trainer(max_steps=steps, default_root_dir=str(tmp_path / 'c'), log_every_n_steps=100).fit(resumed, data(), ckpt_path=str(tmp_path / 'b' / 'last.ckpt'))
+        assert tr.global_step == steps and tr.arena.step_count == steps
+        worst, mean_sum, count = 0.0, 0.0, 0
+        for (n, a), (_, b) in zip(straight.named_parameters(), resumed.named_parameters()):
+            dlt = (a.detach() - b.detach()).abs()
+            worst = max(worst, dlt.max().item())
+            mean_sum += dlt.sum().item(); count += dlt.numel()
+        assert worst <= 2 * 2 * lr + 5e-4, worst            # two steps after the resume, <= 2 * lr each where a gradient's sign flipped
+        assert mean_sum / count <= 2e-5, mean_sum / count
+        # the resumed run saw the SAME batches as steps 3 and 4 of the straight run (position in the epoch restored)
+        la, lb = [Trainer_last(tmp_path / k) for k in ('a', 'c')]
+        assert la['global_step'] == lb['global_step'] == steps
+        assert la['loops']['batches_done_in_epoch'] == lb['loops']['batches_done_in_epoch'] == steps
+
+        # the checkpoint's moments matter: zero them and the continuation leaves the straight run
+        ck2 = torch.load(str(tmp_path / 'b' / 'last.ckpt'), map_location='cpu')
+        for v in ck2['optimizer_states'][0]['state'].values():
+            v['exp_avg'].zero_(); v['exp_avg_sq'].zero_()
+        torch.save(ck2, str(tmp_path / 'b' / 'no_moments.ckpt'))
+        cold = _model()
+        Trainer(max_steps=steps, default_root_dir=str(tmp_path / 'd'), log_every_n_steps=100).fit(cold, data(), ckpt_path=str(tmp_path / 'b' / 'no_moments.ckpt'))
+        dl = [(a.detach() - b.detach()).abs() for a, b in zip(straight.parameters(), cold.parameters())]
+        cold_mean = sum(x.sum().item() for x in dl) / sum(x.numel() for x in dl)
+        assert cold_mean > 10 * max(mean_sum / count, 1e-6), (cold_mean, mean_sum / count)
+    finally:
+        gconv.set_deterministic(old_det)
+
+
+def Trainer_last(root):
+    return torch.load(str(root / 'last.ckpt'), map_location='cpu')
+
+
+def _rccl_rank(rank: int, world: int, port: int, q):
+    """One RCCL rank of test_two_rank_rccl_tokenizer_step (spawned: one process per GPU)."""
+    import os
+    import sys
+    import torch.distributed as dist
+    for p in (ROOT, os.path.join(ROOT, 'open-genie_amd')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    torch.cuda.set_device(rank)
+    dev = torch.device('cuda', rank)
+    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    try:
+        from genie.trainer import DataParallel, ParamArena, Trainer, sync_replicas
+
+        def build(seed):
+            from genie import VideoTokenizer
+            torch.manual_seed(seed)
+            return VideoTokenizer(ENC, DEC, d_codebook=10, gan_loss_weight=0., perc_loss_weight=0.).to(dev).train()
+
+        gen = torch.Generator(device=dev).manual_seed(50 + rank)
+        x = torch.randn(2, 3, 4, 16, 16, device=dev, generator=gen)           # rank r holds its own clips
+        grads = {}
+        for mode in ('bucketed', 'plain'):
+            m = build(1000 + rank)                                           # differently initialised on purpose: sync_replicas must fix it
+            arena = ParamArena(m)
+            sync_replicas(arena, m)
+            arena.attach_weight_packs(m)
+            dp = DataParallel(arena.grads)
+            assert dp.active and dp.world == world
+            if mode == 'bucketed':
+                dp.install_overlap_hooks(arena, m, Trainer.bucket_modules(arena, m, 4))      # what Trainer.fit / bench.py do
+                dp.trace = True
+            loss, _ = m(x)
+            loss.backward()
+            fired = list(dp.fired)
+            if mode == 'bucketed':
+                dp.finish()
+                torch.cuda.synchronize()
+                rep = dp.comm_report()
+                assert len(fired) >= len(dp.buckets) - 1, (fired, len(dp.buckets))     # all but the first bucket start during backward
+                assert rep['exposed_ms_per_step'] >= 0 and rep['allreduce_ms_per_step'] > 0 and len(rep['buckets']) == len(dp.buckets)
+            else:
+                from genie import functional as GF
+                GF.join_wgrad()
+                dist.all_reduce(arena.grads)                                 # the unbucketed reference: ONE all-reduce after backward
+                arena.grads.mul_(1.0 / world)
+                rep = None
+            torch.cuda.synchronize()
+            grads[mode] = arena.grads.clone()
+            params = arena.params.clone()
+        ref = grads['plain']
+        err = (grads['bucketed'] - ref).abs().max().item()
+        # same sums in the same order per element (two ranks): only the atomic order inside the weight-gradient kernels differs run to run
+        assert err <= 2e-3 * ref.abs().max().item() + 1e-6, err
+        gathered = [torch.empty_like(params) for _ in range(world)]
+        dist.all_gather(gathered, params)
+        assert all(torch.equal(g, gathered[0]) for g in gathered), 'replicas differ after sync_replicas'
+        both = [torch.empty_like(ref) for _ in range(world)]
+        dist.all_gather(both, grads['bucketed'])
+        assert torch.equal(both[0], both[1]), 'ranks hold different reduced gradients'
+        q.put((rank, err, rep['exposed_ms_per_step'] if rep else None))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs two GPUs (the gpurun boxes expose one; an 8-GPU driver box runs it)')
+def test_two_rank_rccl_tokenizer_step():
+    """Two RCCL ranks over a real tokenizer step: replicas synchronised from rank 0, gradients reduced in the
+    equal-byte buckets Trainer.fit / bench.py cut, on the comm stream during backward -- equal to ONE unbucketed all-reduce after
+    backward, identical on both ranks, and the `comm` report is filled in."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29700 + os.getpid() % 200
+    procs = [ctx.Process(target=_rccl_rank, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=5) for _ in range(2))
+    assert len(res) == 2

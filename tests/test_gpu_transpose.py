@@ -75,6 +75,37 @@ def test_spacetime_upsample(cin, cout, tf, sf, size):
     assert sorted(m.state_dict()) == ['go_up.bias', 'go_up.weight']
 
 
+def test_spacetime_upsample_follows_parameter_updates():
+    """the conv kernels see a derived copy of ``go_up.weight`` (fresh tensor each call, version 0, usually the same address), so
+    the bf16 weight packs must be keyed on the parameter: after an in-place update (optimiser step / load_state_dict) forward AND
+    backward-data must use the new weights."""
+    from genie.module.video import SpaceTimeUpsample
+    from oracle import genie_oracle as O
+    torch.manual_seed(11)
+    m = SpaceTimeUpsample(64, 32, time_factor=2, space_factor=2).cuda()
+    x = bf16_round(torch.randn(2, 64, 3, 4, 4))
+    dy = None
+    for step in range(3):
+        with torch.no_grad():
+            if step:
+                m.go_up.weight.copy_(bf16_round(torch.randn_like(m.go_up.weight) * 0.1))          # what an optimiser step / checkpoint load does
+            else:
+                m.go_up.weight.copy_(bf16_round(m.go_up.weight))
+        w = m.go_up.weight.detach().cpu().clone().requires_grad_(True)
+        b = m.go_up.bias.detach().cpu().clone().requires_grad_(True)
+        xr = x.clone().requires_grad_(True)
+        ref = O.spacetime_upsample(xr, w, b, 2, 2)
+        dy = bf16_round(torch.randn_like(ref)) if dy is None else dy
+        ref.backward(dy)
+        xc = x.cuda().requires_grad_(True)
+        m.zero_grad(set_to_none=True)
+        out = m(xc)
+        assert_close_bf16(out, ref, f'spacetime upsample after update {step}')
+        out.backward(dy.cuda())
+        assert_close_bf16(xc.grad, xr.grad, f'spacetime upsample dx after update {step}')
+        assert rel_rms(m.go_up.weight.grad, w.grad) < 2e-3
+
+
 def test_negative_causal_pad_crops_like_the_reference():
     from genie.module.video import CausalConv3d
     from oracle import genie_oracle as O
