@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GENIE_ABI_VERSION 9
+#define GENIE_ABI_VERSION 10
 
 #define GENIE_F32 0
 #define GENIE_BF16 1
@@ -377,11 +377,17 @@ int genie_attention_fwd(const void* q, const void* k, const void* v, const void*
                         int causal, int out_channels, void* stream);
 /* `out` must be the attention output WITHOUT the residual (o_attn of the forward) when resid is NULL; with resid given,
  * out - resid is used (less accurate).  Self-attention (q == k == v): dq receives dQ + dK + dV.  Otherwise dq gets dQ and
- * dk / dv (addressed by dkv_map, which must not alias across sequences) get dK / dV.  D_ws: fp32 [out_tokens][nhead] scratch. */
+ * dk / dv (addressed by dkv_map, which must not alias across sequences) get dK / dV.  D_ws: fp32 [2][out_tokens][nhead] scratch
+ * (ABI 10: D = rowsum(dO * O), then lse * log2 e -- the form the exp2-domain backward kernels subtract). */
 int genie_attention_bwd(const void* q, const void* k, const void* v, const void* out, const void* resid, const void* dO,
                         const float* lse, float* D_ws, void* dq, void* dk, void* dv, int nseq, int nhead, int d_head, int Sq, int Sk,
                         const int64_t* q_map, const int64_t* kv_map, const int64_t* out_map, const int64_t* dkv_map, float scale,
                         int causal, int out_channels, int64_t out_tokens, void* stream);
+
+/* d_head 64 runs on register-lean kernels (attention_lean.hip: four / three waves per SIMD) where their preconditions hold.  mask: bit 0
+ * forward, bit 1 backward dQ, bit 2 backward dK / dV; a negative mask only queries.  Returns the previous mask (default 7, or the
+ * GENIE_ATTN_LEAN environment variable).  Process-wide; meant for A/B timing and for tests that cover both kernel families. (ABI 10) */
+int genie_attention_lean_mode(int mask);
 
 /* Debug / bring-up probes (used by tests only). */
 int genie_probe_ds_read_tr16(const void* lds_image_u16_2048, const int32_t* lane_byte_addr_64, void* out_u16_64x4,

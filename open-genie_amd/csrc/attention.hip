@@ -18,44 +18,9 @@
 #include "common.h"
 #include "genie_hip.h"
 #include "attn_args.h"
+#include "attn_common.h"
 
 static __device__ __attribute__((aligned(256))) uint32_t g_zero_page_a[64];
-
-#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
-#define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
-
-// ds_read_b64_tr_b16 as inline asm: hipcc treats the builtin as possibly aliasing an in-flight LDS-DMA and puts
-// s_waitcnt vmcnt(0) in front of it, which would drain the K/V prefetch every tile.  The caller waits (lgkmcnt) before use.
-__device__ __forceinline__ bf16x4_t attn_tr16(uint32_t lds_addr) {
-    bf16x4_t v;
-    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(lds_addr));
-    return v;
-}
-// 16-B chunk `chunk` of LDS row `row` (CPR chunks per row) lives at slot attn_swz<CPR>(row, chunk).  The key is a bijection of the
-// low row bits, so the 32-row ds_read_b128 fragment reads stay conflict-free, and its bit pattern also separates the four
-// consecutive rows of a transposing ds_read_b64_tr_b16 group (rows r and r + 2 of a 128-B-pitch tile share banks otherwise:
-// the first version's (row >> 1) & 7 key cost 31 % of the LDS cycles in conflicts, SQ_LDS_BANK_CONFLICT).
-template <int CPR>
-__device__ __forceinline__ int attn_swz(int row, int chunk) {
-    if (CPR == 16) return chunk ^ (((row & 3) << 2) | ((row >> 2) & 3));
-    if (CPR == 8) return chunk ^ ((((row >> 1) & 1) << 2) | ((row >> 2) & 3));
-    if (CPR == 4) return chunk ^ ((row >> 2) & 3);
-    return chunk;
-}
-
-template <int IMM>
-__device__ __forceinline__ bf16x4_t attn_tr16i(uint32_t lds_addr) {      // same read with a compile-time byte offset
-    bf16x4_t v;
-    if constexpr (IMM <= 65535) {                                        // fits the 16-bit offset field
-        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "i"(IMM));
-    } else {
-        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(lds_addr + (uint32_t)IMM));
-    }
-    return v;
-}
-__device__ __forceinline__ uint32_t attn_lds_offset(const void* p) {
-    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
-}
 
 // ------------------------------------------------------------------------------------------------
 // rotary + LayerNorm prologue: one wave per token, C <= 2048
@@ -346,21 +311,6 @@ extern "C" int genie_rotary_layernorm_bwd(const void* x, const void* du, const v
 // ------------------------------------------------------------------------------------------------
 // attention core
 // ------------------------------------------------------------------------------------------------
-// Epilogue staging.  In the MFMA C layout a lane holds 4 consecutive channels of ONE token row, so a direct store instruction
-// touches 32 different rows with 16 B each; measured on the T = 16 / S = 64 shapes, where the kernel is pure traffic, that
-// pattern ran at ~1.8 TB/s against 5.8 TB/s for whole 16-B chunks, 8 lanes per row.  Every kernel therefore hands its 32 x DH
-// wave tile back through LDS (fp32 where a residual / partner gradient is still to be added, so nothing is rounded twice).
-template <int DH>
-__device__ __forceinline__ void rows_put_f32(float* fl, int lr, int h, int dg, const f32x4_t f) {
-    *reinterpret_cast<f32x4_t*>(fl + lr * DH + ((dg ^ (lr & (DH / 8 - 1))) << 3) + 4 * h) = f;
-}
-template <int DH>
-__device__ __forceinline__ void rows_get_f32(const float* fl, int row, int c, float (&f)[8]) {
-    const float* src = fl + row * DH + ((c ^ (row & (DH / 8 - 1))) << 3);
-    const f32x4_t f0 = *reinterpret_cast<const f32x4_t*>(src), f1 = *reinterpret_cast<const f32x4_t*>(src + 4);
-    f[0] = f0[0]; f[1] = f0[1]; f[2] = f0[2]; f[3] = f0[3]; f[4] = f1[0]; f[5] = f1[1]; f[6] = f1[2]; f[7] = f1[3];
-}
-
 // Forward.  NW waves of 32 queries share 64-key K/V tiles that live in a ring of THREE LDS stages, DMA'd two tiles ahead
 // (counted vmcnt + raw barrier: a whole tile stays in flight across the barrier).  Softmax runs in the exp2 domain with the
 // scale folded into one FMA per score; masks are only evaluated on tiles that touch the end of the key range or the causal
@@ -816,6 +766,7 @@ extern "C" int genie_attention_fwd(const void* q, const void* k, const void* v, 
         GENIE_CHECK_LAUNCH();
         return GENIE_OK;
     }
+    if (genie_attn_lean_fwd_ok(a, d_head)) return genie_attn_lean_fwd(a, s);        // d_head 64, four waves per SIMD (attention_lean.hip)
     int nw = (Sq + 31) / 32;
     nw = nw >= 3 ? 4 : nw;                                        // 1, 2 or 4 waves (every wave stages the same number of pieces)
     const int qtiles = (Sq + 32 * nw - 1) / (32 * nw);
@@ -853,7 +804,7 @@ extern "C" int genie_attention_fwd(const void* q, const void* k, const void* v, 
 template <int DH>
 __global__ void __launch_bounds__(256) attn_bwd_prep_kernel(const bf16_t* __restrict__ dO, const bf16_t* __restrict__ out,
                                                             const bf16_t* __restrict__ resid, float* __restrict__ D, long long ntok, int C,
-                                                            int nhead) {
+                                                            int nhead, const float* __restrict__ lse, float* __restrict__ lse2) {
     const int lane = threadIdx.x & 63;
     const long long tok = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (tok >= ntok) return;
@@ -876,7 +827,10 @@ __global__ void __launch_bounds__(256) attn_bwd_prep_kernel(const bf16_t* __rest
         }
 #pragma unroll
         for (int o = 1; o < LPH; o <<= 1) acc += __shfl_xor(acc, o, 64);
-        if (ch < nch && (ch % LPH) == 0) D[tok * nhead + ch / LPH] = acc;
+        if (ch < nch && (ch % LPH) == 0) {
+            D[tok * nhead + ch / LPH] = acc;
+            lse2[tok * nhead + ch / LPH] = lse[tok * nhead + ch / LPH] * 1.4426950408889634f;      // the exp2-domain form the backward kernels subtract
+        }
     }
 }
 
@@ -1473,6 +1427,7 @@ extern "C" int genie_attention_bwd(const void* q, const void* k, const void* v, 
     GENIE_CHECK_ARG(self || (dk && dv), "genie_attention_bwd: dk/dv required when k/v differ from q");
     AttnBwdArgs a;
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.dO = (const bf16_t*)dO; a.lse = lse; a.D = D_ws;
+    a.lse2 = D_ws + out_tokens * nhead;
     a.dq = (bf16_t*)dq; a.dk = self ? (bf16_t*)dq : (bf16_t*)dk; a.dv = (bf16_t*)dv; a.dq_in = (const bf16_t*)dq;
     a.qm = mk_map(q_map); a.km = mk_map(kv_map); a.om = mk_map(out_map); a.dkm = dkv_map ? mk_map(dkv_map) : a.km;
     a.nseq = nseq; a.nhead = nhead; a.Sq = Sq; a.Sk = Sk; a.C = out_channels; a.Ckv = 0; a.scale = scale; a.causal = causal;
@@ -1482,9 +1437,9 @@ extern "C" int genie_attention_bwd(const void* q, const void* k, const void* v, 
     GENIE_CHECK_ARG(scale > 0.f, "genie_attention_bwd: scale must be positive (got %g)", (double)scale);
     if (d_head < 32) return genie_attn_narrow_bwd(a, d_head, s);                                     // D + dQ, then dK / dV (attention_narrow.hip)
     const unsigned pblocks = (unsigned)((out_tokens + 3) / 4);
-    if (d_head == 32) attn_bwd_prep_kernel<32><<<pblocks, 256, 0, s>>>((const bf16_t*)dO, (const bf16_t*)out, (const bf16_t*)resid, D_ws, out_tokens, out_channels, nhead);
-    else if (d_head == 64) attn_bwd_prep_kernel<64><<<pblocks, 256, 0, s>>>((const bf16_t*)dO, (const bf16_t*)out, (const bf16_t*)resid, D_ws, out_tokens, out_channels, nhead);
-    else attn_bwd_prep_kernel<128><<<pblocks, 256, 0, s>>>((const bf16_t*)dO, (const bf16_t*)out, (const bf16_t*)resid, D_ws, out_tokens, out_channels, nhead);
+    if (d_head == 32) attn_bwd_prep_kernel<32><<<pblocks, 256, 0, s>>>((const bf16_t*)dO, (const bf16_t*)out, (const bf16_t*)resid, D_ws, out_tokens, out_channels, nhead, lse, D_ws + out_tokens * nhead);
+    else if (d_head == 64) attn_bwd_prep_kernel<64><<<pblocks, 256, 0, s>>>((const bf16_t*)dO, (const bf16_t*)out, (const bf16_t*)resid, D_ws, out_tokens, out_channels, nhead, lse, D_ws + out_tokens * nhead);
+    else attn_bwd_prep_kernel<128><<<pblocks, 256, 0, s>>>((const bf16_t*)dO, (const bf16_t*)out, (const bf16_t*)resid, D_ws, out_tokens, out_channels, nhead, lse, D_ws + out_tokens * nhead);
     GENIE_CHECK_LAUNCH();
     GENIE_CHECK_ARG(scale > 0.f, "genie_attention_bwd: scale must be positive (got %g)", (double)scale);
     if (self && Sq == Sk && Sq <= 32 && same_map(a.qm, a.km) && small_attn_mode()) {
@@ -1521,10 +1476,13 @@ extern "C" int genie_attention_bwd(const void* q, const void* k, const void* v, 
         if (lds_k > 65536) GENIE_CHECK_ARG(hipFuncSetAttribute((const void*)kk, hipFuncAttributeMaxDynamicSharedMemorySize, lds_k) == hipSuccess, "hipFuncSetAttribute failed"); \
         kk<<<gk, 64 * NWv, lds_k, s>>>(a);                                                               \
     } while (0)
+    const int lean = genie_attn_lean_bwd_mask(a, d_head);       // d_head 64: the register-lean kernels (attention_lean.hip) where they apply
 #define GENIE_ATTN_BWD_DH(DHv)                                                                           \
     do {                                                                                                 \
-        if (nwq == 1) GENIE_ATTN_DQ(DHv, 1); else if (nwq == 2) GENIE_ATTN_DQ(DHv, 2); else GENIE_ATTN_DQ(DHv, 4);      \
-        if (nwk == 1) GENIE_ATTN_DKV(DHv, 1); else if (nwk == 2) GENIE_ATTN_DKV(DHv, 2); else GENIE_ATTN_DKV(DHv, 4);   \
+        if (lean & 1) { if (int rc = genie_attn_lean_bwd_dq(a, s)) return rc; }                          \
+        else if (nwq == 1) GENIE_ATTN_DQ(DHv, 1); else if (nwq == 2) GENIE_ATTN_DQ(DHv, 2); else GENIE_ATTN_DQ(DHv, 4);      \
+        if (lean & 2) { if (int rc = genie_attn_lean_bwd_dkv(a, s)) return rc; }                         \
+        else if (nwk == 1) GENIE_ATTN_DKV(DHv, 1); else if (nwk == 2) GENIE_ATTN_DKV(DHv, 2); else GENIE_ATTN_DKV(DHv, 4);   \
     } while (0)
     if (d_head == 32) GENIE_ATTN_BWD_DH(32);
     else if (d_head == 64) GENIE_ATTN_BWD_DH(64);

@@ -26,6 +26,7 @@ struct AttnArgs {
 struct AttnBwdArgs {
     const bf16_t* q; const bf16_t* k; const bf16_t* v; const bf16_t* dO;
     const float* lse; const float* D;
+    const float* lse2;                        // lse * log2(e), written next to D by the preprocess kernel (second half of D_ws)
     const bf16_t* out; const bf16_t* resid;   // narrow kernels: D is computed in the dQ kernel (out = o_attn when resid is null)
     bf16_t* dq; bf16_t* dk; bf16_t* dv;      // dq: q-map addressing; dk/dv: kv-map addressing (dkv kernel)
     const bf16_t* dq_in;                      // dkv kernel, fused self-attention: dk row += dq_in row (then dk holds dQ + dK + dV)
@@ -39,3 +40,11 @@ struct AttnBwdArgs {
 // d_head 8 / 16 (attention_narrow.hip); same contracts as the MFMA kernels behind genie_attention_fwd / genie_attention_bwd
 int genie_attn_narrow_fwd(const AttnArgs& a, int d_head, hipStream_t s);
 int genie_attn_narrow_bwd(const AttnBwdArgs& a, int d_head, hipStream_t s);
+
+// register-lean d_head = 64 kernels (attention_lean.hip).  genie_attn_lean_fwd_ok: the forward call may take them;
+// genie_attn_lean_bwd_mask: bit 0 = the dQ kernel, bit 1 = the dK / dV kernel may (D / lse2 already computed by the preprocess kernel)
+bool genie_attn_lean_fwd_ok(const AttnArgs& a, int d_head);
+int genie_attn_lean_fwd(const AttnArgs& a, hipStream_t s);
+int genie_attn_lean_bwd_mask(const AttnBwdArgs& a, int d_head);
+int genie_attn_lean_bwd_dq(const AttnBwdArgs& a, hipStream_t s);
+int genie_attn_lean_bwd_dkv(const AttnBwdArgs& a, hipStream_t s);

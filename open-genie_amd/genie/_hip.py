@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('GENIE_HIP_LIB', os.path.join(os.path.dirname(_HERE), 'lib', 'libgenie_hip.so'))
 
 GENIE_F32, GENIE_BF16 = 0, 1
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class GenieTap(C.Structure):
@@ -112,6 +112,7 @@ SIGNATURES = {
     'genie_rotary_layernorm_bwd': (C.c_int, [_P, _P, _P, _P, _L, _I, _L, _P, _L, _I, _P, _P, _P, _P, _P]),
     'genie_attention_fwd': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _PL, _PL, _PL, _F, _I, _I, _P]),
     'genie_attention_bwd': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _PL, _PL, _PL, _PL, _F, _I, _I, _L, _P]),
+    'genie_attention_lean_mode': (C.c_int, [_I]),
     'genie_probe_ds_read_tr16': (C.c_int, [_P, _P, _P, _P]),
 }
 

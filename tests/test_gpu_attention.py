@@ -197,6 +197,55 @@ CORE_CASES = [
 ]
 
 
+@pytest.mark.parametrize('nseq,nhead,dh,sq,sk,causal,cross', [c for c in CORE_CASES if c[2] == 64 and c[3] > 32])
+def test_attention_general_kernels_on_lean_shapes(nseq, nhead, dh, sq, sk, causal, cross):
+    """d_head 64 runs on the register-lean kernels by default (attention_lean.hip: four / three waves per SIMD); the general kernels of
+    attention.hip stay the fallback for layouts the lean ones refuse (strides beyond 32-bit offsets, K != V in the dK / dV pass) -- the same
+    cases through them (genie_attention_lean_mode(0)), against the same fp32 reference."""
+    from genie import _hip
+    lib = _hip.load_library()
+    old = lib.genie_attention_lean_mode(0)
+    try:
+        assert lib.genie_attention_lean_mode(-1) == 0
+        test_attention_core_kernels(nseq, nhead, dh, sq, sk, causal, cross)
+    finally:
+        lib.genie_attention_lean_mode(old)
+    assert lib.genie_attention_lean_mode(-1) == old
+
+
+def test_attention_lean_and_general_kernels_agree():
+    """Same inputs through both kernel families: same tiling and arithmetic (only the order of the row-sum additions differs), so the
+    outputs agree far inside the fp32-reference tolerance -- a layout or masking slip in the re-cut kernels shows here first."""
+    from genie import _hip
+    lib = _hip.load_library()
+    P = _hip.ptr
+    torch.manual_seed(5)
+    for (nseq, nhead, sq, causal) in ((2, 2, 333, False), (1, 2, 700, True), (3, 1, 65, True)):
+        c = nhead * 64
+        scale = 64 ** -0.5 * 1.7
+        q = (torch.randn(nseq, sq, c, device='cuda') * 0.8).to(torch.bfloat16)
+        do = (torch.randn(nseq, sq, c, device='cuda') * 0.5).to(torch.bfloat16)
+        qmap = _hip.i64((1, sq * c, 0, c))
+        res = []
+        for mode in (7, 0):
+            old = lib.genie_attention_lean_mode(mode)
+            try:
+                out, lse = torch.empty_like(q), torch.empty(nseq * sq * nhead, device='cuda')
+                D, dq = torch.empty(2 * nseq * sq * nhead, device='cuda'), torch.empty_like(q)
+                _hip.check(lib.genie_attention_fwd(P(q), P(q), P(q), None, P(out), None, P(lse), nseq, nhead, 64, sq, sq, qmap, qmap, qmap, scale,
+                                                   int(causal), c, _hip.stream_ptr()), 'fwd')
+                _hip.check(lib.genie_attention_bwd(P(q), P(q), P(q), P(out), None, P(do), P(lse), P(D), P(dq), None, None, nseq, nhead, 64, sq, sq,
+                                                   qmap, qmap, qmap, None, scale, int(causal), c, nseq * sq, _hip.stream_ptr()), 'bwd')
+                torch.cuda.synchronize()
+                res.append((out.float(), lse.clone(), dq.float()))
+            finally:
+                lib.genie_attention_lean_mode(old)
+        (o1, l1, g1), (o0, l0, g0) = res
+        assert (o1 - o0).abs().max().item() <= 2 ** -7 * o0.abs().max().item() + 1e-6          # a bf16 ulp or two of the output
+        assert (l1 - l0).abs().max().item() <= 1e-4
+        assert rel_rms(g1, g0) < 2e-3, rel_rms(g1, g0)
+
+
 @pytest.mark.parametrize('nseq,nhead,dh,sq,sk,causal,cross', CORE_CASES)
 def test_attention_core_kernels(nseq, nhead, dh, sq, sk, causal, cross):
     """genie_attention_fwd / _bwd through the C ABI on longer and ragged sequences (several key tiles, partial last tile,
@@ -241,7 +290,7 @@ def test_attention_core_kernels(nseq, nhead, dh, sq, sk, causal, cross):
     torch.testing.assert_close(lse.cpu().reshape(nseq, sq, nhead), lse_ref.transpose(1, 2).contiguous(), rtol=2e-3, atol=2e-3)
 
     dod = do.cuda().to(torch.bfloat16)
-    D = torch.empty(nseq * sq * nhead, device='cuda')
+    D = torch.empty(2 * nseq * sq * nhead, device='cuda')                 # D, then lse * log2 e (ABI 10)
     dq = torch.empty_like(qd)
     dk = torch.empty_like(kd) if cross else None
     dv = torch.empty_like(vd) if cross else None
