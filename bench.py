@@ -95,6 +95,7 @@ def _cpu_baseline_worker(threads: int, frames: int, q) -> None:
 
     first = step()                                          # warm-up 1 (also tells how many more steps the budget allows)
     warm, timed = (2, 3) if first < 14.0 else ((1, 1) if first < 40.0 else (1, 0))
+    timed = max(timed, int(os.environ.get('GENIE_CPU_BASELINE_MIN_TIMED', '0')))      # scripts/cpu_baseline_reference.py: a warm step even on a slow host
     for _ in range(warm - 1):
         step()
     times = [step() for _ in range(timed)] or [first]

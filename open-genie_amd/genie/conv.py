@@ -41,20 +41,21 @@ class LaunchProfiler:
         ev.record(torch.cuda.current_stream())
         return ev
 
-    def end(self, variant: str, label: str, flops: float, start) -> None:
+    def end(self, variant: str, label: str, flops: float, start, bytes_: float = 0.0) -> None:
+        """`bytes_`: algorithmic HBM bytes of the launch (traffic-bound kernels: attention on short sequences); 0 = priced by `flops` alone."""
         ev = torch.cuda.Event(enable_timing=True)
         ev.record(torch.cuda.current_stream())
-        self.records.append((variant, label, flops, start, ev))
+        self.records.append((variant, label, flops, start, ev, bytes_))
 
     def summary(self):
         torch.cuda.synchronize()
         out = {}
-        for variant, label, flops, s, e in self.records:
+        for variant, label, flops, s, e, nbytes in self.records:
             ms = s.elapsed_time(e)
-            v = out.setdefault(variant, {'launches': 0, 'ms': 0.0, 'flops': 0.0, 'by_label': {}})
-            v['launches'] += 1; v['ms'] += ms; v['flops'] += flops
-            b = v['by_label'].setdefault(label, {'launches': 0, 'ms': 0.0, 'flops': 0.0})
-            b['launches'] += 1; b['ms'] += ms; b['flops'] += flops
+            v = out.setdefault(variant, {'launches': 0, 'ms': 0.0, 'flops': 0.0, 'bytes': 0.0, 'by_label': {}})
+            v['launches'] += 1; v['ms'] += ms; v['flops'] += flops; v['bytes'] += nbytes
+            b = v['by_label'].setdefault(label, {'launches': 0, 'ms': 0.0, 'flops': 0.0, 'bytes': 0.0})
+            b['launches'] += 1; b['ms'] += ms; b['flops'] += flops; b['bytes'] += nbytes
         return out
 
 

@@ -21,6 +21,7 @@ import torch.nn.functional as F
 from torch import Tensor
 
 from .. import _hip
+from .. import conv as _conv
 from .. import functional as GF
 from ..cl import empty_like_cl, is_cl, pitch_of, to_cl
 from ..utils import default, exists
@@ -92,6 +93,13 @@ class _Merge(nn.Module):
 # ------------------------------------------------------------------------------------------------
 # fused block function:  out = Attn(LN(rot(x))) [+ x]
 # ------------------------------------------------------------------------------------------------
+def _attn_variant(direction: str, S: int, d_head: int) -> str:
+    """Name under which conv.LaunchProfiler files an attention call: the kernel family the C side picks for it (attention.hip /
+    attention_lean.hip / attention_narrow.hip) and the roofline that bounds it (MFMA from S >= 1024, traffic below)."""
+    fam = 'attn_narrow' if d_head < 32 else ('attn_small' if S <= 32 else 'attn')
+    return f'{fam}_{direction}[{"mfma" if S >= 1024 and d_head >= 32 else "hbm"}]'
+
+
 class _AttnFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x: Tensor, gamma: Tensor, beta: Tensor, table: Optional[Tensor], kext: Optional[Tensor], vext: Optional[Tensor],
@@ -125,9 +133,14 @@ class _AttnFn(torch.autograd.Function):
         keep = any(ctx.needs_input_grad)
         oattn = empty_like_cl(x) if (keep and add_resid) else None
         lse = torch.empty(ntok * n_head, dtype=torch.float32, device=x.device)
+        prof = _conv.PROFILER if _conv.PROFILER is not None and not _conv.PROFILER.only_triple else None
+        t0 = prof.begin() if prof is not None else None
         _hip.check(lib.genie_attention_fwd(P(u), P(k), P(v), P(x) if add_resid else None, P(out), P(oattn), P(lse), nseq, n_head, d_head, S, Sk,
                                            _hip.i64(qmap), _hip.i64(kvmap), _hip.i64(qmap), scale, 1 if causal else 0, c, _hip.stream_ptr()),
                    'genie_attention_fwd')
+        if prof is not None:                              # dense count 4 S Sk C per sequence; traffic: read u (q, k / v), resid, write out
+            prof.end(_attn_variant('fwd', S, d_head), f'attention fwd {mode} S={S} Sk={Sk} C={c} nseq={nseq}', 4.0 * S * Sk * c * nseq, t0,
+                     bytes_=(4.0 if add_resid else 3.0) * ntok * c * 2)
         ctx.cfg = (mode, n_head, d_head, scale, causal, add_resid, eps, qmap, kvmap, nseq, S, Sk, pos_div, pos_mod)
         ctx.save_for_backward(x, gamma, beta, table, kext, vext, u, oattn if oattn is not None else out, lse, stats)
         return out
@@ -151,9 +164,14 @@ class _AttnFn(torch.autograd.Function):
             dk = torch.empty((nseq, Sk, c), dtype=torch.bfloat16, device=x.device)
             dv = torch.empty_like(dk)
             dkvmap = _hip.i64((1, Sk * c, 0, c))
+        prof = _conv.PROFILER if _conv.PROFILER is not None and not _conv.PROFILER.only_triple else None
+        t0 = prof.begin() if prof is not None else None
         _hip.check(lib.genie_attention_bwd(P(u), P(k), P(v), P(out), None, P(dout), P(lse), P(D), P(du), P(dk), P(dv),
                                            nseq, n_head, d_head, S, Sk, _hip.i64(qmap), _hip.i64(kvmap), _hip.i64(qmap), dkvmap, scale,
                                            1 if causal else 0, c, ntok, _hip.stream_ptr()), 'genie_attention_bwd')
+        if prof is not None:                              # 2.5 x the forward count (five GEMM units of the maths); traffic: u, out, dout read, du written (+ dq re-read)
+            prof.end(_attn_variant('bwd', S, d_head), f'attention bwd {mode} S={S} Sk={Sk} C={c} nseq={nseq}', 10.0 * S * Sk * c * nseq, t0,
+                     bytes_=5.0 * ntok * c * 2)
         dx = empty_like_cl(x)
         need_g, need_b = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
         direct = GF._direct(gamma) and GF._direct(beta) and gamma.is_leaf and beta.is_leaf and gamma.dtype == torch.float32

@@ -20,12 +20,14 @@ from genie import _hip    # noqa: E402
 def main():
     lib = _hip.load_library()
     iters = int(os.environ.get('AB_ITERS', 30))
-    only = ['spatial S=4096', 'spatial S=1024', 'spatial S=256', 'spatial S=64']
+    only = os.environ.get('AB_ONLY', 'spatial S=4096,spatial S=1024,spatial S=256,spatial S=64').split(',')
+    modes = [int(m) for m in os.environ.get('AB_MODES', '0,7,1,2,4').split(',')]
+    reps = int(os.environ.get('AB_REPS', 2))
     base_report = mb.report
     rows = []
-    for rep in range(2):
-        for mode in (0, 7, 1, 2, 4):
-            if rep == 1 and mode not in (0, 7):
+    for rep in range(reps):
+        for mode in modes:
+            if rep >= 1 and mode not in (0, 7):
                 continue
             lib.genie_attention_lean_mode(mode)
 

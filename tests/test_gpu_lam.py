@@ -109,7 +109,6 @@ def check_lam(tag, enc, dec, d, n_embd, clip, seed, tol_fp32, tol_emul=None):
     assert tuple(h['idxs'].shape) == tuple(idx_ref.shape)
     assert abs(h['rec_loss'].item() - rec_ref.item()) < 2e-2 * abs(rec_ref.item()), (h['rec_loss'].item(), rec_ref.item())
     assert abs(h['q_loss'].item() - q_ref.item()) < 2e-2 * abs(q_ref.item()) + 1e-3, (h['q_loss'].item(), q_ref.item())
-    assert rel_rms(h['rec'], recon_ref) < 3e-2, rel_rms(h['rec'], recon_ref)
     assert rel_rms(h['enc_video'], tr['enc_video']) < 3e-2
     # the action id is the sign pattern of a K = n_embd * H/2 * W/2 projection of bf16 activations: it may differ from the fp32 oracle's only
     # where the oracle's pre-sign value is within eps of zero; everywhere else the ids agree bit for bit
@@ -123,6 +122,16 @@ def check_lam(tag, enc, dec, d, n_embd, clip, seed, tol_fp32, tol_emul=None):
     idx_h = h['idxs'].cpu().reshape(idx_ref.shape)
     assert torch.equal(idx_h.reshape(-1)[safe.reshape(-1)], idx_ref.reshape(-1)[safe.reshape(-1)])
     match = (idx_h == idx_ref).float().mean().item()
+    # end-to-end reconstruction against the fp32 oracle.  The decoder is conditioned on the quantised action (temporal attention over the
+    # codes of frames <= t), so a frame whose id legitimately differs (a bit inside eps, allowed above) changes its own and every later
+    # frame's reconstruction by far more than rounding does: the bound applies to the frames BEFORE a clip's first differing id -- all
+    # of them when the ids agree, which is the normal case (the stage-fed comparison below covers every frame either way)
+    same = (idx_h == idx_ref).reshape(b, -1)
+    first_bad = [int((~same[i]).nonzero()[0]) if (~same[i]).any() else same.shape[1] for i in range(b)]
+    e2e = [rel_rms(h['rec'][i:i + 1, :, :n], recon_ref[i:i + 1, :, :n]) for i, n in enumerate(first_bad) if n > 0]
+    report(f'{tag}_end_to_end', frames_compared=first_bad, rec_rel_rms=[round(e, 5) for e in e2e],
+           rec_rel_rms_all_frames=round(rel_rms(h['rec'], recon_ref), 5), idx_match_rate=match)
+    assert all(e < 3e-2 for e in e2e), (e2e, first_bad)
     # per stage, same inputs: fp32 arithmetic (loose, reported) and the bf16-at-stores emulation (the parity bound)
     errs, edges, idx_o = lam_stages_oracle(h, x, sd, enc, dec, d, None)
     assert torch.equal(h['idxs'].cpu().reshape(idx_o.shape), idx_o)          # operator boundary: bit-exact on the same latent
