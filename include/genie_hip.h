@@ -385,9 +385,16 @@ int genie_attention_bwd(const void* q, const void* k, const void* v, const void*
                         int causal, int out_channels, int64_t out_tokens, void* stream);
 
 /* d_head 64 runs on register-lean kernels (attention_lean.hip: four / three waves per SIMD) where their preconditions hold.  mask: bit 0
- * forward, bit 1 backward dQ, bit 2 backward dK / dV; a negative mask only queries.  Returns the previous mask (default 7, or the
- * GENIE_ATTN_LEAN environment variable).  Process-wide; meant for A/B timing and for tests that cover both kernel families. (ABI 10) */
+ * forward, bit 1 backward dQ, bit 2 backward dK / dV; bit 3: no s_setprio around the MFMA clusters; bit 4: the forward's running maximum is
+ * deferred (O, l rescaled only when a tile's maximum exceeds it by more than 2^8 in the exp2 domain; P <= 2^8 instead of <= 1, the row's
+ * largest weight is then rounded to bf16 like every other one instead of being exactly 1); bit 5: plain grid instead of the XCD-aware one.
+ * A negative mask only queries.  Returns the previous mask (default 23 = bits 0, 1, 2, 4, or the GENIE_ATTN_LEAN environment variable).
+ * Process-wide; meant for A/B timing and for tests that cover both kernel families and both maximum rules. (ABI 10) */
 int genie_attention_lean_mode(int mask);
+
+/* Resident blocks per CU of a lean kernel at its launch configuration (which: 0 forward, 1 backward dQ, 2 backward dK / dV), as the HIP
+ * runtime computes it; -1 on error.  Budget: 4 / 3 / 3. */
+int genie_attention_lean_occupancy(int which);
 
 /* Debug / bring-up probes (used by tests only). */
 int genie_probe_ds_read_tr16(const void* lds_image_u16_2048, const int32_t* lane_byte_addr_64, void* out_u16_64x4,

@@ -745,7 +745,7 @@ extern "C" int genie_attention_fwd(const void* q, const void* k, const void* v, 
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.resid = (const bf16_t*)resid; a.out = (bf16_t*)out; a.oattn = (bf16_t*)o_attn; a.lse = lse;
     a.qm = mk_map(q_map); a.km = mk_map(kv_map); a.om = mk_map(out_map);
     GENIE_CHECK_ARG(a.qm.n_inner >= 1 && a.km.n_inner >= 1 && a.om.n_inner >= 1, "genie_attention_fwd: bad sequence map");
-    a.nseq = nseq; a.nhead = nhead; a.Sq = Sq; a.Sk = Sk; a.scale = scale; a.causal = causal; a.kv_same = (k == v) ? 1 : 0;
+    a.nseq = nseq; a.nhead = nhead; a.Sq = Sq; a.Sk = Sk; a.scale = scale; a.causal = causal; a.kv_same = (k == v) ? 1 : 0; a.xcd_swizzle = 0;
     a.C = out_channels;
     GENIE_CHECK_ARG(out_channels >= nhead * d_head, "genie_attention_fwd: out_channels %d < nhead * d_head", out_channels);
     GENIE_CHECK_ARG(scale > 0.f, "genie_attention_fwd: scale must be positive (got %g)", (double)scale);
@@ -1431,7 +1431,7 @@ extern "C" int genie_attention_bwd(const void* q, const void* k, const void* v, 
     a.dq = (bf16_t*)dq; a.dk = self ? (bf16_t*)dq : (bf16_t*)dk; a.dv = (bf16_t*)dv; a.dq_in = (const bf16_t*)dq;
     a.qm = mk_map(q_map); a.km = mk_map(kv_map); a.om = mk_map(out_map); a.dkm = dkv_map ? mk_map(dkv_map) : a.km;
     a.nseq = nseq; a.nhead = nhead; a.Sq = Sq; a.Sk = Sk; a.C = out_channels; a.Ckv = 0; a.scale = scale; a.causal = causal;
-    a.kv_same = (k == v) ? 1 : 0; a.fuse_self = self ? 1 : 0;
+    a.kv_same = (k == v) ? 1 : 0; a.fuse_self = self ? 1 : 0; a.xcd_swizzle = 0;
     a.out = (const bf16_t*)out; a.resid = (const bf16_t*)resid;
     hipStream_t s = (hipStream_t)stream;
     GENIE_CHECK_ARG(scale > 0.f, "genie_attention_bwd: scale must be positive (got %g)", (double)scale);

@@ -53,6 +53,28 @@ __device__ __forceinline__ void attn_dma16(const void* base, int bytes_left, cha
 __device__ __forceinline__ void attn_dma4(const float* src, char* lds) {      // 4 B per lane, flat address
     __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(lds), 4, 0, 0);
 }
+// Workgroup -> (sequence, head, tile).  The hardware deals consecutive workgroup ids round-robin over the 8 XCDs, each with its own 4-MB L2.
+// With the plain (x = sequence * tiles + tile, y = head) grid the 32 query tiles of one (sequence, head) -- which all stream the SAME
+// 512 KB of K / V (S = 4096) -- land on all 8 XCDs, every L2 holds pieces of every sequence at once (16 MB for the blocks resident on
+// one XCD) and the tiles come from the Infinity Cache.  Swizzled: XCD c owns the c-th contiguous eighth of the (sequence, head, tile)
+// list, so the ~128 blocks resident on it belong to about four (sequence, head) pairs: 2 MB of K / V, L2-resident.
+// Launch: 1-D grid of 8 * ceil(N / 8) blocks; blocks whose list position is past N return at once.
+struct AttnBlock { int seq, head, tile; bool live; };
+__device__ __forceinline__ AttnBlock attn_block_of(int swizzle, int nseq, int nhead, int tiles) {
+    AttnBlock b;
+    if (!swizzle) {
+        b.seq = blockIdx.x / tiles; b.tile = blockIdx.x % tiles; b.head = blockIdx.y; b.live = true;
+        return b;
+    }
+    const int n = nseq * nhead * tiles, per = (n + 7) >> 3;
+    const int pos = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    b.live = (int)(blockIdx.x >> 3) < per && pos < n;
+    b.tile = pos % tiles;
+    const int sh = pos / tiles;
+    b.head = sh % nhead;
+    b.seq = sh / nhead;
+    return b;
+}
 template <int I, int N, class F>
 __device__ __forceinline__ void attn_static_for(F&& f) {
     if constexpr (I < N) {
@@ -60,7 +82,11 @@ __device__ __forceinline__ void attn_static_for(F&& f) {
         attn_static_for<I + 1, N>(f);
     }
 }
-template <int DH, int NW, bool KVSAME>
+// PRIO: s_setprio(1) around the MFMA clusters (the general kernels' habit).  DEFER: the running maximum only moves -- and O, l are only
+// rescaled -- when some lane's tile maximum exceeds it by more than 2^8 in the exp2 domain (defer-max, cdna_hip_programming.md T13):
+// P is then bounded by 2^8 instead of 1, which neither fp32 sums nor bf16 P mind; on i.i.d. scores the exact rule rescales on two
+// tiles out of three (any of 32 queries meeting a new maximum), 35 VALU instructions each, in a loop that is VALU-bound.
+template <int DH, int NW, bool KVSAME, bool PRIO, bool DEFER>
 __global__ void __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(64 * NW) attn_fwd4_kernel(const AttnArgs a) {
     constexpr int KT = 64, ROWB = DH * 2, CPR = DH / 8, TILE = KT * ROWB, KS = DH / 16, DT = DH / 32;
     constexpr int SLABS = TILE / 1024, LPW = SLABS / NW, LPT = KVSAME ? LPW : 2 * LPW;
@@ -71,7 +97,9 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(64 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int qtiles = (a.Sq + 32 * NW - 1) / (32 * NW);
-    const int seq = blockIdx.x / qtiles, qtile = blockIdx.x % qtiles, head = blockIdx.y;
+    const AttnBlock blk = attn_block_of(a.xcd_swizzle, a.nseq, a.nhead, qtiles);
+    if (!blk.live) return;
+    const int seq = blk.seq, qtile = blk.tile, head = blk.head;
     const int q0 = qtile * (32 * NW) + wave * 32;
     const int qi = q0 + (lane & 31);
     const int h = lane >> 5;
@@ -170,7 +198,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(64 
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt) kfr[kt][ks] = *reinterpret_cast<const bf16x8_t*>(smem + KBASE + kt * 32 * ROWB + k_off[ks]);
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -179,8 +207,17 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(64 
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt) sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[kt][ks], qf[ks], sacc[kt], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
+        // V^T fragments of the first 32 keys: requested now, they land under the maximum / first-half exponentials
         bf16x4_t vlo[2][2][DT], vhi[2][2][DT];
+        attn_static_for<0, 2>([&](auto s2c) {
+            constexpr int s2 = decltype(s2c)::value;
+#pragma unroll
+            for (int d = 0; d < DT; ++d) {
+                vlo[0][s2][d] = attn_tr16i<VBASE + (16 * s2) * ROWB>(v_off[d][0]);
+                vhi[0][s2][d] = attn_tr16i<VBASE + (16 * s2) * ROWB>(v_off[d][1]);
+            }
+        });
         // masks: only where the tile crosses the end of the keys or (causal) the diagonal of this wave's queries.  Key (kt, r) of lane
         // half h is kt * 32 + (r & 3) + 8 (r >> 2) + 4 h: one per-lane threshold, compile-time constants on the other side
         if ((k0 + KT > a.Sk) || (a.causal && k0 + KT - 1 > q0)) {
@@ -207,7 +244,8 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(64 
         }
         tmax = attn_xmax32(tmax);
         const float m_new = fmaxf(m_run, tmax);
-        if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0) {
+        // exact rule: any lane's maximum moved.  Deferred rule: some lane's moved by more than 8 / c2 (the first tile always does: m = -1e30)
+        if (__builtin_amdgcn_ballot_w64(DEFER ? (m_new - m_run) * c2 > 8.f : m_new > m_run) != 0) {
             const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
             l_run *= alpha;
 #pragma unroll
@@ -217,7 +255,11 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(64 
             m_run = m_new;
         }
         const float mc = m_run * c2;
-        // exp2, row sums on four independent chains, and P packed to bf16 on the way out (the fp32 scores die pair by pair)
+        // exp2, row sums on four independent chains, P packed to bf16 on the way out (the fp32 scores die pair by pair).  The first
+        // half's four P V products are issued between the two halves' exponentials, so that they run in the matrix pipe while this
+        // wave's own VALU works through the second half.  (Measured neutral against issuing all eight at the end -- 932 vs 936 TFLOP/s
+        // at S = 4096 -- like the other schedule changes tried on this loop: the SQ counters put the VALU at 74 % and the matrix pipe
+        // at 43 % of the kernel's cycles with only a quarter of the latter overlapped, profiles/r04_pmc_attn.txt.)
         uint32_t pw[2][8];
         float ps0 = 0.f, ps1 = 0.f, ps2 = 0.f, ps3 = 0.f;
         attn_static_for<0, 2>([&](auto ktc) {
@@ -232,44 +274,14 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(64 
                 pw[kt][2 * e] = pack_bf16x2(p0, p1);
                 pw[kt][2 * e + 1] = pack_bf16x2(p2, p3);
             }
-            if constexpr (kt == 0) {
-                // V^T fragments of the first 32 keys go out once half of the fp32 scores are dead; they land under the second half's exponentials
-                __builtin_amdgcn_sched_barrier(0);
-                attn_static_for<0, 2>([&](auto s2c) {
-                    constexpr int s2 = decltype(s2c)::value;
-#pragma unroll
-                    for (int d = 0; d < DT; ++d) {
-                        vlo[0][s2][d] = attn_tr16i<VBASE + (16 * s2) * ROWB>(v_off[d][0]);
-                        vhi[0][s2][d] = attn_tr16i<VBASE + (16 * s2) * ROWB>(v_off[d][1]);
-                    }
-                });
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        });
-        float psum = (ps0 + ps1) + (ps2 + ps3);
-        psum = attn_xsum32(psum);
-        l_run += psum;
-
-        // the second half's V^T fragments go out now (the fp32 scores are dead, their registers are free) and land under the first half's
-        // products; LDS returns in order, so a counted wait releases the first half while the second is still in flight
-        __builtin_amdgcn_sched_barrier(0);
-        attn_static_for<0, 2>([&](auto s2c) {
-            constexpr int s2 = decltype(s2c)::value;
-#pragma unroll
-            for (int d = 0; d < DT; ++d) {
-                vlo[1][s2][d] = attn_tr16i<VBASE + (32 + 16 * s2) * ROWB>(v_off[d][0]);
-                vhi[1][s2][d] = attn_tr16i<VBASE + (32 + 16 * s2) * ROWB>(v_off[d][1]);
-            }
-        });
-        asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(4 * DT) : "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-        attn_static_for<0, 2>([&](auto ktc) {
-            constexpr int kt = decltype(ktc)::value;
             if constexpr (kt == 1) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
+                float psum = (ps0 + ps1) + (ps2 + ps3);
+                psum = attn_xsum32(psum);
+                l_run += psum;
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 u32x4_t pv4;
@@ -283,8 +295,21 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(64 
                     oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[d], 0, 0, 0);
                 }
             }
+            if (PRIO) __builtin_amdgcn_s_setprio(0);
+            if constexpr (kt == 0) {
+                // second half's V^T fragments: requested behind the first half's products, they land under the second half's exponentials
+                __builtin_amdgcn_sched_barrier(0);
+                attn_static_for<0, 2>([&](auto s2c) {
+                    constexpr int s2 = decltype(s2c)::value;
+#pragma unroll
+                    for (int d = 0; d < DT; ++d) {
+                        vlo[1][s2][d] = attn_tr16i<VBASE + (32 + 16 * s2) * ROWB>(v_off[d][0]);
+                        vhi[1][s2][d] = attn_tr16i<VBASE + (32 + 16 * s2) * ROWB>(v_off[d][1]);
+                    }
+                });
+                __builtin_amdgcn_sched_barrier(0);
+            }
         });
-        __builtin_amdgcn_s_setprio(0);
         asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LPT) : "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -336,7 +361,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(64 
 // accumulators), p = exp2(c s - lse), dS = p (dP - D) packed to bf16, dQ^T += K^T dS^T (4 MFMAs).  Keys past the end need no mask
 // here: their K rows are zeros (descriptor range check), so whatever p they get multiplies a zero row; only the causal diagonal does.
 // ------------------------------------------------------------------------------------------------------------------------------
-template <int DH, int NW, bool KVSAME>
+template <int DH, int NW, bool KVSAME, bool PRIO>
 __global__ void __attribute__((amdgpu_waves_per_eu(3, 3))) __launch_bounds__(64 * NW) attn_bwd_dq3_kernel(const AttnBwdArgs a) {
     constexpr int KT = 64, ROWB = DH * 2, CPR = DH / 8, TILE = KT * ROWB, KS = DH / 16, DT = DH / 32;
     constexpr int SLABS = TILE / 1024, LPW = SLABS / NW, LPT = KVSAME ? LPW : 2 * LPW;
@@ -346,7 +371,9 @@ __global__ void __attribute__((amdgpu_waves_per_eu(3, 3))) __launch_bounds__(64 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int qtiles = (a.Sq + 32 * NW - 1) / (32 * NW);
-    const int seq = blockIdx.x / qtiles, qtile = blockIdx.x % qtiles, head = blockIdx.y;
+    const AttnBlock blk = attn_block_of(a.xcd_swizzle, a.nseq, a.nhead, qtiles);
+    if (!blk.live) return;
+    const int seq = blk.seq, qtile = blk.tile, head = blk.head;
     const int q0 = qtile * (32 * NW) + wave * 32;
     const int qi = q0 + (lane & 31), h = lane >> 5;
     bf16x8_t qf[KS], dof[KS];
@@ -447,13 +474,13 @@ __global__ void __attribute__((amdgpu_waves_per_eu(3, 3))) __launch_bounds__(64 
             f32x16_t sacc, pacc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; pacc[r] = 0.f; }
-            __builtin_amdgcn_s_setprio(1);
+            if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[ks], qf[ks], sacc, 0, 0, 0);                                   // S^T
                 pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(KVSAME ? kfr[ks] : vfr[KVSAME ? 0 : ks], dof[ks], pacc, 0, 0, 0);  // dP^T
             }
-            __builtin_amdgcn_s_setprio(0);
+            if (PRIO) __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             // K^T fragments of this half for dQ^T += K^T dS^T: requested now, they land under the element-wise phase
             bf16x4_t klo[2][DT], khi[2][DT];
@@ -478,7 +505,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(3, 3))) __launch_bounds__(64 
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_setprio(1);
+            if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 u32x4_t d4;
@@ -492,7 +519,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(3, 3))) __launch_bounds__(64 
                     dq[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kT, df, dq[d], 0, 0, 0);                                     // dQ^T += K^T dS^T
                 }
             }
-            __builtin_amdgcn_s_setprio(0);
+            if (PRIO) __builtin_amdgcn_s_setprio(0);
         });
         asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LPT) : "memory");
         __builtin_amdgcn_s_barrier();
@@ -535,7 +562,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(3, 3))) __launch_bounds__(64 
 // (K == V) keeps a single copy of the lane's key row.  Queries past the end are zero rows (descriptor range check) with lse = D = 0:
 // p = 1 multiplies dO = 0 / dP - D = 0, so only the causal diagonal needs a mask.
 // ------------------------------------------------------------------------------------------------------------------------------
-template <int DH, int NW, bool KVSAME>
+template <int DH, int NW, bool KVSAME, bool PRIO>
 __global__ void __attribute__((amdgpu_waves_per_eu(3, 3))) __launch_bounds__(64 * NW) attn_bwd_dkv3_kernel(const AttnBwdArgs a) {
     constexpr int QT = 64, ROWB = DH * 2, CPR = DH / 8, TILE = QT * ROWB, KS = DH / 16, DT = DH / 32;
     constexpr int SLABS = TILE / 1024, LPW = SLABS / NW, LPT = 2 * LPW + 2;
@@ -545,7 +572,9 @@ __global__ void __attribute__((amdgpu_waves_per_eu(3, 3))) __launch_bounds__(64 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ktiles = (a.Sk + 32 * NW - 1) / (32 * NW);
-    const int seq = blockIdx.x / ktiles, ktile_i = blockIdx.x % ktiles, head = blockIdx.y;
+    const AttnBlock blk = attn_block_of(a.xcd_swizzle, a.nseq, a.nhead, ktiles);
+    if (!blk.live) return;
+    const int seq = blk.seq, ktile_i = blk.tile, head = blk.head;
     const int key0 = ktile_i * (32 * NW) + wave * 32;
     const int ki = key0 + (lane & 31), h = lane >> 5;
     bf16x8_t kf[KS], vf[KVSAME ? 1 : KS];
@@ -668,7 +697,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(3, 3))) __launch_bounds__(64 
             f32x16_t sacc, pacc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; pacc[r] = 0.f; }
-            __builtin_amdgcn_s_setprio(1);
+            if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr[ks], kf[ks], sacc, 0, 0, 0);                          // S[q][key]
@@ -676,7 +705,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(3, 3))) __launch_bounds__(64 
                 if (ks + 2 < KS) load_a(ks + 2);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_s_setprio(0);
+            if (PRIO) __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             // dO^T fragments of this half for dV^T += dO^T P: requested now, they land under the element-wise phase
             bf16x4_t tlo[2][DT], thi[2][DT];
@@ -710,7 +739,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(3, 3))) __launch_bounds__(64 
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_setprio(1);
+            if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 u32x4_t p4;
@@ -724,7 +753,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(3, 3))) __launch_bounds__(64 
                     dv[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(doT, pf, dv[d], 0, 0, 0);           // dV^T += dO^T P
                 }
             }
-            __builtin_amdgcn_s_setprio(0);
+            if (PRIO) __builtin_amdgcn_s_setprio(0);
             // Q^T fragments into the registers the dO^T fragments just left; they land while the matrix pipe drains the four products above
             __builtin_amdgcn_sched_barrier(0);
             attn_static_for<0, 2>([&](auto s2c) {
@@ -737,7 +766,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(3, 3))) __launch_bounds__(64 
             });
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_setprio(1);
+            if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 u32x4_t d4;
@@ -751,7 +780,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(3, 3))) __launch_bounds__(64 
                     dk[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qT, df, dk[d], 0, 0, 0);            // dK^T += Q^T dS
                 }
             }
-            __builtin_amdgcn_s_setprio(0);
+            if (PRIO) __builtin_amdgcn_s_setprio(0);
         });
         asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LPT) : "memory");
         __builtin_amdgcn_s_barrier();
@@ -817,16 +846,18 @@ __global__ void __attribute__((amdgpu_waves_per_eu(3, 3))) __launch_bounds__(64 
 // ------------------------------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------------------------------
-// GENIE_ATTN_LEAN: bit 0 forward, bit 1 backward dQ, bit 2 backward dK / dV (default 7; 0 sends everything through attention.hip's
-// general kernels -- A/B timing and the tests that compare the two families)
+// GENIE_ATTN_LEAN / genie_attention_lean_mode: bit 0 forward, bit 1 backward dQ, bit 2 backward dK / dV on the lean kernels (0 sends
+// everything through attention.hip's general kernels -- A/B timing and the tests that compare the two families); bit 3: no s_setprio
+// around the MFMA clusters; bit 4: deferred running maximum in the forward (see attn_fwd4_kernel)
+#define LEAN_DEFAULT 23      // lean forward + dQ + dK-dV, deferred running maximum
 static int g_lean_mode = -1;
 static int lean_mode() {
-    if (g_lean_mode < 0) { const char* e = getenv("GENIE_ATTN_LEAN"); g_lean_mode = e ? atoi(e) : 7; }
+    if (g_lean_mode < 0) { const char* e = getenv("GENIE_ATTN_LEAN"); g_lean_mode = e ? atoi(e) : LEAN_DEFAULT; }
     return g_lean_mode;
 }
 extern "C" int genie_attention_lean_mode(int mask) {
     const int old = lean_mode();
-    if (mask >= 0) g_lean_mode = mask & 7;
+    if (mask >= 0) g_lean_mode = mask & 63;
     return old;
 }
 // byte offsets inside a sequence travel as 32-bit buffer offsets / record counts
@@ -847,31 +878,52 @@ int genie_attn_lean_bwd_mask(const AttnBwdArgs& a, int d_head) {
     return m;
 }
 
-int genie_attn_lean_fwd(const AttnArgs& a, hipStream_t s) {
+// grid of a lean launch: XCD-swizzled 1-D (default) or the general kernels' (sequence * tiles, head)
+static dim3 lean_grid(int nseq, int nhead, int tiles, int* swizzle) {
+    *swizzle = (lean_mode() & 32) ? 0 : 1;
+    if (!*swizzle) return dim3((unsigned)(nseq * tiles), (unsigned)nhead, 1);
+    const long long n = (long long)nseq * nhead * tiles;
+    return dim3((unsigned)(((n + 7) / 8) * 8), 1, 1);
+}
+
+int genie_attn_lean_fwd(const AttnArgs& a_in, hipStream_t s) {
+    AttnArgs a = a_in;
     constexpr int nw = 4;
     const int qtiles = (a.Sq + 32 * nw - 1) / (32 * nw);
-    GENIE_CHECK_ARG((long long)a.nseq * qtiles < (1ll << 31) && a.nhead <= 65535, "genie_attention_fwd: grid too large");
+    GENIE_CHECK_ARG((long long)a.nseq * qtiles * a.nhead < (1ll << 31) - 8 && a.nhead <= 65535, "genie_attention_fwd: grid too large");
     const int tile = 64 * 64 * 2;
     int lds = 3 * (a.kv_same ? tile : 2 * tile);
     if (lds < nw * 32 * 64 * 4) lds = nw * 32 * 64 * 4;               // the epilogue stages NW x 32 fp32 rows in the ring's memory
-    dim3 grid((unsigned)(a.nseq * qtiles), a.nhead, 1);
-    if (a.kv_same) attn_fwd4_kernel<64, 4, true><<<grid, 64 * nw, lds, s>>>(a);
-    else attn_fwd4_kernel<64, 4, false><<<grid, 64 * nw, lds, s>>>(a);
+    const dim3 grid = lean_grid(a.nseq, a.nhead, qtiles, &a.xcd_swizzle);
+    const bool prio = !(lean_mode() & 8), defer = (lean_mode() & 16) != 0;
+#define LEAN_FWD(KV)                                                                                     \
+    do {                                                                                                 \
+        if (prio && defer) attn_fwd4_kernel<64, 4, KV, true, true><<<grid, 64 * nw, lds, s>>>(a);        \
+        else if (prio) attn_fwd4_kernel<64, 4, KV, true, false><<<grid, 64 * nw, lds, s>>>(a);           \
+        else if (defer) attn_fwd4_kernel<64, 4, KV, false, true><<<grid, 64 * nw, lds, s>>>(a);          \
+        else attn_fwd4_kernel<64, 4, KV, false, false><<<grid, 64 * nw, lds, s>>>(a);                    \
+    } while (0)
+    if (a.kv_same) LEAN_FWD(true); else LEAN_FWD(false);
+#undef LEAN_FWD
     GENIE_CHECK_LAUNCH();
     return GENIE_OK;
 }
 
-int genie_attn_lean_bwd_dq(const AttnBwdArgs& a, hipStream_t s) {
+int genie_attn_lean_bwd_dq(const AttnBwdArgs& a_in, hipStream_t s) {
+    AttnBwdArgs a = a_in;
     int nw = (a.Sq + 31) / 32;
     nw = nw >= 3 ? 4 : nw;
     const int qtiles = (a.Sq + 32 * nw - 1) / (32 * nw);
     const int tile = 64 * 64 * 2;
     const int lds = 3 * (a.kv_same ? tile : 2 * tile);
-    dim3 grid((unsigned)(a.nseq * qtiles), a.nhead, 1);
+    const dim3 grid = lean_grid(a.nseq, a.nhead, qtiles, &a.xcd_swizzle);
+    const bool prio = !(lean_mode() & 8);
 #define LEAN_DQ(NWv)                                                                                     \
     do {                                                                                                 \
-        if (a.kv_same) attn_bwd_dq3_kernel<64, NWv, true><<<grid, 64 * NWv, lds, s>>>(a);                \
-        else attn_bwd_dq3_kernel<64, NWv, false><<<grid, 64 * NWv, lds, s>>>(a);                         \
+        if (a.kv_same && prio) attn_bwd_dq3_kernel<64, NWv, true, true><<<grid, 64 * NWv, lds, s>>>(a);  \
+        else if (a.kv_same) attn_bwd_dq3_kernel<64, NWv, true, false><<<grid, 64 * NWv, lds, s>>>(a);    \
+        else if (prio) attn_bwd_dq3_kernel<64, NWv, false, true><<<grid, 64 * NWv, lds, s>>>(a);         \
+        else attn_bwd_dq3_kernel<64, NWv, false, false><<<grid, 64 * NWv, lds, s>>>(a);                  \
     } while (0)
     if (nw == 1) LEAN_DQ(1); else if (nw == 2) LEAN_DQ(2); else LEAN_DQ(4);
 #undef LEAN_DQ
@@ -879,15 +931,33 @@ int genie_attn_lean_bwd_dq(const AttnBwdArgs& a, hipStream_t s) {
     return GENIE_OK;
 }
 
-int genie_attn_lean_bwd_dkv(const AttnBwdArgs& a, hipStream_t s) {
+int genie_attn_lean_bwd_dkv(const AttnBwdArgs& a_in, hipStream_t s) {
+    AttnBwdArgs a = a_in;
     int nw = (a.Sk + 31) / 32;
     nw = nw >= 3 ? 4 : nw;
     const int ktiles = (a.Sk + 32 * nw - 1) / (32 * nw);
     const int tile = 64 * 64 * 2;
     const int lds = 3 * (2 * tile + 512);
-    dim3 grid((unsigned)(a.nseq * ktiles), a.nhead, 1);
-    if (nw == 2) attn_bwd_dkv3_kernel<64, 2, true><<<grid, 128, lds, s>>>(a);
-    else attn_bwd_dkv3_kernel<64, 4, true><<<grid, 256, lds, s>>>(a);
+    const dim3 grid = lean_grid(a.nseq, a.nhead, ktiles, &a.xcd_swizzle);
+    const bool prio = !(lean_mode() & 8);
+    if (nw == 2 && prio) attn_bwd_dkv3_kernel<64, 2, true, true><<<grid, 128, lds, s>>>(a);
+    else if (nw == 2) attn_bwd_dkv3_kernel<64, 2, true, false><<<grid, 128, lds, s>>>(a);
+    else if (prio) attn_bwd_dkv3_kernel<64, 4, true, true><<<grid, 256, lds, s>>>(a);
+    else attn_bwd_dkv3_kernel<64, 4, true, false><<<grid, 256, lds, s>>>(a);
     GENIE_CHECK_LAUNCH();
     return GENIE_OK;
+}
+
+// Resident blocks per CU the runtime computes for a lean kernel at its launch configuration (which: 0 forward, 1 dQ, 2 dK / dV; four waves per
+// block, K == V layout).  The kernels are budgeted for 4 / 3 / 3 blocks per CU; a toolchain that allocates differently shows here
+// (tests/test_gpu_attention.py) instead of as a silent slowdown.
+extern "C" int genie_attention_lean_occupancy(int which) {
+    int n = -1;
+    const int tile = 64 * 64 * 2;
+    hipError_t e;
+    if (which == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_fwd4_kernel<64, 4, true, true, false>, 256, 4 * 32 * 64 * 4);
+    else if (which == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_bwd_dq3_kernel<64, 4, true, true>, 256, 3 * tile);
+    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_bwd_dkv3_kernel<64, 4, true, true>, 256, 3 * (2 * tile + 512));
+    if (e != hipSuccess) { genie_set_error("hipOccupancyMaxActiveBlocksPerMultiprocessor: %s", hipGetErrorString(e)); return -1; }
+    return n;
 }

@@ -21,6 +21,7 @@ struct AttnArgs {
     float scale;
     int causal;
     int kv_same;                // k == v tile (one LDS image)
+    int xcd_swizzle;            // lean kernels: 1-D grid, workgroup -> (sequence, head, tile) through attn_block_of (0: blockIdx.x / .y as is)
 };
 
 struct AttnBwdArgs {
@@ -34,6 +35,7 @@ struct AttnBwdArgs {
     int nseq, nhead, Sq, Sk, C, Ckv;
     float scale;
     int causal, kv_same, fuse_self;
+    int xcd_swizzle;            // as AttnArgs::xcd_swizzle
 };
 
 

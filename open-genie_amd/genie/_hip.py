@@ -113,6 +113,7 @@ SIGNATURES = {
     'genie_attention_fwd': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _PL, _PL, _PL, _F, _I, _I, _P]),
     'genie_attention_bwd': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _PL, _PL, _PL, _PL, _F, _I, _I, _L, _P]),
     'genie_attention_lean_mode': (C.c_int, [_I]),
+    'genie_attention_lean_occupancy': (C.c_int, [_I]),
     'genie_probe_ds_read_tr16': (C.c_int, [_P, _P, _P, _P]),
 }
 

@@ -227,7 +227,7 @@ def test_attention_lean_and_general_kernels_agree():
         do = (torch.randn(nseq, sq, c, device='cuda') * 0.5).to(torch.bfloat16)
         qmap = _hip.i64((1, sq * c, 0, c))
         res = []
-        for mode in (7, 0):
+        for mode in (lib.genie_attention_lean_mode(-1) | 7, 0):
             old = lib.genie_attention_lean_mode(mode)
             try:
                 out, lse = torch.empty_like(q), torch.empty(nseq * sq * nhead, device='cuda')
@@ -244,6 +244,46 @@ def test_attention_lean_and_general_kernels_agree():
         assert (o1 - o0).abs().max().item() <= 2 ** -7 * o0.abs().max().item() + 1e-6          # a bf16 ulp or two of the output
         assert (l1 - l0).abs().max().item() <= 1e-4
         assert rel_rms(g1, g0) < 2e-3, rel_rms(g1, g0)
+
+
+@pytest.mark.parametrize('mode', [7, 7 | 8, 7 | 16, 7 | 8 | 16])
+def test_attention_forward_variants_with_late_maxima(mode):
+    """The lean forward's switches (genie_attention_lean_mode bit 3: no s_setprio; bit 4: deferred running maximum) on scores built to move
+    the maximum LATE and by a lot: a few keys far into the sequence are strongly aligned with particular queries (raw score well above
+    everything before them), others only slightly (growth below the deferral threshold) -- the rescale branch fires in the middle of the
+    key loop for some rows of a wave and not for others.  Output and log-sum-exp against fp32 softmax attention, every variant
+    (cdna_hip_programming.md T13: a passing check on bounded random scores says nothing about this branch)."""
+    from genie import _hip
+    lib = _hip.load_library()
+    P = _hip.ptr
+    torch.manual_seed(77)
+    nseq, nhead, dh, S = 2, 2, 64, 1024
+    c = nhead * dh
+    scale = dh ** -0.5 * 2.0
+    q = torch.randn(nseq, S, c) * 0.7
+    k = torch.randn(nseq, S, c) * 0.7
+    v = torch.randn(nseq, S, c)
+    for (qi, ki, gain) in ((5, 700, 6.0), (37, 901, 3.0), (300, 130, 8.0), (1000, 1023, 5.0), (64, 64, 1.5), (511, 333, 1.2)):
+        k[:, ki] = q[:, qi] * gain                           # one key per chosen query, far above (or just above) that row's other scores
+    q, k, v = bf16_round(q), bf16_round(k), bf16_round(v)
+    qh = q.reshape(nseq, S, nhead, dh).transpose(1, 2)
+    kh = k.reshape(nseq, S, nhead, dh).transpose(1, 2)
+    vh = v.reshape(nseq, S, nhead, dh).transpose(1, 2)
+    sc = (qh @ kh.transpose(-1, -2)) * scale
+    o_ref = (sc.softmax(-1) @ vh).transpose(1, 2).reshape(nseq, S, c)
+    lse_ref = sc.logsumexp(-1).transpose(1, 2).contiguous()
+    assert (sc.max(-1).values - sc[..., :64].max(-1).values).max().item() * 1.4427 > 20      # the late keys do move the maximum past any threshold
+    qd, kd, vd = (t.cuda().to(torch.bfloat16) for t in (q, k, v))
+    out, lse = torch.empty_like(qd), torch.empty(nseq * S * nhead, device='cuda')
+    m = _hip.i64((1, S * c, 0, c))
+    old = lib.genie_attention_lean_mode(mode)
+    try:
+        _hip.check(lib.genie_attention_fwd(P(qd), P(kd), P(vd), None, P(out), None, P(lse), nseq, nhead, dh, S, S, m, m, m, scale, 0, c, _hip.stream_ptr()), 'fwd')
+        torch.cuda.synchronize()
+    finally:
+        lib.genie_attention_lean_mode(old)
+    assert_close_bf16(out, o_ref, f'attention fwd, late maxima, mode {mode}', rms_frac=8e-3)
+    torch.testing.assert_close(lse.cpu().reshape(nseq, S, nhead), lse_ref, rtol=2e-3, atol=2e-3)
 
 
 @pytest.mark.parametrize('nseq,nhead,dh,sq,sk,causal,cross', CORE_CASES)
