@@ -377,15 +377,15 @@ int genie_attention_fwd(const void* q, const void* k, const void* v, const void*
                         int causal, int out_channels, void* stream);
 /* `out` must be the attention output WITHOUT the residual (o_attn of the forward) when resid is NULL; with resid given,
  * out - resid is used (less accurate).  Self-attention (q == k == v): dq receives dQ + dK + dV.  Otherwise dq gets dQ and
- * dk / dv (addressed by dkv_map, which must not alias across sequences) get dK / dV.  D_ws: fp32 [2][out_tokens][nhead] scratch
- * (ABI 10: D = rowsum(dO * O), then lse * log2 e -- the form the exp2-domain backward kernels subtract). */
+ * dk / dv (addressed by dkv_map, which must not alias across sequences) get dK / dV.  D_ws: fp32 [3][out_tokens][nhead] scratch
+ * (ABI 10: D = rowsum(dO * O), then lse * log2 e and -D -- the forms the exp2-domain backward kernels consume). */
 int genie_attention_bwd(const void* q, const void* k, const void* v, const void* out, const void* resid, const void* dO,
                         const float* lse, float* D_ws, void* dq, void* dk, void* dv, int nseq, int nhead, int d_head, int Sq, int Sk,
                         const int64_t* q_map, const int64_t* kv_map, const int64_t* out_map, const int64_t* dkv_map, float scale,
                         int causal, int out_channels, int64_t out_tokens, void* stream);
 
 /* d_head 64 runs on register-lean kernels (attention_lean.hip: four / three waves per SIMD) where their preconditions hold.  mask: bit 0
- * forward, bit 1 backward dQ, bit 2 backward dK / dV; bit 3: no s_setprio around the MFMA clusters; bit 4: the forward's running maximum is
+ * forward, bit 1 backward dQ, bit 2 backward dK / dV; bit 3: reserved; bit 4: the forward's running maximum is
  * deferred (O, l rescaled only when a tile's maximum exceeds it by more than 2^8 in the exp2 domain; P <= 2^8 instead of <= 1, the row's
  * largest weight is then rounded to bf16 like every other one instead of being exactly 1); bit 5: plain grid instead of the XCD-aware one.
  * A negative mask only queries.  Returns the previous mask (default 23 = bits 0, 1, 2, 4, or the GENIE_ATTN_LEAN environment variable).

@@ -804,7 +804,7 @@ extern "C" int genie_attention_fwd(const void* q, const void* k, const void* v, 
 template <int DH>
 __global__ void __launch_bounds__(256) attn_bwd_prep_kernel(const bf16_t* __restrict__ dO, const bf16_t* __restrict__ out,
                                                             const bf16_t* __restrict__ resid, float* __restrict__ D, long long ntok, int C,
-                                                            int nhead, const float* __restrict__ lse, float* __restrict__ lse2) {
+                                                            int nhead, const float* __restrict__ lse, float* __restrict__ lse2, float* __restrict__ negD) {
     const int lane = threadIdx.x & 63;
     const long long tok = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (tok >= ntok) return;
@@ -830,6 +830,7 @@ __global__ void __launch_bounds__(256) attn_bwd_prep_kernel(const bf16_t* __rest
         if (ch < nch && (ch % LPH) == 0) {
             D[tok * nhead + ch / LPH] = acc;
             lse2[tok * nhead + ch / LPH] = lse[tok * nhead + ch / LPH] * 1.4426950408889634f;      // the exp2-domain form the backward kernels subtract
+            negD[tok * nhead + ch / LPH] = -acc;                                                  // accumulator input of the lean kernels' dP products
         }
     }
 }
@@ -1428,6 +1429,7 @@ extern "C" int genie_attention_bwd(const void* q, const void* k, const void* v, 
     AttnBwdArgs a;
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.dO = (const bf16_t*)dO; a.lse = lse; a.D = D_ws;
     a.lse2 = D_ws + out_tokens * nhead;
+    a.negD = D_ws + 2 * out_tokens * nhead;
     a.dq = (bf16_t*)dq; a.dk = self ? (bf16_t*)dq : (bf16_t*)dk; a.dv = (bf16_t*)dv; a.dq_in = (const bf16_t*)dq;
     a.qm = mk_map(q_map); a.km = mk_map(kv_map); a.om = mk_map(out_map); a.dkm = dkv_map ? mk_map(dkv_map) : a.km;
     a.nseq = nseq; a.nhead = nhead; a.Sq = Sq; a.Sk = Sk; a.C = out_channels; a.Ckv = 0; a.scale = scale; a.causal = causal;
@@ -1437,9 +1439,9 @@ extern "C" int genie_attention_bwd(const void* q, const void* k, const void* v, 
     GENIE_CHECK_ARG(scale > 0.f, "genie_attention_bwd: scale must be positive (got %g)", (double)scale);
     if (d_head < 32) return genie_attn_narrow_bwd(a, d_head, s);                                     // D + dQ, then dK / dV (attention_narrow.hip)
     const unsigned pblocks = (unsigned)((out_tokens + 3) / 4);
-    if (d_head == 32) attn_bwd_prep_kernel<32><<<pblocks, 256, 0, s>>>((const bf16_t*)dO, (const bf16_t*)out, (const bf16_t*)resid, D_ws, out_tokens, out_channels, nhead, lse, D_ws + out_tokens * nhead);
-    else if (d_head == 64) attn_bwd_prep_kernel<64><<<pblocks, 256, 0, s>>>((const bf16_t*)dO, (const bf16_t*)out, (const bf16_t*)resid, D_ws, out_tokens, out_channels, nhead, lse, D_ws + out_tokens * nhead);
-    else attn_bwd_prep_kernel<128><<<pblocks, 256, 0, s>>>((const bf16_t*)dO, (const bf16_t*)out, (const bf16_t*)resid, D_ws, out_tokens, out_channels, nhead, lse, D_ws + out_tokens * nhead);
+    if (d_head == 32) attn_bwd_prep_kernel<32><<<pblocks, 256, 0, s>>>((const bf16_t*)dO, (const bf16_t*)out, (const bf16_t*)resid, D_ws, out_tokens, out_channels, nhead, lse, D_ws + out_tokens * nhead, D_ws + 2 * out_tokens * nhead);
+    else if (d_head == 64) attn_bwd_prep_kernel<64><<<pblocks, 256, 0, s>>>((const bf16_t*)dO, (const bf16_t*)out, (const bf16_t*)resid, D_ws, out_tokens, out_channels, nhead, lse, D_ws + out_tokens * nhead, D_ws + 2 * out_tokens * nhead);
+    else attn_bwd_prep_kernel<128><<<pblocks, 256, 0, s>>>((const bf16_t*)dO, (const bf16_t*)out, (const bf16_t*)resid, D_ws, out_tokens, out_channels, nhead, lse, D_ws + out_tokens * nhead, D_ws + 2 * out_tokens * nhead);
     GENIE_CHECK_LAUNCH();
     GENIE_CHECK_ARG(scale > 0.f, "genie_attention_bwd: scale must be positive (got %g)", (double)scale);
     if (self && Sq == Sk && Sq <= 32 && same_map(a.qm, a.km) && small_attn_mode()) {

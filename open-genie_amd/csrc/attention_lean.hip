@@ -82,11 +82,11 @@ __device__ __forceinline__ void attn_static_for(F&& f) {
         attn_static_for<I + 1, N>(f);
     }
 }
-// PRIO: s_setprio(1) around the MFMA clusters (the general kernels' habit).  DEFER: the running maximum only moves -- and O, l are only
+// DEFER: the running maximum only moves -- and O, l are only
 // rescaled -- when some lane's tile maximum exceeds it by more than 2^8 in the exp2 domain (defer-max, cdna_hip_programming.md T13):
 // P is then bounded by 2^8 instead of 1, which neither fp32 sums nor bf16 P mind; on i.i.d. scores the exact rule rescales on two
 // tiles out of three (any of 32 queries meeting a new maximum), 35 VALU instructions each, in a loop that is VALU-bound.
-template <int DH, int NW, bool KVSAME, bool PRIO, bool DEFER>
+template <int DH, int NW, bool KVSAME, bool DEFER>
 __global__ void __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(64 * NW) attn_fwd4_kernel(const AttnArgs a) {
     constexpr int KT = 64, ROWB = DH * 2, CPR = DH / 8, TILE = KT * ROWB, KS = DH / 16, DT = DH / 32;
     constexpr int SLABS = TILE / 1024, LPW = SLABS / NW, LPT = KVSAME ? LPW : 2 * LPW;
@@ -198,7 +198,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(64 
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt) kfr[kt][ks] = *reinterpret_cast<const bf16x8_t*>(smem + KBASE + kt * 32 * ROWB + k_off[ks]);
         __builtin_amdgcn_sched_barrier(0);
-        if (PRIO) __builtin_amdgcn_s_setprio(1);
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -207,7 +207,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(64 
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt) sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[kt][ks], qf[ks], sacc[kt], 0, 0, 0);
-        if (PRIO) __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(0);
         // V^T fragments of the first 32 keys: requested now, they land under the maximum / first-half exponentials
         bf16x4_t vlo[2][2][DT], vhi[2][2][DT];
         attn_static_for<0, 2>([&](auto s2c) {
@@ -281,7 +281,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(64 
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
-            if (PRIO) __builtin_amdgcn_s_setprio(1);
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 u32x4_t pv4;
@@ -295,7 +295,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(64 
                     oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[d], 0, 0, 0);
                 }
             }
-            if (PRIO) __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_setprio(0);
             if constexpr (kt == 0) {
                 // second half's V^T fragments: requested behind the first half's products, they land under the second half's exponentials
                 __builtin_amdgcn_sched_barrier(0);
@@ -361,7 +361,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(64 
 // accumulators), p = exp2(c s - lse), dS = p (dP - D) packed to bf16, dQ^T += K^T dS^T (4 MFMAs).  Keys past the end need no mask
 // here: their K rows are zeros (descriptor range check), so whatever p they get multiplies a zero row; only the causal diagonal does.
 // ------------------------------------------------------------------------------------------------------------------------------
-template <int DH, int NW, bool KVSAME, bool PRIO>
+template <int DH, int NW, bool KVSAME>
 __global__ void __attribute__((amdgpu_waves_per_eu(3, 3))) __launch_bounds__(64 * NW) attn_bwd_dq3_kernel(const AttnBwdArgs a) {
     constexpr int KT = 64, ROWB = DH * 2, CPR = DH / 8, TILE = KT * ROWB, KS = DH / 16, DT = DH / 32;
     constexpr int SLABS = TILE / 1024, LPW = SLABS / NW, LPT = KVSAME ? LPW : 2 * LPW;
@@ -377,7 +377,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(3, 3))) __launch_bounds__(64 
     const int q0 = qtile * (32 * NW) + wave * 32;
     const int qi = q0 + (lane & 31), h = lane >> 5;
     bf16x8_t qf[KS], dof[KS];
-    float lse2 = 0.f, D_q = 0.f;                  // lse * log2(e)
+    float lse2 = 0.f, nD_q = 0.f;                 // lse * log2(e); -D
     {
         const bool ok = qi < a.Sq;
         const long long qoff = seq_base(a.qm, seq) + (long long)(ok ? qi : 0) * a.qm.pos_stride;
@@ -395,7 +395,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(3, 3))) __launch_bounds__(64 
         if (ok) {
             const long long tok = ooff / a.C;
             lse2 = a.lse2[tok * a.nhead + head];
-            D_q = a.D[tok * a.nhead + head];
+            nD_q = -a.D[tok * a.nhead + head];
         }
     }
     f32x16_t dq[DT];
@@ -403,6 +403,11 @@ __global__ void __attribute__((amdgpu_waves_per_eu(3, 3))) __launch_bounds__(64 
     for (int d = 0; d < DT; ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dq[d][r] = 0.f;
+    // dS = p (dP - D): the subtraction rides in the dP^T product as its accumulator INPUT -- a lane's 16 accumulator rows all belong to
+    // its one query, so a block of 16 registers holding -D feeds the first MFMA of every half (16 registers for 32 v_sub_f32 per tile)
+    f32x16_t negD;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) negD[r] = nD_q;
     const float c2 = a.scale * 1.4426950408889634f;
     const int blk_q_max = qtile * (32 * NW) + 32 * NW - 1;
     int k_end = a.Sk;
@@ -471,16 +476,16 @@ __global__ void __attribute__((amdgpu_waves_per_eu(3, 3))) __launch_bounds__(64 
                 if (!KVSAME) vfr[ks] = *reinterpret_cast<const bf16x8_t*>(smem + VBASE + kt * 32 * ROWB + k_off[ks]);
             }
             __builtin_amdgcn_sched_barrier(0);
-            f32x16_t sacc, pacc;
+            f32x16_t sacc, pacc = negD;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; pacc[r] = 0.f; }
-            if (PRIO) __builtin_amdgcn_s_setprio(1);
+            for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[ks], qf[ks], sacc, 0, 0, 0);                                   // S^T
-                pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(KVSAME ? kfr[ks] : vfr[KVSAME ? 0 : ks], dof[ks], pacc, 0, 0, 0);  // dP^T
+                pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(KVSAME ? kfr[ks] : vfr[KVSAME ? 0 : ks], dof[ks], pacc, 0, 0, 0);  // dP^T - D
             }
-            if (PRIO) __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             // K^T fragments of this half for dQ^T += K^T dS^T: requested now, they land under the element-wise phase
             bf16x4_t klo[2][DT], khi[2][DT];
@@ -501,11 +506,11 @@ __global__ void __attribute__((amdgpu_waves_per_eu(3, 3))) __launch_bounds__(64 
             for (int e = 0; e < 8; ++e) {
                 const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[2 * e], c2, -lse2));
                 const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[2 * e + 1], c2, -lse2));
-                dw[e] = pack_bf16x2(p0 * (pacc[2 * e] - D_q), p1 * (pacc[2 * e + 1] - D_q));                                     // dS^T / scale
+                dw[e] = pack_bf16x2(p0 * pacc[2 * e], p1 * pacc[2 * e + 1]);                                     // dS^T / scale
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
-            if (PRIO) __builtin_amdgcn_s_setprio(1);
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 u32x4_t d4;
@@ -519,7 +524,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(3, 3))) __launch_bounds__(64 
                     dq[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kT, df, dq[d], 0, 0, 0);                                     // dQ^T += K^T dS^T
                 }
             }
-            if (PRIO) __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_setprio(0);
         });
         asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LPT) : "memory");
         __builtin_amdgcn_s_barrier();
@@ -562,11 +567,11 @@ __global__ void __attribute__((amdgpu_waves_per_eu(3, 3))) __launch_bounds__(64 
 // (K == V) keeps a single copy of the lane's key row.  Queries past the end are zero rows (descriptor range check) with lse = D = 0:
 // p = 1 multiplies dO = 0 / dP - D = 0, so only the causal diagonal needs a mask.
 // ------------------------------------------------------------------------------------------------------------------------------
-template <int DH, int NW, bool KVSAME, bool PRIO>
+template <int DH, int NW, bool KVSAME>
 __global__ void __attribute__((amdgpu_waves_per_eu(3, 3))) __launch_bounds__(64 * NW) attn_bwd_dkv3_kernel(const AttnBwdArgs a) {
     constexpr int QT = 64, ROWB = DH * 2, CPR = DH / 8, TILE = QT * ROWB, KS = DH / 16, DT = DH / 32;
     constexpr int SLABS = TILE / 1024, LPW = SLABS / NW, LPT = 2 * LPW + 2;
-    constexpr int STAGE = 2 * TILE + 512;            // Q tile | dO tile | lse * log2e [64] | D [64]
+    constexpr int STAGE = 2 * TILE + 512;            // Q tile | dO tile | lse * log2e [64] | -D [64]
     static_assert(SLABS % NW == 0, "every wave stages the same number of pieces (counted vmcnt)");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -645,7 +650,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(3, 3))) __launch_bounds__(64 
             if (t < ntile && qrow < a.Sq) {
                 const long long tok = tok_seq + (long long)qrow * tok_step;
                 pl = a.lse2 + tok * a.nhead + head;
-                pd = a.D + tok * a.nhead + head;
+                pd = a.negD + tok * a.nhead + head;
             }
             attn_dma4(pl, qt_ + 2 * TILE);
             attn_dma4(pd, qt_ + 2 * TILE + 256);
@@ -694,18 +699,26 @@ __global__ void __attribute__((amdgpu_waves_per_eu(3, 3))) __launch_bounds__(64 
             load_a(0);
             if (KS > 1) load_a(1);
             __builtin_amdgcn_sched_barrier(0);
+            // dS = p (dP - D): -D of the half's 32 queries (staged next to the tile by the DMA) is the accumulator INPUT of the dP product --
+            // accumulator row r of a lane is query 8 (r >> 2) + 4 h + (r & 3): four 16-B LDS reads instead of 32 v_sub_f32
             f32x16_t sacc, pacc;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; pacc[r] = 0.f; }
-            if (PRIO) __builtin_amdgcn_s_setprio(1);
+            for (int g = 0; g < 4; ++g) {
+                const f32x4_t d4 = *reinterpret_cast<const f32x4_t*>(D_l + qt * 32 + 8 * g + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pacc[4 * g + e] = d4[e];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr[ks], kf[ks], sacc, 0, 0, 0);                          // S[q][key]
-                pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dofr[ks], KVSAME ? kf[ks] : vf[KVSAME ? 0 : ks], pacc, 0, 0, 0);   // dP[q][key]
+                pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dofr[ks], KVSAME ? kf[ks] : vf[KVSAME ? 0 : ks], pacc, 0, 0, 0);   // dP[q][key] - D[q]
                 if (ks + 2 < KS) load_a(ks + 2);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (PRIO) __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             // dO^T fragments of this half for dV^T += dO^T P: requested now, they land under the element-wise phase
             bf16x4_t tlo[2][DT], thi[2][DT];
@@ -726,20 +739,19 @@ __global__ void __attribute__((amdgpu_waves_per_eu(3, 3))) __launch_bounds__(64 
             for (int g = 0; g < 4; ++g) {
                 const int ql0 = qt * 32 + 8 * g + 4 * h;                                               // rows 4 g .. 4 g + 3 of this lane
                 const f32x4_t l4 = *reinterpret_cast<const f32x4_t*>(lse_l + ql0);
-                const f32x4_t d4 = *reinterpret_cast<const f32x4_t*>(D_l + ql0);
                 float p[4], ds[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int r = 4 * g + e;
                     p[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[r], c2, -l4[e]));
-                    ds[e] = p[e] * (pacc[r] - d4[e]);                                                   // dS / scale
+                    ds[e] = p[e] * pacc[r];                                                             // dS / scale
                 }
                 pw[2 * g] = pack_bf16x2(p[0], p[1]); pw[2 * g + 1] = pack_bf16x2(p[2], p[3]);
                 dw[2 * g] = pack_bf16x2(ds[0], ds[1]); dw[2 * g + 1] = pack_bf16x2(ds[2], ds[3]);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
-            if (PRIO) __builtin_amdgcn_s_setprio(1);
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 u32x4_t p4;
@@ -753,7 +765,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(3, 3))) __launch_bounds__(64 
                     dv[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(doT, pf, dv[d], 0, 0, 0);           // dV^T += dO^T P
                 }
             }
-            if (PRIO) __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_setprio(0);
             // Q^T fragments into the registers the dO^T fragments just left; they land while the matrix pipe drains the four products above
             __builtin_amdgcn_sched_barrier(0);
             attn_static_for<0, 2>([&](auto s2c) {
@@ -766,7 +778,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(3, 3))) __launch_bounds__(64 
             });
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
-            if (PRIO) __builtin_amdgcn_s_setprio(1);
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 u32x4_t d4;
@@ -780,7 +792,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(3, 3))) __launch_bounds__(64 
                     dk[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qT, df, dk[d], 0, 0, 0);            // dK^T += Q^T dS
                 }
             }
-            if (PRIO) __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_setprio(0);
         });
         asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LPT) : "memory");
         __builtin_amdgcn_s_barrier();
@@ -847,8 +859,8 @@ __global__ void __attribute__((amdgpu_waves_per_eu(3, 3))) __launch_bounds__(64 
 // host side
 // ------------------------------------------------------------------------------------------------------------------------------
 // GENIE_ATTN_LEAN / genie_attention_lean_mode: bit 0 forward, bit 1 backward dQ, bit 2 backward dK / dV on the lean kernels (0 sends
-// everything through attention.hip's general kernels -- A/B timing and the tests that compare the two families); bit 3: no s_setprio
-// around the MFMA clusters; bit 4: deferred running maximum in the forward (see attn_fwd4_kernel)
+// everything through attention.hip's general kernels -- A/B timing and the tests that compare the two families); bit 3: unused (was:
+// no s_setprio around the MFMA clusters -- measured neutral, profiles/r04_attention_lean_ab.log); bit 4: deferred running maximum in the forward (see attn_fwd4_kernel)
 #define LEAN_DEFAULT 23      // lean forward + dQ + dK-dV, deferred running maximum
 static int g_lean_mode = -1;
 static int lean_mode() {
@@ -895,16 +907,11 @@ int genie_attn_lean_fwd(const AttnArgs& a_in, hipStream_t s) {
     int lds = 3 * (a.kv_same ? tile : 2 * tile);
     if (lds < nw * 32 * 64 * 4) lds = nw * 32 * 64 * 4;               // the epilogue stages NW x 32 fp32 rows in the ring's memory
     const dim3 grid = lean_grid(a.nseq, a.nhead, qtiles, &a.xcd_swizzle);
-    const bool prio = !(lean_mode() & 8), defer = (lean_mode() & 16) != 0;
-#define LEAN_FWD(KV)                                                                                     \
-    do {                                                                                                 \
-        if (prio && defer) attn_fwd4_kernel<64, 4, KV, true, true><<<grid, 64 * nw, lds, s>>>(a);        \
-        else if (prio) attn_fwd4_kernel<64, 4, KV, true, false><<<grid, 64 * nw, lds, s>>>(a);           \
-        else if (defer) attn_fwd4_kernel<64, 4, KV, false, true><<<grid, 64 * nw, lds, s>>>(a);          \
-        else attn_fwd4_kernel<64, 4, KV, false, false><<<grid, 64 * nw, lds, s>>>(a);                    \
-    } while (0)
-    if (a.kv_same) LEAN_FWD(true); else LEAN_FWD(false);
-#undef LEAN_FWD
+    const bool defer = (lean_mode() & 16) != 0;
+    if (a.kv_same && defer) attn_fwd4_kernel<64, 4, true, true><<<grid, 64 * nw, lds, s>>>(a);
+    else if (a.kv_same) attn_fwd4_kernel<64, 4, true, false><<<grid, 64 * nw, lds, s>>>(a);
+    else if (defer) attn_fwd4_kernel<64, 4, false, true><<<grid, 64 * nw, lds, s>>>(a);
+    else attn_fwd4_kernel<64, 4, false, false><<<grid, 64 * nw, lds, s>>>(a);
     GENIE_CHECK_LAUNCH();
     return GENIE_OK;
 }
@@ -917,13 +924,10 @@ int genie_attn_lean_bwd_dq(const AttnBwdArgs& a_in, hipStream_t s) {
     const int tile = 64 * 64 * 2;
     const int lds = 3 * (a.kv_same ? tile : 2 * tile);
     const dim3 grid = lean_grid(a.nseq, a.nhead, qtiles, &a.xcd_swizzle);
-    const bool prio = !(lean_mode() & 8);
 #define LEAN_DQ(NWv)                                                                                     \
     do {                                                                                                 \
-        if (a.kv_same && prio) attn_bwd_dq3_kernel<64, NWv, true, true><<<grid, 64 * NWv, lds, s>>>(a);  \
-        else if (a.kv_same) attn_bwd_dq3_kernel<64, NWv, true, false><<<grid, 64 * NWv, lds, s>>>(a);    \
-        else if (prio) attn_bwd_dq3_kernel<64, NWv, false, true><<<grid, 64 * NWv, lds, s>>>(a);         \
-        else attn_bwd_dq3_kernel<64, NWv, false, false><<<grid, 64 * NWv, lds, s>>>(a);                  \
+        if (a.kv_same) attn_bwd_dq3_kernel<64, NWv, true><<<grid, 64 * NWv, lds, s>>>(a);                \
+        else attn_bwd_dq3_kernel<64, NWv, false><<<grid, 64 * NWv, lds, s>>>(a);                         \
     } while (0)
     if (nw == 1) LEAN_DQ(1); else if (nw == 2) LEAN_DQ(2); else LEAN_DQ(4);
 #undef LEAN_DQ
@@ -939,11 +943,8 @@ int genie_attn_lean_bwd_dkv(const AttnBwdArgs& a_in, hipStream_t s) {
     const int tile = 64 * 64 * 2;
     const int lds = 3 * (2 * tile + 512);
     const dim3 grid = lean_grid(a.nseq, a.nhead, ktiles, &a.xcd_swizzle);
-    const bool prio = !(lean_mode() & 8);
-    if (nw == 2 && prio) attn_bwd_dkv3_kernel<64, 2, true, true><<<grid, 128, lds, s>>>(a);
-    else if (nw == 2) attn_bwd_dkv3_kernel<64, 2, true, false><<<grid, 128, lds, s>>>(a);
-    else if (prio) attn_bwd_dkv3_kernel<64, 4, true, true><<<grid, 256, lds, s>>>(a);
-    else attn_bwd_dkv3_kernel<64, 4, true, false><<<grid, 256, lds, s>>>(a);
+    if (nw == 2) attn_bwd_dkv3_kernel<64, 2, true><<<grid, 128, lds, s>>>(a);
+    else attn_bwd_dkv3_kernel<64, 4, true><<<grid, 256, lds, s>>>(a);
     GENIE_CHECK_LAUNCH();
     return GENIE_OK;
 }
@@ -955,9 +956,9 @@ extern "C" int genie_attention_lean_occupancy(int which) {
     int n = -1;
     const int tile = 64 * 64 * 2;
     hipError_t e;
-    if (which == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_fwd4_kernel<64, 4, true, true, false>, 256, 4 * 32 * 64 * 4);
-    else if (which == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_bwd_dq3_kernel<64, 4, true, true>, 256, 3 * tile);
-    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_bwd_dkv3_kernel<64, 4, true, true>, 256, 3 * (2 * tile + 512));
+    if (which == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_fwd4_kernel<64, 4, true, true>, 256, 4 * 32 * 64 * 4);
+    else if (which == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_bwd_dq3_kernel<64, 4, true>, 256, 3 * tile);
+    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_bwd_dkv3_kernel<64, 4, true>, 256, 3 * (2 * tile + 512));
     if (e != hipSuccess) { genie_set_error("hipOccupancyMaxActiveBlocksPerMultiprocessor: %s", hipGetErrorString(e)); return -1; }
     return n;
 }

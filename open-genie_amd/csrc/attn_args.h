@@ -27,7 +27,8 @@ struct AttnArgs {
 struct AttnBwdArgs {
     const bf16_t* q; const bf16_t* k; const bf16_t* v; const bf16_t* dO;
     const float* lse; const float* D;
-    const float* lse2;                        // lse * log2(e), written next to D by the preprocess kernel (second half of D_ws)
+    const float* lse2;                        // lse * log2(e) and
+    const float* negD;                        // -D, written behind D by the preprocess kernel (D_ws = [D | lse2 | negD], ABI 10)
     const bf16_t* out; const bf16_t* resid;   // narrow kernels: D is computed in the dQ kernel (out = o_attn when resid is null)
     bf16_t* dq; bf16_t* dk; bf16_t* dv;      // dq: q-map addressing; dk/dv: kv-map addressing (dkv kernel)
     const bf16_t* dq_in;                      // dkv kernel, fused self-attention: dk row += dq_in row (then dk holds dQ + dK + dV)

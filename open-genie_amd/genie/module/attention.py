@@ -154,7 +154,7 @@ class _AttnFn(torch.autograd.Function):
         ntok = b * t * h * w
         dout = to_cl(dout)
         du = empty_like_cl(x)
-        D = GF.workspace(2 * ntok * n_head, x.device, 'attn_D')            # D, then lse * log2 e (ABI 10)
+        D = GF.workspace(3 * ntok * n_head, x.device, 'attn_D')            # D, lse * log2 e, -D (ABI 10)
         P = _hip.ptr
         dk = dv = None
         if kext is None:

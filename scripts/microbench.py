@@ -108,7 +108,7 @@ def bench_attn(iters, only=None):
         stats = torch.empty(ntok * 2, device='cuda')
         out = torch.empty_like(x); oattn = torch.empty_like(x)
         lse = torch.empty(ntok * nh, device='cuda')
-        D = torch.empty(2 * ntok * nh, device='cuda')                    # D, then lse * log2 e (ABI 10)
+        D = torch.empty(3 * ntok * nh, device='cuda')                    # D, lse * log2 e, -D (ABI 10)
         dout = rand_cl(b, c, t, h, w, 0.1)
         du = torch.empty_like(x); dx = torch.empty_like(x)
         dg = torch.zeros(c, device='cuda'); db = torch.zeros(c, device='cuda')

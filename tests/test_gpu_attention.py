@@ -231,7 +231,7 @@ def test_attention_lean_and_general_kernels_agree():
             old = lib.genie_attention_lean_mode(mode)
             try:
                 out, lse = torch.empty_like(q), torch.empty(nseq * sq * nhead, device='cuda')
-                D, dq = torch.empty(2 * nseq * sq * nhead, device='cuda'), torch.empty_like(q)
+                D, dq = torch.empty(3 * nseq * sq * nhead, device='cuda'), torch.empty_like(q)
                 _hip.check(lib.genie_attention_fwd(P(q), P(q), P(q), None, P(out), None, P(lse), nseq, nhead, 64, sq, sq, qmap, qmap, qmap, scale,
                                                    int(causal), c, _hip.stream_ptr()), 'fwd')
                 _hip.check(lib.genie_attention_bwd(P(q), P(q), P(q), P(out), None, P(do), P(lse), P(D), P(dq), None, None, nseq, nhead, 64, sq, sq,
@@ -246,9 +246,17 @@ def test_attention_lean_and_general_kernels_agree():
         assert rel_rms(g1, g0) < 2e-3, rel_rms(g1, g0)
 
 
-@pytest.mark.parametrize('mode', [7, 7 | 8, 7 | 16, 7 | 8 | 16])
+def test_lean_kernels_keep_their_occupancy():
+    """The register-lean kernels are budgeted for 4 (forward, 128 VGPRs) / 3 / 3 (backward, <= 168) resident blocks of four waves per CU;
+    a toolchain or source change that costs a wave per SIMD should fail here, not show up as a silent 10-20 % slowdown."""
+    from genie import _hip
+    lib = _hip.load_library()
+    assert [lib.genie_attention_lean_occupancy(i) for i in range(3)] == [4, 3, 3]
+
+
+@pytest.mark.parametrize('mode', [7, 7 | 16, 7 | 32, 7 | 16 | 32])
 def test_attention_forward_variants_with_late_maxima(mode):
-    """The lean forward's switches (genie_attention_lean_mode bit 3: no s_setprio; bit 4: deferred running maximum) on scores built to move
+    """The lean forward's switches (genie_attention_lean_mode bit 4: deferred running maximum; bit 5: plain grid) on scores built to move
     the maximum LATE and by a lot: a few keys far into the sequence are strongly aligned with particular queries (raw score well above
     everything before them), others only slightly (growth below the deferral threshold) -- the rescale branch fires in the middle of the
     key loop for some rows of a wave and not for others.  Output and log-sum-exp against fp32 softmax attention, every variant
@@ -330,7 +338,7 @@ def test_attention_core_kernels(nseq, nhead, dh, sq, sk, causal, cross):
     torch.testing.assert_close(lse.cpu().reshape(nseq, sq, nhead), lse_ref.transpose(1, 2).contiguous(), rtol=2e-3, atol=2e-3)
 
     dod = do.cuda().to(torch.bfloat16)
-    D = torch.empty(2 * nseq * sq * nhead, device='cuda')                 # D, then lse * log2 e (ABI 10)
+    D = torch.empty(3 * nseq * sq * nhead, device='cuda')                 # D, lse * log2 e, -D (ABI 10)
     dq = torch.empty_like(qd)
     dk = torch.empty_like(kd) if cross else None
     dv = torch.empty_like(vd) if cross else None
