@@ -263,6 +263,10 @@ int genie_silu_bwd(const void* x, const void* dy, void* dx, int64_t numel, void*
  * (discriminator.py:91), forward and backward.  (GroupNorm fuses it as act = 2, slope 0.01: genie_groupnorm_fwd / _bwd.) */
 int genie_leaky_relu_fwd(const void* x, void* y, int64_t numel, float slope, void* stream);
 int genie_leaky_relu_bwd(const void* x, const void* dy, void* dx, int64_t numel, float slope, void* stream);
+/* GELU (exact erf form) over a CL buffer.  replaces: nn.GELU, the activation between the layers of ForwardBlock (misc.py:78,94-98) when
+ * SpaceTimeAttention is built with hid_dim (attention.py:429-438), forward and backward.  (ABI 10) */
+int genie_gelu_fwd(const void* x, void* y, int64_t numel, void* stream);
+int genie_gelu_bwd(const void* x, const void* dy, void* dx, int64_t numel, void* stream);
 int genie_add(const void* a, const void* b, void* y, int64_t numel, void* stream);
 
 /* ---------------------------------------------------------------------------------------------

@@ -714,6 +714,46 @@ extern "C" int genie_blur_pool3d_bwd(const void* dy_cl, int out_channels, int ou
 }
 
 // LeakyReLU over a CL buffer (reference: nn.LeakyReLU in ImageResidualBlock image.py:118-131 and FrameDiscriminator.to_logits discriminator.py:91)
+// GELU, the exact (erf) form of nn.GELU() -- the default activation of the reference's ForwardBlock (misc.py:78), reached through
+// SpaceTimeAttention(hid_dim=...) (attention.py:429-438).  gelu(x) = x Phi(x);  gelu'(x) = Phi(x) + x phi(x).
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.39894228040143268f * __expf(-0.5f * x * x);
+}
+__global__ void __launch_bounds__(256) gelu_fwd_kernel(const u32x4_t* __restrict__ x, u32x4_t* __restrict__ y, long long n16) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long long)gridDim.x * 256) {
+        float f[8];
+        unpack8(x[i], f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = gelu_f(f[j]);
+        y[i] = pack8(f);
+    }
+}
+__global__ void __launch_bounds__(256) gelu_bwd_kernel(const u32x4_t* __restrict__ x, const u32x4_t* __restrict__ dy, u32x4_t* __restrict__ dx, long long n16) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long long)gridDim.x * 256) {
+        float f[8], g[8];
+        unpack8(x[i], f);
+        unpack8(dy[i], g);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g[j] *= gelu_grad_f(f[j]);
+        dx[i] = pack8(g);
+    }
+}
+extern "C" int genie_gelu_fwd(const void* x, void* y, int64_t numel, void* stream) {
+    GENIE_CHECK_ARG(x && y && numel % 8 == 0, "genie_gelu_fwd: null pointer or numel %lld not a multiple of 8", (long long)numel);
+    if (numel == 0) return GENIE_OK;
+    gelu_fwd_kernel<<<ew_grid(numel / 8), 256, 0, (hipStream_t)stream>>>((const u32x4_t*)x, (u32x4_t*)y, numel / 8);
+    GENIE_CHECK_LAUNCH();
+    return GENIE_OK;
+}
+extern "C" int genie_gelu_bwd(const void* x, const void* dy, void* dx, int64_t numel, void* stream) {
+    GENIE_CHECK_ARG(x && dy && dx && numel % 8 == 0, "genie_gelu_bwd: null pointer or numel %lld not a multiple of 8", (long long)numel);
+    if (numel == 0) return GENIE_OK;
+    gelu_bwd_kernel<<<ew_grid(numel / 8), 256, 0, (hipStream_t)stream>>>((const u32x4_t*)x, (const u32x4_t*)dy, (u32x4_t*)dx, numel / 8);
+    GENIE_CHECK_LAUNCH();
+    return GENIE_OK;
+}
+
 extern "C" int genie_leaky_relu_fwd(const void* x, void* y, int64_t numel, float slope, void* stream) {
     GENIE_CHECK_ARG(x && y && numel % 8 == 0, "genie_leaky_relu_fwd: null pointer or numel %lld not a multiple of 8", (long long)numel);
     if (numel == 0) return GENIE_OK;

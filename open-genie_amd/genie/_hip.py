@@ -90,6 +90,8 @@ SIGNATURES = {
     'genie_blur_pool3d_bwd': (C.c_int, [_P, _I, _I, _PL, _P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), _P, _I, _P, _P]),
     'genie_silu_fwd': (C.c_int, [_P, _P, _L, _P]),
     'genie_silu_bwd': (C.c_int, [_P, _P, _P, _L, _P]),
+    'genie_gelu_fwd': (C.c_int, [_P, _P, _L, _P]),
+    'genie_gelu_bwd': (C.c_int, [_P, _P, _P, _L, _P]),
     'genie_leaky_relu_fwd': (C.c_int, [_P, _P, _L, _F, _P]),
     'genie_leaky_relu_bwd': (C.c_int, [_P, _P, _P, _L, _F, _P]),
     'genie_add': (C.c_int, [_P, _P, _P, _L, _P]),
@@ -133,8 +135,52 @@ def load_library() -> C.CDLL:
         fn.restype, fn.argtypes = res, args
     if lib.genie_abi_version() != ABI_VERSION:
         raise RuntimeError(f'genie: {LIB_PATH} has ABI {lib.genie_abi_version()}, expected {ABI_VERSION}; rebuild')
+    if os.environ.get('GENIE_ROCTX', '0') not in ('0', ''):
+        lib = _RoctxProxy(lib)
     _lib = lib
     return lib
+
+
+class _RoctxProxy:
+    """GENIE_ROCTX=1: every C-ABI call that enqueues work is bracketed by a roctx range named after the entry point (SURVEY.md section 5,
+    "tracing"): `rocprofv3 --marker-trace --kernel-trace` then shows which operator of the reference's module tree a kernel belongs to.
+    Off by default -- two extra foreign calls per launch.  Queries (version, error string, last variant, switches) pass straight through."""
+
+    _PLAIN = ('genie_abi_version', 'genie_last_error', 'genie_last_conv_variant', 'genie_last_conv_gn_fused', 'genie_attention_lean_mode',
+              'genie_attention_lean_occupancy')
+
+    def __init__(self, lib: C.CDLL) -> None:
+        self._lib = lib
+        rt = None
+        for name in ('libroctx64.so', 'librocprofiler-sdk-roctx.so', '/opt/rocm/lib/libroctx64.so'):
+            try:
+                rt = C.CDLL(name)
+                break
+            except OSError:
+                continue
+        if rt is None:
+            raise RuntimeError('GENIE_ROCTX=1 but no roctx library (libroctx64.so / librocprofiler-sdk-roctx.so) could be loaded')
+        rt.roctxRangePushA.argtypes, rt.roctxRangePushA.restype = [C.c_char_p], C.c_int
+        rt.roctxRangePop.argtypes, rt.roctxRangePop.restype = [], C.c_int
+        self._push, self._pop = rt.roctxRangePushA, rt.roctxRangePop
+        self._wrapped = {}
+
+    def __getattr__(self, name: str):
+        fn = getattr(self._lib, name)
+        if name in self._PLAIN or not name.startswith('genie_'):
+            return fn
+        w = self._wrapped.get(name)
+        if w is None:
+            label, push, pop = name.encode(), self._push, self._pop
+
+            def w(*args, _fn=fn):
+                push(label)
+                try:
+                    return _fn(*args)
+                finally:
+                    pop()
+            self._wrapped[name] = w
+        return w
 
 
 def check(rc: int, what: str) -> None:

@@ -358,6 +358,30 @@ def silu(x: Tensor) -> Tensor:
     return _SiluFn.apply(to_cl(x))
 
 
+class _GeluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x: Tensor):
+        y = empty_like_cl(x)
+        numel = x.shape[0] * x.shape[2] * x.shape[3] * x.shape[4] * pitch_of(x)
+        _hip.check(_hip.load_library().genie_gelu_fwd(x.data_ptr(), y.data_ptr(), numel, _hip.stream_ptr()), 'genie_gelu_fwd')
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        (x,) = ctx.saved_tensors
+        dy = to_cl(dy)
+        dx = empty_like_cl(x)
+        numel = x.shape[0] * x.shape[2] * x.shape[3] * x.shape[4] * pitch_of(x)
+        _hip.check(_hip.load_library().genie_gelu_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), numel, _hip.stream_ptr()), 'genie_gelu_bwd')
+        return dx
+
+
+def gelu(x: Tensor) -> Tensor:
+    """nn.GELU() (exact erf form) on a CL tensor."""
+    return _GeluFn.apply(to_cl(x))
+
+
 class _LeakyFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x: Tensor, slope: float):

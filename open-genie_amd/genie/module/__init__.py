@@ -8,7 +8,7 @@ from typing import List, Tuple
 import torch.nn as nn
 
 from ..utils import Blueprint, default, exists
-from .norm import AdaptiveGroupNorm, GroupNorm, SiLU
+from .norm import GELU, AdaptiveGroupNorm, GroupNorm, SiLU
 from .video import (CausalConv3d, CausalConvTranspose3d, DepthToSpaceTimeUpsample, DepthToSpaceUpsample,
                     DepthToTimeUpsample, SpaceTimeDownsample, VideoResidualBlock)
 
@@ -52,7 +52,7 @@ def get_module(name: str):
         case 'adaptive_group_norm':
             return AdaptiveGroupNorm
         case 'gelu':
-            return nn.GELU
+            return GELU                       # nn.GELU subclass: same constructor, same (empty) state_dict
         case 'relu':
             return nn.ReLU
         case 'leaky_relu':

@@ -24,8 +24,10 @@ from .. import _hip
 from .. import conv as _conv
 from .. import functional as GF
 from ..cl import empty_like_cl, is_cl, pitch_of, to_cl
+from ..conv import same_spec
 from ..utils import default, exists
 from .misc import ForwardBlock
+from .video import Conv3d
 
 
 class RotaryEmbedding(nn.Module):
@@ -273,8 +275,9 @@ class TemporalAttention(Attention):
 
 
 class SpaceTimeAttention(nn.Module):
-    """reference attention.py:373-474:  x = space(x) + x;  x = temp(x) + x;  x = ffn(x) + x  with
-    ffn = GroupNorm(n_head) -> Conv3d(C, C, k, padding=(k-1)//2, bias=bias) (no activation, no hidden layer)."""
+    """reference attention.py:373-474:  x = space(x) + x;  x = temp(x) + x;  x = ffn(x) + ffn_skip(x)  with
+    ffn = ForwardBlock(GroupNorm(n_head) -> Conv3d layers over (C, *hid_dim, d_out) with GELU between them, misc.py:71-104); the shipped
+    blueprints use hid_dim = None, d_out = None: one Conv3d(C, C, k, padding=(k-1)//2, bias=bias)."""
 
     def __init__(self, n_head, d_head, d_inp: int | None = None, d_out: int | None = None, hid_dim=None, bias: bool = False,
                  embed=True, scale: float | None = None, dropout: float = 0.0, kernel_size: int = 3, transpose: bool = False,
@@ -296,10 +299,14 @@ class SpaceTimeAttention(nn.Module):
         self.in_channels = default(d_inp, n_head[0] * d_head[0])
         self.out_channels = default(d_out, n_head[1] * d_head[1])
         space_hid, time_hid = d_head[0] * n_head[0], d_head[1] * n_head[1]
-        if (exists(d_inp) and d_inp != space_hid) or (exists(d_out) and time_hid != d_out) or hid_dim is not None:
-            raise NotImplementedError('SpaceTimeAttention: d_inp / d_out / hid_dim different from n_head * d_head are not implemented on the '
-                                      'HIP path (the reference cannot run d_inp != n_head * d_head either, SURVEY.md section 0)')
-        self.time_skip, self.space_skip, self.ffn_skip = nn.Identity(), nn.Identity(), nn.Identity()
+        if exists(d_inp) and d_inp != space_hid:
+            raise NotImplementedError('SpaceTimeAttention: d_inp different from n_head * d_head is not implemented on the HIP path (the '
+                                      'reference cannot run it either: its Attention normalises d_inp features and splits n_head * d_head, SURVEY.md section 0)')
+        if space_hid != time_hid:
+            raise NotImplementedError('SpaceTimeAttention: the spatial and the temporal sub-layer must have the same width on the HIP path')
+        self.time_skip, self.space_skip = nn.Identity(), nn.Identity()
+        # reference attention.py:453: a 1x1x1 projection of the skip path when the feed-forward changes the width
+        self.ffn_skip = Conv3d(time_hid, d_out, (1, 1, 1), same_spec(time_hid, d_out, (1, 1, 1)), bias=True) if exists(d_out) and time_hid != d_out else nn.Identity()
         self.transpose = transpose
 
     def forward(self, video: Tensor, cond=None, mask: Tensor | None = None) -> Tensor:
@@ -310,8 +317,20 @@ class SpaceTimeAttention(nn.Module):
         x = to_cl(video if tr else video.permute(0, 4, 1, 2, 3))
         x = self.space_attn(x, cond=space_cond, mask=mask, transpose=True, _add_resid=True)
         x = self.temp_attn(x, cond=time_cond, mask=mask, transpose=True, _add_resid=True)
+        # feed-forward (reference misc.py:86-98): GroupNorm, then Conv3d layers with the activation between them (none after the last unless
+        # `last_act`); hid_dim = None is the shipped blueprints' single conv.  The skip connection rides in the last conv's GEMM epilogue
+        # whenever nothing follows that conv and the skip is the identity.
         net = self.ffn[1].net
-        gn, conv = net[0], net[1][0]
+        gn, layers = net[0], list(net)[1:]
+        skip = x if isinstance(self.ffn_skip, nn.Identity) else self.ffn_skip(x)
         y = GF.group_norm(x, gn.num_groups, gn.weight, gn.bias, gn.eps)
-        x = conv(y, resid=x)
+        for i, layer in enumerate(layers):
+            conv, act = layer[0], layer[1]
+            fuse = i == len(layers) - 1 and isinstance(act, nn.Identity)
+            y = conv(y, resid=skip if fuse else None)
+            if not isinstance(act, nn.Identity):
+                y = act(y)
+            if i == len(layers) - 1 and not fuse:
+                y = y + skip
+        x = y
         return x if tr else x.permute(0, 2, 3, 4, 1)

@@ -9,7 +9,7 @@ from torch import Tensor
 
 from ..conv import same_spec
 from ..utils import default
-from .norm import GroupNorm
+from .norm import GELU, GroupNorm
 from .video import Conv3d, _triple
 
 
@@ -17,6 +17,8 @@ class ForwardBlock(nn.Module):
     def __init__(self, in_dim: int, out_dim: int | None = None, hid_dim: int | Tuple[int, ...] | None = 256,
                  block=nn.Linear, act_fn=nn.GELU, num_groups: int = 1, last_act: bool = False, **kwargs) -> None:
         super().__init__()
+        if act_fn is nn.GELU:
+            act_fn = GELU                                     # same module, HIP kernel on video tensors
         out_dim = default(out_dim, in_dim)
         if isinstance(hid_dim, int):
             hid_dim = (hid_dim,)

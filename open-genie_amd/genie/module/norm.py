@@ -22,6 +22,16 @@ class SiLU(nn.SiLU):
         return GF.silu(inp)
 
 
+class GELU(nn.GELU):
+    """nn.GELU() on the HIP path (5-D video tensors, exact erf form; the reference's ForwardBlock activation, misc.py:78).  Other ranks
+    and the tanh approximation stay with torch."""
+
+    def forward(self, inp: Tensor) -> Tensor:
+        if inp.dim() == 5 and inp.is_cuda and self.approximate == 'none':
+            return GF.gelu(inp)
+        return super().forward(inp)
+
+
 class AdaptiveGroupNorm(nn.Module):
     """reference norm.py:8-69: group_norm(x) * Linear(mean_{t,h,w} cond) + Linear(mean cond).
     The scale/shift are folded into the normalisation pass; the two (B, dim_cond) x (dim_cond, C) products are

@@ -104,14 +104,23 @@ class CausalConv3d(nn.Module):
         stride, dilation, kernel_size = _triple(stride), _triple(dilation), _triple(kernel_size)
         if isinstance(padding, int) or padding is None:
             padding = (padding, padding)
-        if pad_mode != 'constant':
-            raise NotImplementedError(f"CausalConv3d: pad_mode '{pad_mode}' is not implemented on the HIP path (zero padding only)")
+        if pad_mode not in ('constant', 'reflect', 'replicate', 'circular'):
+            raise ValueError(f"CausalConv3d: unknown pad_mode '{pad_mode}'")
         bias = kwargs.pop('bias', True)
         if kwargs.pop('groups', 1) != 1:
             raise NotImplementedError('CausalConv3d: grouped convolutions are not implemented on the HIP path')
         if kwargs:
             raise TypeError(f'CausalConv3d: unexpected arguments {sorted(kwargs)}')
         spec = causal_spec(in_channels, out_channels, kernel_size, stride, dilation, padding, shuffle=_shuffle)
+        # zero padding ('constant', every shipped blueprint) is a predicate in the conv kernels' gather.  The other F.pad modes of the
+        # reference (video.py:160-164) have no such form: the padded tensor is materialised once (torch's pad kernel on the bf16 tensor, a
+        # copy of the activation -- plumbing, not arithmetic) and the conv then runs WITHOUT padding on it.
+        self.pad_mode, self._pads = pad_mode, None
+        if pad_mode != 'constant':
+            if causal_time_crop(kernel_size, stride, dilation):
+                raise NotImplementedError("CausalConv3d: a negative causal pad (cropping) together with a non-constant pad_mode is not implemented")
+            self._pads = (spec.pad_front[2], spec.pad_back[2], spec.pad_front[1], spec.pad_back[1], spec.pad_front[0], spec.pad_back[0])
+            spec = ConvSpec(in_channels, spec.cout, kernel_size, stride, dilation, (0, 0, 0), (0, 0, 0), _shuffle)
         self.conv3d = Conv3d(in_channels, out_channels, kernel_size, spec, bias=bias)
         self.in_channels, self.out_channels = in_channels, out_channels
         # a NEGATIVE causal pad (kt = 1, time stride 2: (kt - 1) dil + 1 - stride = -1) crops leading frames in the reference (F.pad with a
@@ -123,6 +132,8 @@ class CausalConv3d(nn.Module):
             if inp.shape[2] <= self.time_crop:
                 raise ValueError(f'CausalConv3d: {inp.shape[2]} frames, the causal padding of this layer removes {self.time_crop}')
             inp = to_cl(inp)[:, :, self.time_crop:].contiguous(memory_format=torch.channels_last_3d)     # a dense CL copy of the kept frames
+        if self._pads is not None:
+            inp = torch.nn.functional.pad(to_cl(inp), self._pads, mode=self.pad_mode)
         return self.conv3d(inp)
 
     @property

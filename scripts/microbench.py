@@ -238,10 +238,18 @@ def bench_conv(iters):
         lib = _hip.load_library()
         ms = timeit(lambda: conv_forward(x, wf, None, spec), iters)
         report('conv', name + ' | fwd', ms, flops=fl, kernel=gconv.VARIANT_NAMES.get(lib.genie_last_conv_variant()))
-        ms = timeit(lambda: conv_dgrad(dy, wb, spec, size), iters)
+        # upsample convs: the training step un-shuffles the output gradient ONCE (genie_unshuffle_cl) and hands it to both the backward-data
+        # and the weight-gradient pass (functional._Conv3dFn.backward) -- timed the same way here, the un-shuffle as its own line
+        # (round 3 timed the gather-through-the-shuffle kernels the step no longer uses: 0.32-0.37 where the step runs 0.48)
+        dyu = None
+        if spec.shuffle is not None and gconv.wgrad_unshuffled_ok(spec, x):
+            dyu = gconv.unshuffle_dy(dy, spec)
+            ms = timeit(lambda: gconv.unshuffle_dy(dy, spec), iters)
+            report('conv', name + ' | un-shuffle of dy (shared by dgrad and wgrad)', ms, bytes_=2.0 * dy.numel() * 2)
+        ms = timeit(lambda: conv_dgrad(dy, wb, spec, size, dy_unshuffled=dyu), iters)
         report('conv', name + ' | dgrad', ms, flops=fl, kernel=gconv.VARIANT_NAMES.get(lib.genie_last_conv_variant()))
         if not NO_WGRAD:
-            ms = timeit(lambda: conv_wgrad(x, dy, spec, dw, None), iters)
+            ms = timeit(lambda: conv_wgrad(x, dy if dyu is None else dyu, spec, dw, None, dyu is not None), iters)
             report('conv', name + ' | wgrad', ms, flops=fl, kernel=gconv.VARIANT_NAMES.get(lib.genie_last_conv_variant()))
         del x, y, dw, wf, wb, wt
         torch.cuda.empty_cache()

@@ -55,3 +55,20 @@ def test_struct_layouts_match_header():
         subprocess.run(['gcc', '-I', os.path.join(ROOT, 'include'), c, '-o', exe], check=True)
         sizes = [int(v) for v in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split()]
     assert sizes == [ctypes.sizeof(_hip.GenieTap), ctypes.sizeof(_hip.GenieConvDesc), ctypes.sizeof(_hip.GenieWgradDesc)]
+
+
+def test_roctx_ranges_behind_env_switch():
+    """GENIE_ROCTX=1 brackets every enqueueing C-ABI call with a roctx range named after the entry point (tracing):
+    the proxy loads a roctx library, forwards arguments and return codes unchanged, and leaves the query entry points alone.  (In a child
+    process: the switch is read when the library is first loaded.)"""
+    import subprocess
+    import sys
+    code = ('import sys; sys.path[:0] = [%r, %r]\n'
+            'from genie import _hip\n'
+            'lib = _hip.load_library()\n'
+            'assert type(lib).__name__ == "_RoctxProxy" and lib.genie_abi_version() == _hip.ABI_VERSION\n'
+            'assert lib.genie_conv_igemm(None, None) == -1 and b"null descriptor" in lib.genie_last_error()\n'
+            'assert lib.genie_attention_lean_mode(-1) >= 0\n'
+            'print("ok")\n') % (ROOT, os.path.join(ROOT, 'open-genie_amd'))
+    r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, GENIE_ROCTX='1'), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip().endswith('ok'), r.stderr[-2000:]

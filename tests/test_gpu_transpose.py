@@ -131,3 +131,34 @@ def test_negative_causal_pad_crops_like_the_reference():
     assert rel_rms(m.conv3d.weight.grad, w.grad) < 2e-3
     with pytest.raises(ValueError):
         m(torch.randn(1, 64, 1, 6, 6, device='cuda'))
+
+
+@pytest.mark.parametrize('mode', ['replicate', 'reflect', 'circular'])
+@pytest.mark.parametrize('cin,cout,k,stride,size', [(64, 48, 3, (1, 1, 1), (2, 4, 6, 6)), (32, 64, (3, 3, 3), (1, 2, 2), (1, 5, 8, 8)), (128, 128, 3, (1, 1, 1), (1, 3, 8, 8))])
+def test_causal_conv3d_pad_modes(mode, cin, cout, k, stride, size):
+    """CausalConv3d(pad_mode=...) other than zeros (reference video.py:154-192: F.pad(inp, (wp, wp, hp, hp, tp, 0), mode) then an unpadded
+    nn.Conv3d) -- outputs, input and parameter gradients against exactly that composition in fp32.  Round 3 raised for these modes."""
+    from genie.module.video import CausalConv3d
+    torch.manual_seed(13)
+    m = CausalConv3d(cin, cout, k, stride=stride, pad_mode=mode)
+    with torch.no_grad():
+        m.conv3d.weight.copy_(bf16_round(m.conv3d.weight))
+    w, b = m.conv3d.weight.detach().clone().requires_grad_(True), m.conv3d.bias.detach().clone().requires_grad_(True)
+    m = m.cuda()
+    n, t, h, ww = size
+    x = bf16_round(torch.randn(n, cin, t, h, ww))
+    xr = x.clone().requires_grad_(True)
+    kt, kh, kw = (k, k, k) if isinstance(k, int) else k
+    pads = ((kw - 1) // 2, (kw - 1) // 2, (kh - 1) // 2, (kh - 1) // 2, (kt - 1) + (1 - stride[0]), 0)
+    ref = torch.nn.functional.conv3d(torch.nn.functional.pad(xr, pads, mode=mode), w, b, stride=stride)
+    dy = bf16_round(torch.randn_like(ref))
+    ref.backward(dy)
+    xc = x.cuda().requires_grad_(True)
+    out = m(xc)
+    assert tuple(out.shape) == tuple(ref.shape)
+    assert_close_bf16(out, ref, f'pad_mode {mode}')
+    out.backward(dy.cuda())
+    assert_close_bf16(xc.grad, xr.grad, f'pad_mode {mode} dx', rel=2 ** -6, rms_frac=6e-3)      # the pad's backward sums bf16 gradients (torch)
+    assert rel_rms(m.conv3d.weight.grad, w.grad) < 2e-3 and rel_rms(m.conv3d.bias.grad, b.grad) < 2e-3
+    with pytest.raises(ValueError):
+        CausalConv3d(cin, cout, k, pad_mode='zeros')
