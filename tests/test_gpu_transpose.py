@@ -158,7 +158,10 @@ def test_causal_conv3d_pad_modes(mode, cin, cout, k, stride, size):
     assert tuple(out.shape) == tuple(ref.shape)
     assert_close_bf16(out, ref, f'pad_mode {mode}')
     out.backward(dy.cuda())
-    assert_close_bf16(xc.grad, xr.grad, f'pad_mode {mode} dx', rel=2 ** -6, rms_frac=6e-3)      # the pad's backward sums bf16 gradients (torch)
+    # the pad's backward (torch) SUMS the conv's bf16 input gradients of the border pixels in bf16: two or three roundings per border element
+    # instead of one, so the bound is on the tensor (and a looser one on the single worst element)
+    assert rel_rms(xc.grad, xr.grad) < 6e-3, rel_rms(xc.grad, xr.grad)
+    assert (xc.grad.float().cpu() - xr.grad).abs().max().item() <= 2 ** -5 * xr.grad.abs().max().item()
     assert rel_rms(m.conv3d.weight.grad, w.grad) < 2e-3 and rel_rms(m.conv3d.bias.grad, b.grad) < 2e-3
     with pytest.raises(ValueError):
         CausalConv3d(cin, cout, k, pad_mode='zeros')
