@@ -142,6 +142,39 @@ def csrc_sha16() -> str:
     return h.hexdigest()[:16]
 
 
+def socket_power_w():
+    """Average socket power in watts as `rocm-smi --showpower --json` reports it for device 0, or None (tool missing / no permission)."""
+    import shutil
+    import subprocess
+    exe = shutil.which('rocm-smi') or '/opt/rocm/bin/rocm-smi'
+    try:
+        out = subprocess.run([exe, '-d', '0', '--showpower', '--json'], capture_output=True, text=True, timeout=20).stdout
+        card = next(iter(json.loads(out).values()))
+        for k, v in card.items():
+            if 'power' in k.lower() and 'w' in k.lower():
+                return float(str(v).split()[0])
+    except Exception:
+        return None
+    return None
+
+
+def power_under_load(fn, seconds: float = 2.0, launch_ms: float = 3.0):
+    """Socket power while `fn` (one asynchronous kernel launch) runs back to back for ~`seconds`: the launches are enqueued first, the
+    host then samples rocm-smi while the GPU works through them.  Returns (mean watts or None, samples)."""
+    n = max(50, int(seconds * 1e3 / max(launch_ms, 0.05)))
+    for _ in range(n):
+        fn()
+    samples = []
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds * 0.8 and len(samples) < 4:
+        w = socket_power_w()
+        if w is None:
+            break
+        samples.append(w)
+    torch.cuda.synchronize()
+    return (round(sum(samples) / len(samples), 1) if samples else None), samples
+
+
 def power_cap_probe(batch: int = 64):
     """How much of the distance between `roofline.achieved` and the 2.5 PFLOP/s peak is the chip's POWER cap rather than the kernel's
     schedule: one launch shape of the dominant kernel (256 -> 256 channels, 3x3x3, 16x32x32, the step's batch) timed on random bf16 operands
@@ -160,6 +193,10 @@ def power_cap_probe(batch: int = 64):
         wf = gconv.pack_weight_fwd(wt, spec)
         ms = mb.timeit(lambda: gconv.conv_forward(x, wf, None, spec), 10)
         out[tag] = {'ms': round(ms, 4), 'tflops': round(fl / ms / 1e9, 1), 'mfma_frac': round(fl / ms / 1e9 / BF16_MFMA_PEAK_TFLOPS, 4)}
+        # energy per useful FLOP: socket power while this launch repeats for ~2 s
+        watts, samples = power_under_load(lambda: gconv.conv_forward(x, wf, None, spec), 2.0, ms)
+        if watts is not None:
+            out[tag].update({'socket_watts': watts, 'watt_samples': samples, 'pJ_per_flop': round(watts / (fl / ms / 1e9) , 3)})      # W / (TFLOP/s) = pJ / FLOP
         out['kernel'] = gconv.VARIANT_NAMES.get(_hip.load_library().genie_last_conv_variant())
         del x, wt, wf
     out['zero_over_random'] = round(out['zero_operands']['tflops'] / out['random_operands']['tflops'], 3)
@@ -188,10 +225,15 @@ def side_kernels(batch: int = 64):
             if 'hbm_frac_min' in r:                      # against the operation's minimal traffic (1R + 1W forward, 2R + 1W backward)
                 hbm[r['name']].update({'gbps_min': r['gbps_min'], 'hbm_frac_min': r['hbm_frac_min']})
     best = max((v['mfma_frac'] for k, v in att.items() if 'fwd' in k), default=None)
+    best_bwd = max((v['mfma_frac'] for k, v in att.items() if 'bwd' in k), default=None)
+    from genie import _hip
+    lib = _hip.load_library()
+    fam = {'lean_mode': lib.genie_attention_lean_mode(-1), 'resident_blocks_per_cu': {k: lib.genie_attention_lean_occupancy(i) for i, k in enumerate(('fwd', 'bwd_dq', 'bwd_dkv'))},
+           'source': 'open-genie_amd/csrc/attention_lean.hip (d_head 64; bits of lean_mode: include/genie_hip.h genie_attention_lean_mode)'}
     # (not under the profiler: the probe launches the dominant kernel itself and would mix into its rocprofv3 / PMC averages)
     return {**({} if os.environ.get('GENIE_BENCH_NO_PROBE') else {'power_cap': power_cap_probe(batch)}),
             'st_attention': {'peak_tflops': BF16_MFMA_PEAK_TFLOPS, 'flop_count': 'dense 4 S^2 C per sequence forward, 2.5x that backward',
-                             'best_fwd_mfma_frac': best, 'kernels': att},
+                             'best_fwd_mfma_frac': best, 'best_bwd_mfma_frac': best_bwd, 'kernel_family': fam, 'kernels': att},
             'hbm_kernels': {'peak_gbps': 8000.0, 'bytes': 'what the passes of the call move (stated per entry); *_min: the minimal traffic of the operation', 'kernels': hbm}}
 
 

@@ -1,0 +1,66 @@
+#!/bin/bash
+# Evidence of one round on one MI355X box (run through gpurun), every stage writing files named for profiles/ under gpurun_out/evidence_<tag>/:
+#
+#   gpurun --timeout 1500 -- 'bash scripts/evidence.sh r04 tests bench profile'
+#   gpurun --timeout 1200 -- 'bash scripts/evidence.sh r04 micro models pmc'
+#
+# stages
+#   tests    full `pytest -m gpu` (no -x)                                   -> <tag>_pytest.log, <tag>_parity_report.jsonl
+#   bench    the default `python bench.py` line                             -> <tag>_bench_default.json
+#   profile  rocprofv3 --kernel-trace --stats of bench.py + FETCH_SIZE / WRITE_SIZE passes (scripts/profile_bench.sh)
+#                                                                          -> <tag>_kernel_stats.csv, <tag>_summary.json, <tag>_bench_under_rocprof.json
+#   micro    scripts/microbench.py at 8 and at 64 clips                     -> <tag>_microbench.json, <tag>_microbench_b64.json
+#   models   scripts/bench_models.py (BASELINE configs[2], [3], [4], REPR tokenizer) + their rocprofv3 kernel tables
+#                                                                          -> <tag>_bench_models.json, <tag>_models_{lam,dyn,genie4}_kernel_stats.csv
+#   pmc      SQ counters of the attention families and of the dominant conv layer (separate rocprofv3 passes)
+#                                                                          -> <tag>_pmc_attn.txt, <tag>_pmc_conv.txt
+# (Rounds 1-3 used one-off scripts/exp_r*.sh files for the same jobs; they are in the history up to commit 7bfe1bc.)
+set -u
+TAG=${1:-r04}; shift || true
+STAGES=${*:-tests bench profile micro models pmc}
+ROOT=$(pwd); OUT=$ROOT/gpurun_out/evidence_$TAG; mkdir -p $OUT
+for st in $STAGES; do
+  case $st in
+    tests)
+      rm -f gpurun_out/parity_report.jsonl
+      timeout 1500 python -m pytest tests -q -m gpu -p no:cacheprovider --durations=5 2>&1 | tail -30 > $OUT/${TAG}_pytest.log
+      cp gpurun_out/parity_report.jsonl $OUT/${TAG}_parity_report.jsonl 2>/dev/null
+      grep -E "passed|failed" $OUT/${TAG}_pytest.log | tail -2 ;;
+    bench)
+      timeout 900 python bench.py > $OUT/bench_default.out 2> $OUT/bench_default.err
+      grep '^{' $OUT/bench_default.out | tail -1 > $OUT/${TAG}_bench_default.json
+      python - "$OUT/${TAG}_bench_default.json" <<'PY'
+import json, sys
+d = json.load(open(sys.argv[1]))
+print('bench:', d['value'], d['unit'], d['ms_per_step'], 'ms/step; roofline', d['roofline'].get('kernel'), d['roofline'].get('frac'),
+      '; st_attention', {k: v for k, v in d.get('st_attention', {}).items() if 'frac' in k})
+PY
+      ;;
+    profile)
+      bash scripts/profile_bench.sh $TAG 64 > $OUT/profile.log 2>&1
+      cp gpurun_out/prof_$TAG/${TAG}_kernel_stats.csv gpurun_out/prof_$TAG/${TAG}_summary.json $OUT/ 2>/dev/null
+      grep '^{' gpurun_out/prof_$TAG/bench_under_rocprof.json | tail -1 > $OUT/${TAG}_bench_under_rocprof.json
+      python -c "import json; s=json.load(open('$OUT/${TAG}_summary.json')); print('profile:', s.get('meta'), s.get('duration_agreement'))" ;;
+    micro)
+      timeout 600 python scripts/microbench.py attn hbm conv --out $OUT/${TAG}_microbench.json > $OUT/micro_b8.log 2>&1
+      MB_BATCH=64 timeout 600 python scripts/microbench.py hbm conv --out $OUT/${TAG}_microbench_b64.json > $OUT/micro_b64.log 2>&1
+      grep -c '"section"' $OUT/micro_b8.log $OUT/micro_b64.log ;;
+    models)
+      timeout 900 python scripts/bench_models.py lam dyn repr genie4 --cpu-baseline > $OUT/bench_models.out 2> $OUT/bench_models.err
+      python - "$OUT" "$TAG" <<'PY'
+import json, sys
+out, tag = sys.argv[1], sys.argv[2]
+rows = [json.loads(l) for l in open(f'{out}/bench_models.out') if l.startswith('{')]
+json.dump(rows, open(f'{out}/{tag}_bench_models.json', 'w'), indent=1)
+for r in rows:
+    print('models:', r['model'][:60], r['ms_per_step'], 'ms;', r.get('roofline', {}).get('kernel'), r.get('roofline', {}).get('frac'), r.get('roofline', {}).get('share_of_step_time'))
+PY
+      bash scripts/profile_models.sh $TAG > $OUT/profile_models.log 2>&1
+      cp gpurun_out/prof_models_$TAG/${TAG}_models_*_kernel_stats.csv $OUT/ 2>/dev/null ;;
+    pmc)
+      timeout 400 bash scripts/pmc_attn.sh > $OUT/pmc_attn.log 2>&1; cp gpurun_out/pmc_attn/summary.txt $OUT/${TAG}_pmc_attn.txt 2>/dev/null
+      MB_BATCH=64 timeout 500 bash scripts/pmc_conv.sh > $OUT/${TAG}_pmc_conv.txt 2>&1 ;;
+    *) echo "unknown stage $st" ;;
+  esac
+done
+ls $OUT
