@@ -213,7 +213,7 @@ def side_kernels(batch: int = 64):
     import contextlib
     import io
     with contextlib.redirect_stdout(io.StringIO()):
-        mb.bench_attn(10, only=('lam spatial S=4096', 'yaml_tok spatial S=1024'))
+        mb.bench_attn(30, only=('lam spatial S=4096', 'yaml_tok spatial S=1024'))      # 30 launches per measurement, best of three
         mb.bench_hbm(10, quick=True)                     # B = 8: the round-1 / round-2 protocol (134 MB per tensor, partly cache-resident)
         mb.bench_hbm(6, quick=True, B=batch)             # the step's own batch: 1.07 GB per 128-channel tensor at 64 clips, pure HBM streams
     att, hbm = {}, {}
@@ -431,7 +431,8 @@ def main():
     # wraps the process), so the figure comes from the committed PMC passes of THIS command (scripts/profile_bench.sh ->
     # profiles/rNN_summary.json) -- and only if that profile was taken on the same kernel sources and batch; otherwise it is stale and
     # stays null (a silently carried-over number is worse than none).
-    prof_summary = next((pp for pp in (os.path.join(ROOT, 'profiles', f) for f in ('r03_summary.json', 'r02_summary.json')) if os.path.exists(pp)), '')
+    # the newest round's summary first: profiles/r04_summary.json, r03_..., ...
+    prof_summary = next((os.path.join(ROOT, 'profiles', f) for f in sorted((f for f in os.listdir(os.path.join(ROOT, 'profiles')) if f.startswith('r') and f.endswith('_summary.json')), reverse=True)), '')
     if 'roofline' in out and prof_summary:
         try:
             ps = json.load(open(prof_summary))
