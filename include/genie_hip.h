@@ -391,7 +391,8 @@ int genie_attention_bwd(const void* q, const void* k, const void* v, const void*
 /* d_head 64 runs on register-lean kernels (attention_lean.hip: four / three waves per SIMD) where their preconditions hold.  mask: bit 0
  * forward, bit 1 backward dQ, bit 2 backward dK / dV; bit 3: reserved; bit 4: the forward's running maximum is
  * deferred (O, l rescaled only when a tile's maximum exceeds it by more than 2^8 in the exp2 domain; P <= 2^8 instead of <= 1, the row's
- * largest weight is then rounded to bf16 like every other one instead of being exactly 1); bit 5: plain grid instead of the XCD-aware one.
+ * largest weight is then rounded to bf16 like every other one instead of being exactly 1); bit 5: plain grid instead of the XCD-aware one;
+ * bit 6: forward blocks of four waves at every length (default: eight waves from 2048 queries on; bit-identical results).
  * A negative mask only queries.  Returns the previous mask (default 23 = bits 0, 1, 2, 4, or the GENIE_ATTN_LEAN environment variable).
  * Process-wide; meant for A/B timing and for tests that cover both kernel families and both maximum rules. (ABI 10) */
 int genie_attention_lean_mode(int mask);

@@ -860,7 +860,8 @@ __global__ void __attribute__((amdgpu_waves_per_eu(3, 3))) __launch_bounds__(64 
 // ------------------------------------------------------------------------------------------------------------------------------
 // GENIE_ATTN_LEAN / genie_attention_lean_mode: bit 0 forward, bit 1 backward dQ, bit 2 backward dK / dV on the lean kernels (0 sends
 // everything through attention.hip's general kernels -- A/B timing and the tests that compare the two families); bit 3: unused (was:
-// no s_setprio around the MFMA clusters -- measured neutral, profiles/r04_attention_lean_ab.log); bit 4: deferred running maximum in the forward (see attn_fwd4_kernel)
+// no s_setprio around the MFMA clusters -- measured neutral, profiles/r04_attention_lean_ab.log); bit 6: forward blocks of four waves at every
+// length (default: eight from 2048 queries on); bit 4: deferred running maximum in the forward (see attn_fwd4_kernel)
 #define LEAN_DEFAULT 23      // lean forward + dQ + dK-dV, deferred running maximum
 static int g_lean_mode = -1;
 static int lean_mode() {
@@ -869,7 +870,7 @@ static int lean_mode() {
 }
 extern "C" int genie_attention_lean_mode(int mask) {
     const int old = lean_mode();
-    if (mask >= 0) g_lean_mode = mask & 63;
+    if (mask >= 0) g_lean_mode = mask & 127;
     return old;
 }
 // byte offsets inside a sequence travel as 32-bit buffer offsets / record counts
@@ -900,7 +901,10 @@ static dim3 lean_grid(int nseq, int nhead, int tiles, int* swizzle) {
 
 int genie_attn_lean_fwd(const AttnArgs& a_in, hipStream_t s) {
     AttnArgs a = a_in;
-    constexpr int nw = 4;
+    // blocks of four waves (128 queries); from 2048 queries on, eight (256 queries share a K / V tile: half the L2 -> LDS bytes per query; two
+    // blocks of eight waves per CU are the same four waves per SIMD).  Same arithmetic, bit-identical results; measured 970 vs 951 TFLOP/s
+    // at S = 4096, equal at 1024, 494 vs 520 at 256 (profiles/r04_attention_lean_ab.log).  Bit 6 of the mode keeps four everywhere (A/B).
+    const int nw = (!(lean_mode() & 64) && a.Sq >= 2048) ? 8 : 4;
     const int qtiles = (a.Sq + 32 * nw - 1) / (32 * nw);
     GENIE_CHECK_ARG((long long)a.nseq * qtiles * a.nhead < (1ll << 31) - 8 && a.nhead <= 65535, "genie_attention_fwd: grid too large");
     const int tile = 64 * 64 * 2;
@@ -908,10 +912,15 @@ int genie_attn_lean_fwd(const AttnArgs& a_in, hipStream_t s) {
     if (lds < nw * 32 * 64 * 4) lds = nw * 32 * 64 * 4;               // the epilogue stages NW x 32 fp32 rows in the ring's memory
     const dim3 grid = lean_grid(a.nseq, a.nhead, qtiles, &a.xcd_swizzle);
     const bool defer = (lean_mode() & 16) != 0;
-    if (a.kv_same && defer) attn_fwd4_kernel<64, 4, true, true><<<grid, 64 * nw, lds, s>>>(a);
-    else if (a.kv_same) attn_fwd4_kernel<64, 4, true, false><<<grid, 64 * nw, lds, s>>>(a);
-    else if (defer) attn_fwd4_kernel<64, 4, false, true><<<grid, 64 * nw, lds, s>>>(a);
-    else attn_fwd4_kernel<64, 4, false, false><<<grid, 64 * nw, lds, s>>>(a);
+#define LEAN_FWD(NWv)                                                                                    \
+    do {                                                                                                 \
+        if (a.kv_same && defer) attn_fwd4_kernel<64, NWv, true, true><<<grid, 64 * NWv, lds, s>>>(a);    \
+        else if (a.kv_same) attn_fwd4_kernel<64, NWv, true, false><<<grid, 64 * NWv, lds, s>>>(a);       \
+        else if (defer) attn_fwd4_kernel<64, NWv, false, true><<<grid, 64 * NWv, lds, s>>>(a);           \
+        else attn_fwd4_kernel<64, NWv, false, false><<<grid, 64 * NWv, lds, s>>>(a);                     \
+    } while (0)
+    if (nw == 8) LEAN_FWD(8); else LEAN_FWD(4);
+#undef LEAN_FWD
     GENIE_CHECK_LAUNCH();
     return GENIE_OK;
 }
