@@ -378,14 +378,15 @@ __global__ void __launch_bounds__(512) wgrad3_kernel(const Wgrad3Args a) {
 //     (t + dt, h + dh) lies outside the clip and a stage issued past the block's last chunk all carry offset 0x80000000 >= num_records
 //     and the DMA writes ZEROS (the mechanism composable_kernel's direct loads rely on) -- one v_or per x piece, nothing per dy piece.
 //   * (t, h) of a piece's image row is wave-uniform: scalar registers, scalar compare / select.
-//   * the bias gradient (an MFMA against ones in 2 waves of every 9th block) is a template parameter of the loop, chosen once per wave
-//     by a scalar branch in front of it; no debug switches.
+//   * the bias gradient (an MFMA against ones) is a template parameter of the loop -- WHICH of the chunk's four k-steps this wave also sums --
+//     chosen once per wave by a scalar branch in front of it (the four ci-waves of a co-half hold the same dy fragments and take one k-step
+//     each, in the block of the first triple / first ci tile); no debug switches.
 // Eligibility (host): dy not shuffled, H * W a multiple of 64 (chunks are whole image rows, M a multiple of 64), a block's byte range
 // below 2 GiB.  Everything else stays on wgrad3_kernel.
 // ------------------------------------------------------------------------------------------------------------------------------
 #define W3L_OOB 0x80000000u
 
-template <int LOG2W, bool BIAS>
+template <int LOG2W, int BIAS_KS>       // BIAS_KS: the k-step (0..3) in which this wave also sums the bias gradient, -1: none
 __device__ __forceinline__ void w3l_loop(const Wgrad3Args& a, char* smem, const int nch, const int wave,
                                           const __amdgpu_buffer_rsrc_t rs_dy, const __amdgpu_buffer_rsrc_t rs_x,
                                           const uint32_t (&voff_dy)[2], const uint32_t (&voff_x)[2], const uint32_t (&x_dst)[2],
@@ -479,7 +480,7 @@ __device__ __forceinline__ void w3l_loop(const Wgrad3Args& a, char* smem, const 
         _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                         \
             _Pragma("unroll") for (int s = 0; s < 3; ++s)                                                        \
                 acc[s][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[s], acc[s][i], 0, 0, 0);         \
-            if (BIAS) accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], ones, accb[i], 0, 0, 0);         \
+            if (BIAS_KS == KS) accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], ones, accb[i], 0, 0, 0); \
             if (i == 0) {                                                                                        \
                 __builtin_amdgcn_sched_barrier(0);                                                               \
                 stage_piece(nbuf, KS);                                                                           \
@@ -534,7 +535,11 @@ __global__ void __launch_bounds__(512) wgrad3l_kernel(const Wgrad3Args a) {
     const int co0 = tile_m * 128, ci0 = tile_n * 128;
     const GenieTap tp = a.taps[3 * tr];
     const int t_dt = __builtin_amdgcn_readfirstlane(tp.dt), t_dh = __builtin_amdgcn_readfirstlane(tp.dh);
-    const bool do_bias = a.dbias != nullptr && tr == 0 && tile_n == 0 && wn == 0;
+    // bias gradient (column sums of dy = an MFMA against ones): in the block of the first triple / first ci tile.  Its four ci-waves of a
+    // co-half all hold the SAME dy fragments, so each takes ONE of the chunk's four k-steps (k-step == wn, a template parameter of the
+    // loop: no branch inside it) -- two extra MFMAs per wave and chunk; round 3 gave all eight to the wn == 0 waves (+33 % on that block's
+    // pace, +5...8 % on the launch).  Every wave of the block adds its partial column sums in the epilogue.
+    const bool do_bias = a.dbias != nullptr && tr == 0 && tile_n == 0;
 
     int c_begin = split * a.chunks_per_split, c_end = c_begin + a.chunks_per_split;
     if (c_end > a.nchunks) c_end = a.nchunks;
@@ -633,11 +638,13 @@ __global__ void __launch_bounds__(512) wgrad3l_kernel(const Wgrad3Args a) {
     }
 
     if (nch > 0) {
-        if (do_bias)
-            w3l_loop<LOG2W, true>(a, smem, nch, wave, rs_dy, rs_x, voff_dy, voff_x, x_dst, x_t, x_h, t_dt, t_dh, a_const, b_const, acc, accb, 0, 0, 0);
-        else
-            w3l_loop<LOG2W, false>(a, smem, nch, wave, rs_dy, rs_x, voff_dy, voff_x, x_dst, x_t, x_h, t_dt, t_dh, a_const, b_const, acc, accb,
-                                   clip_left, clip_chunks, skip_frames);
+#define W3L_RUN(BKS, CL, CC, SF) w3l_loop<LOG2W, BKS>(a, smem, nch, wave, rs_dy, rs_x, voff_dy, voff_x, x_dst, x_t, x_h, t_dt, t_dh, a_const, b_const, acc, accb, CL, CC, SF)
+        if (!do_bias) W3L_RUN(-1, clip_left, clip_chunks, skip_frames);
+        else if (wn == 0) W3L_RUN(0, 0, 0, 0);
+        else if (wn == 1) W3L_RUN(1, 0, 0, 0);
+        else if (wn == 2) W3L_RUN(2, 0, 0, 0);
+        else W3L_RUN(3, 0, 0, 0);
+#undef W3L_RUN
     }
 
     // ---- epilogue: fp32 atomics; D row = cout (registers), col = cin (lane & 31) ----

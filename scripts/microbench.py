@@ -251,6 +251,10 @@ def bench_conv(iters):
         if not NO_WGRAD:
             ms = timeit(lambda: conv_wgrad(x, dy if dyu is None else dyu, spec, dw, None, dyu is not None), iters)
             report('conv', name + ' | wgrad', ms, flops=fl, kernel=gconv.VARIANT_NAMES.get(lib.genie_last_conv_variant()))
+            # the training step's convs have a bias: its gradient (column sums of dy) rides in the same launch
+            db = torch.zeros(spec.cout, device='cuda')
+            ms = timeit(lambda: conv_wgrad(x, dy if dyu is None else dyu, spec, dw, db, dyu is not None), iters)
+            report('conv', name + ' | wgrad + bias gradient', ms, flops=fl, kernel=gconv.VARIANT_NAMES.get(lib.genie_last_conv_variant()))
         del x, y, dw, wf, wb, wt
         torch.cuda.empty_cache()
     if FILTER:
