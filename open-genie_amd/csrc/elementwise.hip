@@ -713,7 +713,6 @@ extern "C" int genie_blur_pool3d_bwd(const void* dy_cl, int out_channels, int ou
     return GENIE_OK;
 }
 
-// LeakyReLU over a CL buffer (reference: nn.LeakyReLU in ImageResidualBlock image.py:118-131 and FrameDiscriminator.to_logits discriminator.py:91)
 // GELU, the exact (erf) form of nn.GELU() -- the default activation of the reference's ForwardBlock (misc.py:78), reached through
 // SpaceTimeAttention(hid_dim=...) (attention.py:429-438).  gelu(x) = x Phi(x);  gelu'(x) = Phi(x) + x phi(x).
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
@@ -754,6 +753,7 @@ extern "C" int genie_gelu_bwd(const void* x, const void* dy, void* dx, int64_t n
     return GENIE_OK;
 }
 
+// LeakyReLU over a CL buffer (reference: nn.LeakyReLU in ImageResidualBlock image.py:118-131 and FrameDiscriminator.to_logits discriminator.py:91)
 extern "C" int genie_leaky_relu_fwd(const void* x, void* y, int64_t numel, float slope, void* stream) {
     GENIE_CHECK_ARG(x && y && numel % 8 == 0, "genie_leaky_relu_fwd: null pointer or numel %lld not a multiple of 8", (long long)numel);
     if (numel == 0) return GENIE_OK;

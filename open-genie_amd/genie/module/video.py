@@ -200,8 +200,6 @@ class BlurPooling3d(nn.Module):
         ks = _triple(kernel_size)
         if isinstance(space_factor, int):
             space_factor = (space_factor, space_factor)
-        if num_groups != 1:
-            raise NotImplementedError('BlurPooling3d: num_groups > 1 is not implemented on the HIP path')
         self.register_buffer('blur', get_blur_kernel(ks))
         self.stride = (time_factor, *space_factor)
         self.kwargs, self.num_groups, self.out_channels = kwargs, num_groups, out_channels
@@ -209,7 +207,18 @@ class BlurPooling3d(nn.Module):
 
     def forward(self, inp: Tensor) -> Tensor:
         inp = to_cl(inp)
-        return GF.blur_pool3d(inp, self.blur, self.stride, self.padding, default(self.out_channels, inp.shape[1]))
+        c, o, g = inp.shape[1], default(self.out_channels, inp.shape[1]), self.num_groups
+        if g == 1:
+            return GF.blur_pool3d(inp, self.blur, self.stride, self.padding, o)
+        # num_groups = g (reference video.py:520-533: F.conv3d(..., groups=g) with the Pascal kernel repeated over (o, c / g)): every output
+        # channel of group i is the strided blur of the SUM of group i's input channels -- the one-group kernels on channel-slice views
+        # (a CL tensor with a pitch wider than its channel count), one launch pair per group, concatenated.  VideoResidualBlock hands its
+        # GroupNorm's num_groups to this module (video.py:592-597), so `video-residual` blueprints with groups AND a downsample land here.
+        if c % g or o % g or (c // g) % 8 or (o // g) % 8:
+            raise NotImplementedError(f'BlurPooling3d: {c} -> {o} channels in {g} groups: groups of a multiple of 8 channels only on the HIP path')
+        cg, og = c // g, o // g
+        outs = [GF.blur_pool3d(inp[:, i * cg:(i + 1) * cg], self.blur, self.stride, self.padding, og) for i in range(g)]
+        return to_cl(torch.cat(outs, dim=1))
 
     def __repr__(self):
         return f'BlurPooling3d({self.out_channels}, kernel_size={tuple(self.blur.shape)}, stride={self.stride}, padding={self.padding})'
@@ -225,12 +234,17 @@ class VideoResidualBlock(nn.Module):
                  pad_mode: str = 'constant', downsample=None, use_causal: bool = False, use_norm: bool = True,
                  use_blur: bool = True, act_fn: str = 'swish') -> None:
         super().__init__()
-        from .norm import GroupNorm, SiLU
+        from .image import LeakyReLU
+        from .norm import GELU, GroupNorm, SiLU
         if isinstance(downsample, int):
             downsample = (downsample, downsample)
         ks = _triple(kernel_size)
-        if act_fn not in ('swish', 'silu'):
-            raise NotImplementedError(f"VideoResidualBlock: act_fn '{act_fn}' is not implemented on the HIP path (swish/silu only)")
+        # reference video.py:581-585.  SiLU and LeakyReLU ride in the GroupNorm pass (genie_groupnorm_fwd act 1 / 2); ReLU (a LeakyReLU of slope
+        # 0) and GELU are one element-wise pass behind it
+        acts = {'swish': (SiLU, 1), 'silu': (SiLU, 1), 'leaky': (LeakyReLU, 2), 'relu': (lambda: LeakyReLU(0.0), 0), 'gelu': (GELU, 0)}
+        if act_fn not in acts:
+            raise ValueError(f"VideoResidualBlock: unknown act_fn '{act_fn}' (relu, gelu, leaky, swish / silu)")
+        Act, self.act_code = acts[act_fn]
         if exists(downsample) and not use_blur:
             # the reference raises TypeError here too (SpaceTimeDownsample gets an unexpected num_groups)
             raise TypeError("VideoResidualBlock: downsample with use_blur=False is unsupported (the reference raises as well)")
@@ -249,27 +263,29 @@ class VideoResidualBlock(nn.Module):
 
         norm = (lambda ch: GroupNorm(num_groups, ch)) if use_norm else (lambda ch: nn.Identity())
         self.res = nn.Sequential(down(in_channels), conv(in_channels, out_channels, 1))
-        self.main = nn.Sequential(norm(in_channels), SiLU(), conv(in_channels, out_channels, ks), down(out_channels),
-                                  norm(out_channels), SiLU(), conv(out_channels, out_channels, ks))
+        self.main = nn.Sequential(norm(in_channels), Act(), conv(in_channels, out_channels, ks), down(out_channels),
+                                  norm(out_channels), Act(), conv(out_channels, out_channels, ks))
         self.inp_channels, self.out_channels = in_channels, out_channels
         self.use_norm, self.use_causal = use_norm, use_causal
 
-    def _norm_act(self, x: Tensor, norm: nn.Module) -> Tensor:
-        if self.use_norm:
-            return GF.group_norm(x, norm.num_groups, norm.weight, norm.bias, norm.eps, act=True)
-        return GF.silu(x)
+    def _norm_act(self, x: Tensor, norm: nn.Module, act: nn.Module) -> Tensor:
+        if not self.use_norm:
+            return act(x)
+        if self.act_code:
+            return GF.group_norm(x, norm.num_groups, norm.weight, norm.bias, norm.eps, act=self.act_code)
+        return act(GF.group_norm(x, norm.num_groups, norm.weight, norm.bias, norm.eps, act=0))
 
     def forward(self, inp: Tensor) -> Tensor:
         inp = to_cl(inp)
-        if self.use_norm and isinstance(self.res[0], nn.Identity) and isinstance(self.main[3], nn.Identity):
+        if self.use_norm and self.act_code == 1 and isinstance(self.res[0], nn.Identity) and isinstance(self.main[3], nn.Identity):
             unwrap = lambda m: m.conv3d if isinstance(m, CausalConv3d) else m
             out = GF.residual_block(inp, self.main[0], unwrap(self.main[2]), self.main[4], unwrap(self.main[6]), unwrap(self.res[1]))
             if out is not None:
                 return out
         res = self.res[1](self.res[0](inp))
-        h = self.main[2](self._norm_act(inp, self.main[0]))
+        h = self.main[2](self._norm_act(inp, self.main[0], self.main[1]))
         h = self.main[3](h)
-        h = self._norm_act(h, self.main[4])
+        h = self._norm_act(h, self.main[4], self.main[5])
         last = self.main[6]
         if isinstance(last, CausalConv3d):
             return last.conv3d(h, resid=res)
