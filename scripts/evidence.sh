@@ -12,6 +12,9 @@
 #   micro    scripts/microbench.py at 8 and at 64 clips                     -> <tag>_microbench.json, <tag>_microbench_b64.json
 #   models   scripts/bench_models.py (BASELINE configs[2], [3], [4], REPR tokenizer) + their rocprofv3 kernel tables
 #                                                                          -> <tag>_bench_models.json, <tag>_models_{lam,dyn,genie4}_kernel_stats.csv
+#   variants the bench on the same box with (a) the RCCL bucket all-reduces on a single-rank group, fp32 and bf16 payload, (b) the weight
+#            gradients on a side stream -- the side measurements DESIGN.md quotes next to the default line
+#                                                                          -> <tag>_bench_variants.jsonl
 #   pmc      SQ counters of the attention families and of the dominant conv layer (separate rocprofv3 passes)
 #                                                                          -> <tag>_pmc_attn.txt, <tag>_pmc_conv.txt
 # (Rounds 1-3 used one-off scripts/exp_r*.sh files for the same jobs; they are in the history up to commit 7bfe1bc.)
@@ -57,6 +60,23 @@ for r in rows:
 PY
       bash scripts/profile_models.sh $TAG > $OUT/profile_models.log 2>&1
       cp gpurun_out/prof_models_$TAG/${TAG}_models_*_kernel_stats.csv $OUT/ 2>/dev/null ;;
+    variants)
+      : > $OUT/${TAG}_bench_variants.jsonl
+      for v in "" "--dp-loopback" "--dp-loopback --grad-compress bf16" "--async-wgrad 1"; do
+        timeout 600 python bench.py --no-cpu-baseline $v 2> $OUT/bench_variant.err | grep '^{' | tail -1 > $OUT/bench_variant.json
+        python - "$OUT/bench_variant.json" "$v" >> $OUT/${TAG}_bench_variants.jsonl <<'PY'
+import json, sys
+d = json.load(open(sys.argv[1]))
+keep = {k: d.get(k) for k in ('value', 'unit', 'ms_per_step', 'steps', 'warmup', 'n_gpus')}
+keep['flags'] = sys.argv[2] or '(default)'
+keep['roofline'] = {k: d['roofline'].get(k) for k in ('kernel', 'frac', 'achieved')}
+for k in ('comm', 'roofline_in_order', 'wgrad_side_stream'):
+    if k in d: keep[k] = d[k]
+keep['config'] = {k: d['config'].get(k) for k in ('clips_per_gpu', 'wgrad_stream', 'grad_allreduce', 'peak_mem_GB')}
+print(json.dumps(keep))
+PY
+      done
+      python -c "import json; [print('variant:', r['flags'], r['value'], r['ms_per_step'], r['roofline']['frac']) for r in map(json.loads, open('$OUT/${TAG}_bench_variants.jsonl'))]" ;;
     pmc)
       timeout 400 bash scripts/pmc_attn.sh > $OUT/pmc_attn.log 2>&1; cp gpurun_out/pmc_attn/summary.txt $OUT/${TAG}_pmc_attn.txt 2>/dev/null
       MB_BATCH=64 timeout 500 bash scripts/pmc_conv.sh > $OUT/${TAG}_pmc_conv.txt 2>&1 ;;
