@@ -54,6 +54,47 @@ class Conv3d(nn.Module):
         return f'{s.cin}, {s.cout}, kernel_size={s.kernel}, stride={s.stride}, pad_front={s.pad_front}, pad_back={s.pad_back}, shuffle={s.shuffle}'
 
 
+class GroupedConv3d(nn.Module):
+    """``nn.Conv3d(groups=G)`` (reference video.py:168-175 hands ``groups`` on to nn.Conv3d): output channels [g co, (g + 1) co) see input
+    channels [g ci, (g + 1) ci) only.  One parameter pair laid out like nn.Conv3d's (``weight`` (Cout, Cin / G, kt, kh, kw), ``bias`` (Cout)),
+    G launches of the dense conv on channel slices (a CL copy of the slice in, a channel concat out -- plumbing; no shipped blueprint
+    uses groups, so there is no grouped kernel)."""
+
+    def __init__(self, in_channels: int, out_channels: int, kernel_size, spec: ConvSpec, groups: int, bias: bool = True) -> None:
+        super().__init__()
+        if groups < 1 or in_channels % groups or out_channels % groups:
+            raise ValueError(f'in_channels {in_channels} and out_channels {out_channels} must be divisible by groups {groups}')   # nn.Conv3d's rule
+        if spec.shuffle is not None:
+            raise NotImplementedError('GroupedConv3d: a depth-to-space store pattern together with groups is not implemented')
+        ks = _triple(kernel_size)
+        ci, co = in_channels // groups, out_channels // groups
+        w = torch.empty(out_channels, ci, *ks)
+        nn.init.kaiming_uniform_(w, a=math.sqrt(5))
+        self.weight = nn.Parameter(w.contiguous(memory_format=torch.channels_last_3d))
+        if bias:
+            bound = 1 / math.sqrt(ci * ks[0] * ks[1] * ks[2])
+            self.bias = nn.Parameter(torch.empty(out_channels).uniform_(-bound, bound))
+        else:
+            self.register_parameter('bias', None)
+        self.in_channels, self.out_channels, self.kernel_size, self.groups = in_channels, out_channels, ks, groups
+        self.spec = ConvSpec(ci, co, spec.kernel, spec.stride, spec.dilation, spec.pad_front, spec.pad_back, None)
+        self.ops = [GF.ConvOp(self.spec) for _ in range(groups)]
+
+    def forward(self, inp: Tensor) -> Tensor:
+        inp = to_cl(inp)
+        ci, co = self.spec.cin, self.spec.cout
+        outs = []
+        for g, op in enumerate(self.ops):
+            xg = inp[:, g * ci:(g + 1) * ci]              # ci % 8 == 0: a CL view (same pitch, 16-byte aligned); else a dense copy with zeroed pad channels
+            if ci % 8:
+                xg = xg.clone(memory_format=torch.contiguous_format)
+            outs.append(GF.conv3d(xg, self.weight[g * co:(g + 1) * co], None if self.bias is None else self.bias[g * co:(g + 1) * co], op))
+        return to_cl(torch.cat(outs, dim=1))
+
+    def extra_repr(self) -> str:
+        return f'{self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, groups={self.groups}, stride={self.spec.stride}'
+
+
 def get_blur_kernel(kernel_size, device=None, dtype=None, norm: bool = True) -> Tensor:
     """Pascal-triangle blur taps (reference video.py:22-56, including its use of kernel_size[0] for the
     h taps and for the length of the w taps)."""
@@ -107,8 +148,7 @@ class CausalConv3d(nn.Module):
         if pad_mode not in ('constant', 'reflect', 'replicate', 'circular'):
             raise ValueError(f"CausalConv3d: unknown pad_mode '{pad_mode}'")
         bias = kwargs.pop('bias', True)
-        if kwargs.pop('groups', 1) != 1:
-            raise NotImplementedError('CausalConv3d: grouped convolutions are not implemented on the HIP path')
+        groups = int(kwargs.pop('groups', 1))
         if kwargs:
             raise TypeError(f'CausalConv3d: unexpected arguments {sorted(kwargs)}')
         spec = causal_spec(in_channels, out_channels, kernel_size, stride, dilation, padding, shuffle=_shuffle)
@@ -121,7 +161,8 @@ class CausalConv3d(nn.Module):
                 raise NotImplementedError("CausalConv3d: a negative causal pad (cropping) together with a non-constant pad_mode is not implemented")
             self._pads = (spec.pad_front[2], spec.pad_back[2], spec.pad_front[1], spec.pad_back[1], spec.pad_front[0], spec.pad_back[0])
             spec = ConvSpec(in_channels, spec.cout, kernel_size, stride, dilation, (0, 0, 0), (0, 0, 0), _shuffle)
-        self.conv3d = Conv3d(in_channels, out_channels, kernel_size, spec, bias=bias)
+        self.conv3d = (Conv3d(in_channels, out_channels, kernel_size, spec, bias=bias) if groups == 1
+                       else GroupedConv3d(in_channels, out_channels, kernel_size, spec, groups, bias=bias))
         self.in_channels, self.out_channels = in_channels, out_channels
         # a NEGATIVE causal pad (kt = 1, time stride 2: (kt - 1) dil + 1 - stride = -1) crops leading frames in the reference (F.pad with a
         # negative amount, video.py:154-164, 189)

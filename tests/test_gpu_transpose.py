@@ -165,3 +165,36 @@ def test_causal_conv3d_pad_modes(mode, cin, cout, k, stride, size):
     assert rel_rms(m.conv3d.weight.grad, w.grad) < 2e-3 and rel_rms(m.conv3d.bias.grad, b.grad) < 2e-3
     with pytest.raises(ValueError):
         CausalConv3d(cin, cout, k, pad_mode='zeros')
+
+
+@pytest.mark.parametrize('cin,cout,groups,k,stride,size', [(64, 128, 2, 3, (1, 1, 1), (2, 4, 8, 8)), (128, 64, 4, (3, 3, 3), (1, 2, 2), (1, 5, 8, 8)),
+                                                           (12, 24, 3, 3, (1, 1, 1), (2, 3, 6, 6)), (64, 64, 64, 3, (2, 1, 1), (1, 6, 6, 6))])
+def test_causal_conv3d_groups(cin, cout, groups, k, stride, size):
+    """CausalConv3d(groups=G) (reference video.py:168-175: the keyword goes to nn.Conv3d) -- outputs, input and parameter gradients against
+    F.conv3d(groups=G) on the causally padded input in fp32; parameters keep nn.Conv3d's grouped shapes (state_dict compatible).  Group
+    widths that are / are not multiples of the 8-channel pitch, and the depthwise case.  Round 3 raised for groups != 1."""
+    from genie.module.video import CausalConv3d
+    torch.manual_seed(17)
+    m = CausalConv3d(cin, cout, k, stride=stride, groups=groups)
+    assert tuple(m.conv3d.weight.shape)[:2] == (cout, cin // groups) and tuple(m.conv3d.bias.shape) == (cout,)
+    with torch.no_grad():
+        m.conv3d.weight.copy_(bf16_round(m.conv3d.weight))
+    w, b = m.conv3d.weight.detach().clone().requires_grad_(True), m.conv3d.bias.detach().clone().requires_grad_(True)
+    m = m.cuda()
+    n, t, h, ww = size
+    x = bf16_round(torch.randn(n, cin, t, h, ww))
+    xr = x.clone().requires_grad_(True)
+    kt, kh, kw = (k, k, k) if isinstance(k, int) else k
+    pads = ((kw - 1) // 2, (kw - 1) // 2, (kh - 1) // 2, (kh - 1) // 2, (kt - 1) + (1 - stride[0]), 0)
+    ref = torch.nn.functional.conv3d(torch.nn.functional.pad(xr, pads), w, b, stride=stride, groups=groups)
+    dy = bf16_round(torch.randn_like(ref))
+    ref.backward(dy)
+    xc = x.cuda().requires_grad_(True)
+    out = m(xc)
+    assert tuple(out.shape) == tuple(ref.shape)
+    assert_close_bf16(out, ref, f'groups {groups}')
+    out.backward(dy.cuda())
+    assert rel_rms(xc.grad, xr.grad) < 4e-3, rel_rms(xc.grad, xr.grad)
+    assert rel_rms(m.conv3d.weight.grad, w.grad) < 2e-3 and rel_rms(m.conv3d.bias.grad, b.grad) < 2e-3
+    with pytest.raises(ValueError):
+        CausalConv3d(cin, cout + 1, k, groups=groups)
