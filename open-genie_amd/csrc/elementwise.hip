@@ -578,8 +578,11 @@ extern "C" int genie_pack_transpose_batched(const GeniePackJob* jobs_dev, int nj
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) chan_sum_kernel(const bf16_t* __restrict__ x, long long npix, int C, int Cp, float* __restrict__ out) {
     // a group of L = 8 lanes per pixel walks the pixel's 16-B chunks; 8 pixels per wave-instruction
+    // only the chunks that hold channels: x may be a channel-slice VIEW (the grouped blur: C = one group, Cp = the pitch of the whole tensor),
+    // and walking the pitch from the view's first channel ran past the end of the tensor on its last pixels (found with rocgdb as a memory
+    // fault that depended on where the allocator had placed the tensor)
     const int lane = threadIdx.x & 63, sub = lane & 7;
-    const int nch = Cp >> 3;
+    const int nch = (C + 7) >> 3;
     for (long long p = ((long long)blockIdx.x * 256 + threadIdx.x) >> 3; p < npix; p += ((long long)gridDim.x * 256) >> 3) {
         float s = 0.f;
         for (int ch = sub; ch < nch; ch += 8) {

@@ -26,6 +26,42 @@ struct GnGeom {
     long long pix_per_blk;
 };
 
+// Sweep order of the streaming passes (K = 16-byte accesses a thread issues together per stream):
+//   legacy (GENIE_GN_SWEEP=0; rounds 1-3): a block owns ONE contiguous pixel range of its sample and walks it two accesses deep -- all four
+//       passes sat at 5.0-5.4 TB/s, which matched the runtime's device copy and was taken for the ceiling;
+//   default: the sample is cut into chunks of K block-rows (K x 4 KB when the 256 threads cover whole pixels) and read with non-temporal loads.
+//       The passes that keep per-block partial sums (statistics K = 8, backward reduce K = 4) give block b the chunks b, b + nblk, ...: the
+//       blocks of a sample read one dense window instead of nblk windows 0.5 MB apart.  The passes that write (apply, backward apply; K = 4)
+//       run ONE chunk per block -- many short blocks dispatched in address order keep the read and the write stream dense, which persistent
+//       blocks do not (scripts/probes/hbm_stream*.hip: a copy reaches 6.2 TB/s that way, 5.3 with a contiguous range per block).
+//   Measured per pass on a 1.07-GB tensor (64 x 128ch x 16x64x64, rocprofv3): statistics 211 -> 162 us (6.6 TB/s), apply 390 -> 358
+//   (6.0), backward reduce 383-428 -> 333 (6.4), backward apply 587 -> 533 us (6.0).
+#define GENIE_GN_SWEEP_DEFAULT 1
+static int gn_sweep() {
+    static const int k = getenv("GENIE_GN_SWEEP") ? atoi(getenv("GENIE_GN_SWEEP")) : GENIE_GN_SWEEP_DEFAULT;
+    return k != 0;
+}
+#define GN_K_STATS 8
+#define GN_K_PASS 4
+// geometry of the passes without per-block partial sums: one chunk per block
+static GnGeom gn_geom_apply(GnGeom g) {
+    if (gn_sweep()) {
+        const int chb = g.CH < 256 ? g.CH : 256;
+        const long long chunk_pix = (long long)GN_K_PASS * (256 / chb);
+        const long long nb = (g.npix + chunk_pix - 1) / chunk_pix;
+        if (nb <= 0x7fffffffll) g.nblk = (int)nb;
+    }
+    return g;
+}
+// activation selected at COMPILE time: with `act` as a run-time argument hipcc turned `act == 1 ? silu(z) : ...` into one scalar branch per
+// ELEMENT (32 three-instruction basic blocks per access, each a serial exp -> rcp chain behind s_nop hazards), and the passes ran at the
+// issue rate of that code, not at the rate of the memory system
+template <int ACT> __device__ __forceinline__ float gn_act(float z) { return ACT == 1 ? silu_f(z) : (ACT == 2 ? (z > 0.f ? z : 0.01f * z) : z); }
+template <int ACT> __device__ __forceinline__ float gn_act_bwd(float z, float d) {
+    return ACT == 1 ? d * silu_grad_f(z) : (ACT == 2 ? (z > 0.f ? d : 0.01f * d) : d);
+}
+__device__ __forceinline__ u32x4_t gn_ld_stream(const bf16_t* p) { return __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p)); }
+
 static GnGeom gn_geom(int N, long long npix, int C, int Cp, int G) {
     GnGeom g;
     g.N = N; g.C = C; g.Cp = Cp; g.G = G; g.CH = Cp / 8; g.npix = npix;
@@ -46,6 +82,7 @@ extern "C" int64_t genie_groupnorm_ws_floats(int N, int C, int G) {
 }
 
 // ---- stats: per (n, blk, channel) sum and sum of squares ------------------------------------------
+template <int K>
 __global__ void __launch_bounds__(256) gn_stats_kernel(const bf16_t* __restrict__ x, GnGeom g, float* __restrict__ part) {
     __shared__ float red[256 * 16];
     const int n = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
@@ -60,13 +97,31 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const bf16_t* __restrict_
         float s[8], q[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) s[j] = q[j] = 0.f;
-        if (pr < R) {
+        if (pr < R && K == 0) {
     #pragma unroll 2
         for (long long p = p0 + pr; p < p1; p += R) {
                 float f[8];
                 unpack8(*reinterpret_cast<const u32x4_t*>(xs + p * g.Cp + cc * 8), f);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { s[j] += f[j]; q[j] += f[j] * f[j]; }
+            }
+        }
+        if (pr < R && K > 0) {
+            constexpr int KK = K > 0 ? K : 1;
+            for (long long pc = (long long)blk * (KK * R); pc < g.npix; pc += (long long)g.nblk * (KK * R)) {
+                u32x4_t v[KK];
+#pragma unroll
+                for (int k = 0; k < KK; ++k) {
+                    const long long p = pc + k * R + pr;
+                    v[k] = p < g.npix ? gn_ld_stream(xs + p * g.Cp + cc * 8) : u32x4_t{0u, 0u, 0u, 0u};
+                }
+#pragma unroll
+                for (int k = 0; k < KK; ++k) {
+                    float f[8];
+                    unpack8(v[k], f);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { s[j] += f[j]; q[j] += f[j] * f[j]; }
+                }
             }
         }
 #pragma unroll
@@ -150,10 +205,42 @@ __device__ __forceinline__ void gn_coef(int n, int c, const GnGeom& g, const flo
     b = (be - mu * rs * ga) * as + ab;
 }
 
+// the same for the 8 consecutive channels [c0, c0 + 8) of one 16-byte chunk.  Common case -- all 8 inside C and inside ONE group, no
+// adaptive scale / shift: one group lookup, gamma / beta as two 16-byte loads each (c0 is a multiple of 8, cudaMalloc'ed parameters are
+// 16-byte aligned when c0 * 4 is) instead of 8 divisions and 32 dependent scalar loads; this is the prologue of every block of every pass
+__device__ __forceinline__ void gn_coef8(int n, int c0, const GnGeom& g, const float* gamma, const float* beta, const float* ada_s,
+                                         const float* ada_b, const float* mean, const float* rstd, float* a, float* b, float* mu,
+                                         float* rs, float* ge) {
+    const int cg = g.C / g.G;
+    const bool fast = c0 + 8 <= g.C && (cg & 7) == 0 && !ada_s && !ada_b && ((reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) & 15) == 0;
+    if (fast) {
+        const int grp = c0 / cg;
+        const float m = mean[n * g.G + grp], r = rstd[n * g.G + grp];
+        float ga[8], be[8];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float4 gv = gamma ? *reinterpret_cast<const float4*>(gamma + c0 + 4 * h) : float4{1.f, 1.f, 1.f, 1.f};
+            const float4 bv = beta ? *reinterpret_cast<const float4*>(beta + c0 + 4 * h) : float4{0.f, 0.f, 0.f, 0.f};
+            ga[4 * h] = gv.x; ga[4 * h + 1] = gv.y; ga[4 * h + 2] = gv.z; ga[4 * h + 3] = gv.w;
+            be[4 * h] = bv.x; be[4 * h + 1] = bv.y; be[4 * h + 2] = bv.z; be[4 * h + 3] = bv.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            mu[j] = m; rs[j] = r; ge[j] = ga[j];
+            a[j] = r * ga[j];
+            b[j] = be[j] - m * r * ga[j];
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) gn_coef(n, c0 + j, g, gamma, beta, ada_s, ada_b, mean, rstd, a[j], b[j], mu[j], rs[j], ge[j]);
+}
+
+template <int K, int ACT>
 __global__ void __launch_bounds__(256) gn_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, GnGeom g,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ ada_s, const float* __restrict__ ada_b,
-                                                       const float* __restrict__ mean, const float* __restrict__ rstd, int act) {
+                                                       const float* __restrict__ mean, const float* __restrict__ rstd) {
     const int n = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
     const long long p0 = (long long)blk * g.pix_per_blk;
     long long p1 = p0 + g.pix_per_blk;
@@ -166,11 +253,11 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const bf16_t* __restrict_
         const int pr = tid / chb, cc = cc0 + tid % chb;
         if (pr >= R) continue;
         float a[8], b[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float mu, rs, ge;
-            gn_coef(n, cc * 8 + j, g, gamma, beta, ada_s, ada_b, mean, rstd, a[j], b[j], mu, rs, ge);
+        {
+            float mu[8], rs[8], ge[8];
+            gn_coef8(n, cc * 8, g, gamma, beta, ada_s, ada_b, mean, rstd, a, b, mu, rs, ge);
         }
+        if (K == 0) {
 #pragma unroll 2
         for (long long p = p0 + pr; p < p1; p += R) {
             float f[8];
@@ -178,12 +265,55 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const bf16_t* __restrict_
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 float z = f[j] * a[j] + b[j];
-                f[j] = act == 1 ? silu_f(z) : (act == 2 ? (z > 0.f ? z : 0.01f * z) : z);
+                f[j] = gn_act<ACT>(z);
             }
             *reinterpret_cast<u32x4_t*>(ys + p * g.Cp + cc * 8) = pack8(f);
         }
+        } else {
+            constexpr int KK = K > 0 ? K : 1;
+            for (long long pc = (long long)blk * (KK * R); pc < g.npix; pc += (long long)g.nblk * (KK * R)) {
+                u32x4_t v[KK];
+#pragma unroll
+                for (int k = 0; k < KK; ++k) {
+                    const long long p = pc + k * R + pr;
+                    v[k] = p < g.npix ? gn_ld_stream(xs + p * g.Cp + cc * 8) : u32x4_t{0u, 0u, 0u, 0u};
+                }
+#pragma unroll
+                for (int k = 0; k < KK; ++k) {
+                    const long long p = pc + k * R + pr;
+                    float f[8];
+                    unpack8(v[k], f);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        float z = f[j] * a[j] + b[j];
+                        f[j] = gn_act<ACT>(z);
+                    }
+                    if (p < g.npix) *reinterpret_cast<u32x4_t*>(ys + p * g.Cp + cc * 8) = pack8(f);
+                }
+            }
+        }
     }
 }
+
+
+// launch one of the streaming passes: sweep order and activation (0 none, 1 SiLU, 2 LeakyReLU 0.01) as template arguments
+#define GN_UNPAREN(...) __VA_ARGS__
+#define GN_LAUNCH_K(kernel, cfg, args)                                                         \
+    do {                                                                                       \
+        if (gn_sweep()) kernel<GN_K_STATS><<<GN_UNPAREN cfg>>>(GN_UNPAREN args);               \
+        else kernel<0><<<GN_UNPAREN cfg>>>(GN_UNPAREN args);                                   \
+    } while (0)
+#define GN_LAUNCH_KA_(kernel, K, act, cfg, args)                                               \
+    do {                                                                                       \
+        if ((act) == 1) kernel<K, 1><<<GN_UNPAREN cfg>>>(GN_UNPAREN args);                     \
+        else if ((act) == 2) kernel<K, 2><<<GN_UNPAREN cfg>>>(GN_UNPAREN args);                \
+        else kernel<K, 0><<<GN_UNPAREN cfg>>>(GN_UNPAREN args);                                \
+    } while (0)
+#define GN_LAUNCH_KA(kernel, act, cfg, args)                                                   \
+    do {                                                                                       \
+        if (gn_sweep()) GN_LAUNCH_KA_(kernel, GN_K_PASS, act, cfg, args);                      \
+        else GN_LAUNCH_KA_(kernel, 0, act, cfg, args);                                         \
+    } while (0)
 
 // Samples per launch group: all of them unless GENIE_GN_CHUNK_MB > 0 and the tensors streamed per sample (`streams` of them, each
 // `bytes_per_sample`) exceed that many MiB in total; then as many whole samples as fit.
@@ -222,11 +352,11 @@ extern "C" int genie_groupnorm_fwd(const void* x, void* y, int N, int64_t npix, 
         bf16_t* ys = (bf16_t*)y + (long long)n0 * npix * cpitch;
         const float* as = ada_scale ? ada_scale + (long long)n0 * C : nullptr;
         const float* ab = ada_shift ? ada_shift + (long long)n0 * C : nullptr;
-        gn_stats_kernel<<<dim3(g.nblk, nn), 256, 0, s>>>(xs, g, ws);
+        GN_LAUNCH_K(gn_stats_kernel, (dim3(g.nblk, nn), 256, 0, s), (xs, g, ws));
         GENIE_CHECK_LAUNCH();
         gn_finalize_kernel<<<dim3(G, nn), GN_FIN_THREADS, 0, s>>>(ws, g, eps, mean + (long long)n0 * G, rstd + (long long)n0 * G);
         GENIE_CHECK_LAUNCH();
-        gn_apply_kernel<<<dim3(g.nblk, nn), 256, 0, s>>>(xs, ys, g, gamma, beta, as, ab, mean + (long long)n0 * G, rstd + (long long)n0 * G, act);
+        GN_LAUNCH_KA(gn_apply_kernel, act, (dim3(gn_geom_apply(g).nblk, nn), 256, 0, s), (xs, ys, gn_geom_apply(g), gamma, beta, as, ab, mean + (long long)n0 * G, rstd + (long long)n0 * G));
         GENIE_CHECK_LAUNCH();
     }
     return GENIE_OK;
@@ -508,11 +638,12 @@ static int gn_fused_fwd_try(const void* x, void* y, int N, long long npix, int C
 
 // ---- backward -------------------------------------------------------------------------------------
 // z = xhat * gam_eff + b_eff,  dz = dy * act'(z);  S1[n,c] = sum dz,  S2[n,c] = sum dz * xhat
+template <int K, int ACT>
 __global__ void __launch_bounds__(256) gn_bwd_reduce_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, GnGeom g,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             const float* __restrict__ ada_s, const float* __restrict__ ada_b,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                            int act, float* __restrict__ part) {
+                                                            float* __restrict__ part) {
     __shared__ float red[256 * 16];
     const int n = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
     const long long p0 = (long long)blk * g.pix_per_blk;
@@ -529,11 +660,13 @@ __global__ void __launch_bounds__(256) gn_bwd_reduce_kernel(const bf16_t* __rest
         for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
         if (pr < R) {
             float a[8], b[8], mu[8], rs[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float ge;
-                gn_coef(n, cc * 8 + j, g, gamma, beta, ada_s, ada_b, mean, rstd, a[j], b[j], mu[j], rs[j], ge);
+            {
+                float ge[8];
+                gn_coef8(n, cc * 8, g, gamma, beta, ada_s, ada_b, mean, rstd, a, b, mu, rs, ge);
             }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) mu[j] = -mu[j] * rs[j];
+            if (K == 0) {
     #pragma unroll 2
         for (long long p = p0 + pr; p < p1; p += R) {
                 float f[8], d[8];
@@ -542,9 +675,35 @@ __global__ void __launch_bounds__(256) gn_bwd_reduce_kernel(const bf16_t* __rest
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const float z = f[j] * a[j] + b[j];
-                    const float dz = act == 1 ? d[j] * silu_grad_f(z) : (act == 2 ? (z > 0.f ? d[j] : 0.01f * d[j]) : d[j]);
+                    const float dz = gn_act_bwd<ACT>(z, d[j]);
                     s1[j] += dz;
-                    s2[j] += dz * (f[j] - mu[j]) * rs[j];
+                    s2[j] += dz * (f[j] * rs[j] + mu[j]);      // mu[j] holds -mean * rstd
+                }
+            }
+            } else {
+                constexpr int KK = K > 0 ? K : 1;
+                for (long long pc = (long long)blk * (KK * R); pc < g.npix; pc += (long long)g.nblk * (KK * R)) {
+                    u32x4_t vx[KK], vd[KK];
+#pragma unroll
+                    for (int k = 0; k < KK; ++k) {
+                        const long long p = pc + k * R + pr;
+                        const bool ok = p < g.npix;
+                        vx[k] = ok ? gn_ld_stream(xs + p * g.Cp + cc * 8) : u32x4_t{0u, 0u, 0u, 0u};
+                        vd[k] = ok ? gn_ld_stream(ds + p * g.Cp + cc * 8) : u32x4_t{0u, 0u, 0u, 0u};      // dy = 0: the pixel adds nothing
+                    }
+#pragma unroll
+                    for (int k = 0; k < KK; ++k) {
+                        float f[8], d[8];
+                        unpack8(vx[k], f);
+                        unpack8(vd[k], d);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const float z = f[j] * a[j] + b[j];
+                            const float dz = gn_act_bwd<ACT>(z, d[j]);
+                            s1[j] += dz;
+                            s2[j] += dz * (f[j] * rs[j] + mu[j]);      // mu[j] holds -mean * rstd
+                        }
+                    }
                 }
             }
         }
@@ -623,11 +782,12 @@ __global__ void __launch_bounds__(GN_FIN_THREADS) gn_bwd_finalize_kernel(const f
     }
 }
 
+template <int K, int ACT>
 __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
                                                            bf16_t* __restrict__ dx, GnGeom g, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const float* __restrict__ ada_s,
                                                            const float* __restrict__ ada_b, const float* __restrict__ mean,
-                                                           const float* __restrict__ rstd, const float* __restrict__ kcoef, int act) {
+                                                           const float* __restrict__ rstd, const float* __restrict__ kcoef) {
     const int n = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
     const long long p0 = (long long)blk * g.pix_per_blk;
     long long p1 = p0 + g.pix_per_blk;
@@ -641,20 +801,28 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const bf16_t* __restr
         const int pr = tid / chb, cc = cc0 + tid % chb;
         if (pr >= R) continue;
         float a[8], b[8], k1[8], k2[8], k3[8];
+        {
+            float mu[8], rs[8], ge[8];
+            gn_coef8(n, cc * 8, g, gamma, beta, ada_s, ada_b, mean, rstd, a, b, mu, rs, ge);
+            const int cg = g.C / g.G;
+            const bool one_group = cc * 8 + 8 <= g.C && (cg & 7) == 0;
+            const float2 kk = one_group ? *reinterpret_cast<const float2*>(kcoef + (n * g.G + cc * 8 / cg) * 2) : float2{0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float mu, rs, ge;
-            const int c = cc * 8 + j;
-            gn_coef(n, c, g, gamma, beta, ada_s, ada_b, mean, rstd, a[j], b[j], mu, rs, ge);
-            if (c < g.C) {
-                const int grp = c / (g.C / g.G);
-                k1[j] = rs * ge;
-                k2[j] = kcoef[(n * g.G + grp) * 2 + 0];
-                k3[j] = kcoef[(n * g.G + grp) * 2 + 1];
-            } else {
-                k1[j] = k2[j] = k3[j] = 0.f;
+            for (int j = 0; j < 8; ++j) {
+                const int c = cc * 8 + j;
+                if (one_group) {
+                    k1[j] = rs[j] * ge[j]; k2[j] = kk.x; k3[j] = kk.y;
+                } else if (c < g.C) {
+                    const int grp = c / cg;
+                    k1[j] = rs[j] * ge[j];
+                    k2[j] = kcoef[(n * g.G + grp) * 2 + 0];
+                    k3[j] = kcoef[(n * g.G + grp) * 2 + 1];
+                } else {
+                    k1[j] = k2[j] = k3[j] = 0.f;
+                }
             }
         }
+        if (K == 0) {
 #pragma unroll 2
         for (long long p = p0 + pr; p < p1; p += R) {
             float f[8], d[8];
@@ -663,10 +831,37 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const bf16_t* __restr
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float z = f[j] * a[j] + b[j];
-                const float dz = act == 1 ? d[j] * silu_grad_f(z) : (act == 2 ? (z > 0.f ? d[j] : 0.01f * d[j]) : d[j]);
+                const float dz = gn_act_bwd<ACT>(z, d[j]);
                 d[j] = k1[j] * dz + k2[j] * f[j] + k3[j];
             }
             *reinterpret_cast<u32x4_t*>(os + p * g.Cp + cc * 8) = pack8(d);
+        }
+        } else {
+            constexpr int KK = K > 0 ? K : 1;
+            for (long long pc = (long long)blk * (KK * R); pc < g.npix; pc += (long long)g.nblk * (KK * R)) {
+                u32x4_t vx[KK], vd[KK];
+#pragma unroll
+                for (int k = 0; k < KK; ++k) {
+                    const long long p = pc + k * R + pr;
+                    const bool ok = p < g.npix;
+                    vx[k] = ok ? gn_ld_stream(xs + p * g.Cp + cc * 8) : u32x4_t{0u, 0u, 0u, 0u};
+                    vd[k] = ok ? gn_ld_stream(ds + p * g.Cp + cc * 8) : u32x4_t{0u, 0u, 0u, 0u};
+                }
+#pragma unroll
+                for (int k = 0; k < KK; ++k) {
+                    const long long p = pc + k * R + pr;
+                    float f[8], d[8];
+                    unpack8(vx[k], f);
+                    unpack8(vd[k], d);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float z = f[j] * a[j] + b[j];
+                        const float dz = gn_act_bwd<ACT>(z, d[j]);
+                        d[j] = k1[j] * dz + k2[j] * f[j] + k3[j];
+                    }
+                    if (p < g.npix) *reinterpret_cast<u32x4_t*>(os + p * g.Cp + cc * 8) = pack8(d);
+                }
+            }
         }
     }
 }
@@ -693,12 +888,12 @@ extern "C" int genie_groupnorm_bwd(const void* x, const void* dy, void* dx, int 
         const float* ab = ada_shift ? ada_shift + (long long)n0 * C : nullptr;
         const float* mu = mean + (long long)n0 * G;
         const float* rs = rstd + (long long)n0 * G;
-        gn_bwd_reduce_kernel<<<dim3(g.nblk, nn), 256, 0, s>>>(xs, dys, g, gamma, beta, as, ab, mu, rs, act, ws);
+        GN_LAUNCH_KA(gn_bwd_reduce_kernel, act, (dim3(g.nblk, nn), 256, 0, s), (xs, dys, g, gamma, beta, as, ab, mu, rs, ws));
         GENIE_CHECK_LAUNCH();
         gn_bwd_finalize_kernel<<<dim3(G, nn), GN_FIN_THREADS, 0, s>>>(ws, g, gamma, beta, as, mu, rs, dgamma, dbeta, dada_scale ? dada_scale + (long long)n0 * C : nullptr,
                                                                       dada_shift ? dada_shift + (long long)n0 * C : nullptr, kcoef);
         GENIE_CHECK_LAUNCH();
-        gn_bwd_apply_kernel<<<dim3(g.nblk, nn), 256, 0, s>>>(xs, dys, (bf16_t*)dx + eo, g, gamma, beta, as, ab, mu, rs, kcoef, act);
+        GN_LAUNCH_KA(gn_bwd_apply_kernel, act, (dim3(gn_geom_apply(g).nblk, nn), 256, 0, s), (xs, dys, (bf16_t*)dx + eo, gn_geom_apply(g), gamma, beta, as, ab, mu, rs, kcoef));
         GENIE_CHECK_LAUNCH();
     }
     return GENIE_OK;
@@ -728,7 +923,7 @@ extern "C" int genie_groupnorm_fwd_from_sums(const void* x, void* y, int N, int6
     const GnGeom g = gn_geom(N, npix, C, cpitch, 1);
     gn_finalize_sums_kernel<<<(N + 255) / 256, 256, 0, s>>>(sums, N, (double)C * (double)npix, eps, mean, rstd);
     GENIE_CHECK_LAUNCH();
-    gn_apply_kernel<<<dim3(g.nblk, N), 256, 0, s>>>((const bf16_t*)x, (bf16_t*)y, g, gamma, beta, nullptr, nullptr, mean, rstd, act);
+    GN_LAUNCH_KA(gn_apply_kernel, act, (dim3(gn_geom_apply(g).nblk, N), 256, 0, s), ((const bf16_t*)x, (bf16_t*)y, gn_geom_apply(g), gamma, beta, nullptr, nullptr, mean, rstd));
     GENIE_CHECK_LAUNCH();
     return GENIE_OK;
 }
@@ -748,7 +943,7 @@ extern "C" int genie_groupnorm_bwd_from_part(const void* x, const void* dy, void
     gf.nblk = nblk;                                      // the partials come one per 256-row conv tile, not one per block of the reduce pass
     gn_bwd_finalize_kernel<<<dim3(1, N), GN_FIN_THREADS, 0, s>>>(part, gf, gamma, beta, nullptr, mean, rstd, dgamma, dbeta, nullptr, nullptr, ws);
     GENIE_CHECK_LAUNCH();
-    gn_bwd_apply_kernel<<<dim3(g.nblk, N), 256, 0, s>>>((const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, g, gamma, beta, nullptr, nullptr, mean, rstd, ws, act);
+    GN_LAUNCH_KA(gn_bwd_apply_kernel, act, (dim3(gn_geom_apply(g).nblk, N), 256, 0, s), ((const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, gn_geom_apply(g), gamma, beta, nullptr, nullptr, mean, rstd, ws));
     GENIE_CHECK_LAUNCH();
     return GENIE_OK;
 }
