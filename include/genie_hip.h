@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GENIE_ABI_VERSION 10
+#define GENIE_ABI_VERSION 11
 
 #define GENIE_F32 0
 #define GENIE_BF16 1
@@ -297,6 +297,28 @@ int genie_masked_ce_fwd(const void* logits_bf16, int64_t pitch, int64_t nrow, in
                         float* row_lse, float* loss_sum, void* stream);
 int genie_masked_ce_bwd(const void* logits_bf16, int64_t pitch, int64_t nrow, int V, const int64_t* target, const unsigned char* mask,
                         const float* row_lse, const float* scale, void* dlogits_bf16, int64_t dpitch, void* stream);
+
+/* Fused vocabulary head + masked token cross-entropy (linear_ce.hip; ABI 11).   replaces: `self.head` Linear(D -> V) of
+ * DynamicsModel.forward (dynamics.py:44, :62) TOGETHER WITH logits[mask] + F.cross_entropy of compute_loss (dynamics.py:89-97) -- the
+ * `linear_cross_entropy(h, W, b, target, mask)` of SURVEY.md section 8(b).  The M x V logits are never written: both directions are
+ * flash-attention-shaped sweeps with D-wide accumulators.
+ *   h: bf16 [M][h_pitch >= D] (the gathered trunk rows); W: bf16 [V][w_pitch >= D] (the head's forward weight pack); bias: fp32 [V] or NULL;
+ *   target: int64 [M]; valid: uint8 [M] or NULL (= every row counts).  D in {64, 128, 256, 512}; genie_linear_ce_supported() says whether
+ *   a shape is taken (otherwise use genie_conv_igemm + genie_masked_ce_*).
+ * fwd: row_lse[m] = logsumexp_v(h[m] . W[v] + b[v]) (fp32 logits);  *loss_sum += sum over valid rows of (lse - logit[target]) (caller zeroes
+ *      it and divides by the valid-row count; a target outside [0, V) poisons it with NaN);  row_e: [M rounded up to 64] scratch the backward
+ *      consumes (-lse, -inf for rows that are off);  dh_f32 (may be NULL = no gradient wanted): [M][D] fp32, softmax(logits) W - W[target],
+ *      i.e. d loss_sum / d h, zeros for rows that are off.  ws: genie_linear_ce_ws_floats(M, D, V, dh_f32 != NULL) floats.
+ * bwd: dh_bf16[m] = dh_f32[m] * *scale (skipped when both are NULL);  dW [V][D] fp32 += *scale * (softmax - onehot)^T h (skipped when NULL),
+ *      dbias [V] += *scale * column sums (may be NULL).  scale = upstream gradient / valid-row count, a device scalar. */
+int genie_linear_ce_supported(int64_t M, int D, int64_t V, int64_t h_pitch, int64_t w_pitch);
+int64_t genie_linear_ce_ws_floats(int64_t M, int D, int64_t V, int with_grad);
+int genie_linear_ce_fwd(const void* h_bf16, int64_t h_pitch, int64_t M, int D, const void* w_bf16, int64_t w_pitch, int64_t V,
+                        const float* bias, const int64_t* target, const unsigned char* valid, float* ws, int64_t ws_floats,
+                        float* row_lse, float* row_e, float* loss_sum, float* dh_f32, void* stream);
+int genie_linear_ce_bwd(const void* h_bf16, int64_t h_pitch, int64_t M, int D, const void* w_bf16, int64_t w_pitch, int64_t V,
+                        const float* bias, const int64_t* target, const float* row_e, const float* scale, const float* dh_f32,
+                        void* dh_bf16, int64_t dh_pitch, float* dW, float* dbias, void* stream);
 
 /* MaskGIT sampling step (maskgit.hip).   replaces: softmax(logits / temp) + torch.multinomial + gather (confidence) and
  * topk + gather + scatter_ of DynamicsModel.generate, dynamics.py:138-158.  The multinomial draw is an inverse-CDF draw from an

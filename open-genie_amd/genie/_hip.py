@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('GENIE_HIP_LIB', os.path.join(os.path.dirname(_HERE), 'lib', 'libgenie_hip.so'))
 
 GENIE_F32, GENIE_BF16 = 0, 1
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 class GenieTap(C.Structure):
@@ -101,6 +101,10 @@ SIGNATURES = {
     'genie_lfq_bwd': (C.c_int, [_P, _P, _P, _P, _I, _L, _I, _L, _P]),
     'genie_masked_ce_fwd': (C.c_int, [_P, _L, _L, _I, _P, _P, _P, _P, _P]),
     'genie_masked_ce_bwd': (C.c_int, [_P, _L, _L, _I, _P, _P, _P, _P, _P, _L, _P]),
+    'genie_linear_ce_supported': (C.c_int, [_L, _I, _L, _L, _L]),
+    'genie_linear_ce_ws_floats': (C.c_int64, [_L, _I, _L, _I]),
+    'genie_linear_ce_fwd': (C.c_int, [_P, _L, _L, _I, _P, _L, _L, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P]),
+    'genie_linear_ce_bwd': (C.c_int, [_P, _L, _L, _I, _P, _L, _L, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P]),
     'genie_maskgit_sample': (C.c_int, [_P, _I, _L, _L, _L, _L, _L, _P, _F, _P, _P, _P]),
     'genie_maskgit_paint': (C.c_int, [_P, _P, _L, _L, _L, _P, _P, _P]),
     'genie_mse_fwd': (C.c_int, [_P, _I, _P, _I, _PL, _PL, _P, _P, _P]),

@@ -91,14 +91,20 @@ class DynamicsModel(nn.Module):
             valid = torch.arange(rp, device=rows.device) < flat.sum()          # (no masked row at all: 0 / 0 = NaN, as F.cross_entropy)
             x = self._trunk(tokens, act_id.detach())
             d = x.shape[-1]
-            xc = x.reshape(-1, d).index_select(0, rows).view(1, gt, gh, 256, d)
-            return GF.masked_cross_entropy(self._head(xc), tokens.reshape(-1).index_select(0, rows).view(1, gt, gh, 256), valid)
+            xr = x.reshape(-1, d).index_select(0, rows)
+            if GF.linear_ce_supported(xr, self.head.weight):
+                return self._fused_loss(xr, tokens.reshape(-1).index_select(0, rows), valid)
+            return GF.masked_cross_entropy(self._head(xr.view(1, gt, gh, 256, d)), tokens.reshape(-1).index_select(0, rows).view(1, gt, gh, 256), valid)
         flat = (host_mask.squeeze() if host_mask is not None else m).reshape(-1)
         rows = flat.nonzero().squeeze(1).to(tokens.device)
         x = self._trunk(tokens, act_id.detach())
         d = x.shape[-1]
         if rows.numel() == 0:
             return x.sum() * float('nan')                                      # F.cross_entropy over zero rows (mean) is NaN
+        xr = x.reshape(-1, d).index_select(0, rows)
+        if GF.linear_ce_supported(xr, self.head.weight):
+            # Linear(D -> V) + cross-entropy as ONE operator: the (rows, V) logits and their gradient never reach HBM (csrc/linear_ce.hip)
+            return self._fused_loss(xr, tokens.reshape(-1).index_select(0, rows), None)
         # the compact rows are laid out as a (t, h, 256) grid for the gather-GEMM (every axis < 1024); the few pad rows re-read row 0
         # and are switched off in the cross-entropy (zero loss, zero gradient)
         r = rows.numel()
@@ -109,6 +115,10 @@ class DynamicsModel(nn.Module):
         xc = x.reshape(-1, d).index_select(0, rows).view(1, gt, gh, 256, d)
         logits = self._head(xc)                                                # (1, gt, gh, 256, V)
         return GF.masked_cross_entropy(logits, tokens.reshape(-1).index_select(0, rows).view(1, gt, gh, 256), valid)
+
+    def _fused_loss(self, xr: Tensor, target: Tensor, valid: Optional[Tensor]) -> Tensor:
+        w = self.head.weight
+        return GF.linear_cross_entropy(xr, w, self.head.bias, self._head_op.pack_fwd(w[:, :, None, None, None]), target, valid)
 
     @staticmethod
     def _compact_grid(r: int):

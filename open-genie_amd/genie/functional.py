@@ -608,6 +608,83 @@ def masked_cross_entropy(logits: Tensor, target: Tensor, mask: Optional[Tensor] 
 
 
 # ------------------------------------------------------------------------------------------------
+# Fused vocabulary head + masked cross-entropy (DynamicsModel.compute_loss): the logits never reach HBM
+# ------------------------------------------------------------------------------------------------
+FUSED_LINEAR_CE = __import__('os').environ.get('GENIE_FUSED_LINEAR_CE', '1') != '0'
+
+
+def linear_ce_supported(h: Tensor, weight: Tensor) -> bool:
+    """May ``linear_cross_entropy`` take (h: (M, D) bf16 rows, weight: (V, D))?  (D in {64, 128, 256, 512}; sizes below 2^31 bytes)"""
+    if not FUSED_LINEAR_CE or h.dim() != 2 or h.dtype != torch.bfloat16 or h.stride(1) != 1 or h.shape[0] < 1:
+        return False
+    return bool(_hip.load_library().genie_linear_ce_supported(h.shape[0], h.shape[1], weight.shape[0], h.stride(0), weight.shape[1]))
+
+
+class _LinearCEFn(torch.autograd.Function):
+    """loss = mean over the rows with valid != 0 of -log softmax(h W^T + b)[target]  -- reference genie/dynamics.py:62 (`self.head`) + :89-97
+    (F.cross_entropy over the gathered rows) as ONE operator (genie_linear_ce_fwd / _bwd, csrc/linear_ce.hip).
+    h: (M, D) bf16; weight: (V, D) fp32 parameter; wpack: its bf16 forward pack (V, D); bias: (V,) fp32 or None."""
+
+    @staticmethod
+    def forward(ctx, h: Tensor, weight: Tensor, bias: Optional[Tensor], wpack: Tensor, target: Tensor, valid: Optional[Tensor]):
+        lib = _hip.load_library()
+        m, d = h.shape
+        v = weight.shape[0]
+        wp = wpack.reshape(v, -1)
+        assert wp.dtype == torch.bfloat16 and wp.is_contiguous() and wp.shape[1] == d
+        tgt = target.reshape(m).to(torch.int64).contiguous()
+        vk = None if valid is None else valid.reshape(m).to(torch.uint8).contiguous()
+        need = any(ctx.needs_input_grad[:3])
+        dev = h.device
+        ws_n = lib.genie_linear_ce_ws_floats(m, d, v, int(need))
+        ws = workspace(ws_n, dev, 'lce')
+        lse = torch.empty(m, dtype=torch.float32, device=dev)
+        row_e = torch.empty((m + 63) // 64 * 64, dtype=torch.float32, device=dev)
+        acc = torch.zeros(1, dtype=torch.float32, device=dev)
+        dh = torch.empty((m, d), dtype=torch.float32, device=dev) if need else None
+        b = None if bias is None else bias.detach()
+        _hip.check(lib.genie_linear_ce_fwd(h.data_ptr(), h.stride(0), m, d, wp.data_ptr(), wp.stride(0), v, _hip.ptr(b), tgt.data_ptr(), _hip.ptr(vk),
+                                           ws.data_ptr(), ws.numel(), lse.data_ptr(), row_e.data_ptr(), acc.data_ptr(), _hip.ptr(dh), _hip.stream_ptr()),
+                   'genie_linear_ce_fwd')
+        count = (vk.sum(dtype=torch.float32) if vk is not None else torch.full((), float(m), device=dev)).reshape(1)
+        ctx.save_for_backward(h, wp, b, tgt, row_e, dh, count)
+        ctx.weight, ctx.bias = weight, bias
+        ctx.lse = lse
+        return (acc / count).reshape(())
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        h, wp, b, tgt, row_e, dh, count = ctx.saved_tensors
+        weight, bias = ctx.weight, ctx.bias
+        lib = _hip.load_library()
+        m, d = h.shape
+        v = wp.shape[0]
+        scale = (g.float().reshape(1) / count).contiguous()
+        need_h, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        need_b = bias is not None and ctx.needs_input_grad[2]
+        dhb = torch.empty((m, d), dtype=torch.bfloat16, device=h.device) if need_h else None
+        dw = db = gw = gb = None
+        if need_w or need_b:
+            if weight.is_leaf and _direct(weight) and (bias is None or (bias.is_leaf and _direct(bias))):
+                gw = _grad_buffer(weight)
+                gb = _grad_buffer(bias) if need_b else None
+            else:
+                gw = dw = torch.zeros((v, d), dtype=torch.float32, device=h.device)
+                gb = db = torch.zeros(v, dtype=torch.float32, device=h.device) if need_b else None
+            assert gw.is_contiguous() and gw.dtype == torch.float32
+        _hip.check(lib.genie_linear_ce_bwd(h.data_ptr(), h.stride(0), m, d, wp.data_ptr(), wp.stride(0), v, _hip.ptr(b), tgt.data_ptr(), row_e.data_ptr(),
+                                           scale.data_ptr(), _hip.ptr(dh) if need_h else None, _hip.ptr(dhb), d, _hip.ptr(gw), _hip.ptr(gb),
+                                           _hip.stream_ptr()), 'genie_linear_ce_bwd')
+        return dhb, dw, db, None, None, None
+
+
+def linear_cross_entropy(h: Tensor, weight: Tensor, bias: Optional[Tensor], wpack: Tensor, target: Tensor, valid: Optional[Tensor] = None) -> Tensor:
+    """mean_{rows with valid} CE(h W^T + b, target) without materialising the (M, V) logits (see ``_LinearCEFn``)."""
+    _hip.require_gpu(h, 'linear_cross_entropy')
+    return _LinearCEFn.apply(h, weight, bias, wpack, target, valid)
+
+
+# ------------------------------------------------------------------------------------------------
 # Embedding lookup whose gradient goes straight into the parameter's gradient buffer
 # ------------------------------------------------------------------------------------------------
 class _EmbeddingFn(torch.autograd.Function):

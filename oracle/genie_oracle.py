@@ -653,6 +653,17 @@ def dynamics_loss(tokens: Tensor, act_id: Tensor, mask: Tensor, sd: SD, desc, fi
     return F.cross_entropy(logits[m].reshape(-1, logits.shape[-1]), tokens[m].reshape(-1))
 
 
+def linear_cross_entropy(h: Tensor, weight: Tensor, bias: Optional[Tensor], target: Tensor, valid: Optional[Tensor] = None) -> Tensor:
+    """The tail of DynamicsModel.compute_loss as one function of the gathered rows: ``self.head`` (dynamics.py:62, nn.Linear built at
+    :32) followed by ``cross_entropy(logits[mask], tokens[mask])`` (dynamics.py:89-97, mean reduction).  h (M, D), weight (V, D),
+    bias (V,) or None, target (M,) int64; `valid` (M,) bool selects the rows that enter the mean (None = all) -- the boolean gather of
+    dynamics.py:92-93 applied to rows that were already gathered."""
+    logits = F.linear(h, weight, bias)
+    if valid is not None:
+        logits, target = logits[valid], target[valid]
+    return F.cross_entropy(logits, target)
+
+
 def maskgit_schedule(steps: int, shape: Sequence[int], which: str = 'linear') -> Tensor:
     """dynamics.py:167-195."""
     n = int(np.prod(shape))

@@ -1,0 +1,110 @@
+"""Times the fused vocabulary head + cross-entropy (csrc/linear_ce.hip) against the materialising path (1x1x1 gather-GEMM + genie_masked_ce
+forward / backward + the two gradient GEMMs) on the BASELINE configs[3] head shape: D = 512, V = 2^18, rows = 0.75 * B * 16 * 8 * 8.
+
+    python scripts/bench_linear_ce.py [--rows 3072,24576] [--reps 5] [--plain 1]
+
+One JSON line per row count: ms of forward (with dh), backward (dW + db + one-hot + dh scale), and the rates against the dense bf16 MFMA
+peak (2.5 PFLOP/s) for (a) the ALGORITHMIC count 6 M V D (what the reference's three products cost) and (b) the EXECUTED count 8 M V D."""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'open-genie_amd')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+from genie import functional as GF        # noqa: E402
+from genie.conv import ConvSpec            # noqa: E402
+
+PEAK = 2.5e15
+
+
+def timed(fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    best = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        torch.cuda.synchronize()
+        best.append(a.elapsed_time(b))
+    best.sort()
+    return best[len(best) // 2]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--rows', default='3072,24576')
+    ap.add_argument('--d', type=int, default=512)
+    ap.add_argument('--v', type=int, default=1 << 18)
+    ap.add_argument('--reps', type=int, default=5)
+    ap.add_argument('--plain', type=int, default=1)
+    args = ap.parse_args()
+    d, v = args.d, args.v
+    torch.manual_seed(0)
+    w = (torch.randn(v, d, device='cuda') * d ** -0.5).requires_grad_(True)
+    b = (torch.randn(v, device='cuda') * 0.1).requires_grad_(True)
+    wp = w.detach().to(torch.bfloat16).contiguous()
+    for m in [int(x) for x in args.rows.split(',')]:
+        h = torch.randn(m, d, device='cuda').to(torch.bfloat16).requires_grad_(True)
+        t = torch.zeros(m, dtype=torch.int64, device='cuda')
+        out = {}
+
+        def fwd():
+            out['loss'] = GF.linear_cross_entropy(h, w, b, wp, t, None)
+
+        def bwd():
+            w.grad = None
+            b.grad = None
+            h.grad = None
+            out['loss'].backward(retain_graph=True)
+
+        f_ms = timed(fwd, args.reps)
+        b_ms = timed(bwd, args.reps)
+        flops = 2.0 * m * v * d
+        rec = {'rows': m, 'D': d, 'V': v, 'fused_fwd_ms': round(f_ms, 3), 'fused_bwd_ms': round(b_ms, 3), 'fused_ms': round(f_ms + b_ms, 3),
+               'fused_fwd_frac_executed': round(2 * flops / (f_ms * 1e-3) / PEAK, 4), 'fused_bwd_frac_executed': round(2 * flops / (b_ms * 1e-3) / PEAK, 4),
+               'fused_frac_algorithmic_6MVD': round(3 * flops / ((f_ms + b_ms) * 1e-3) / PEAK, 4),
+               'fused_frac_executed_8MVD': round(4 * flops / ((f_ms + b_ms) * 1e-3) / PEAK, 4), 'loss': out['loss'].item()}
+        if args.plain and ((m + 255) // 256 * 256) * v < 2 ** 31:      # (the gather-GEMM addresses its destination with 31 bits: 8192 rows at V = 2^18)
+            from genie.dynamics import DynamicsModel
+            op = GF.ConvOp(ConvSpec(d, v, (1, 1, 1)))
+            k = (m + 255) // 256
+            gh = k if k <= 512 else 512
+            gt = (k + gh - 1) // gh
+            rp = gt * gh * 256
+            hp = torch.cat([h.detach(), h.detach().new_zeros(rp - m, d)]).requires_grad_(True)
+            valid = torch.arange(rp, device='cuda') < m
+            tp = torch.zeros(rp, dtype=torch.int64, device='cuda')
+            po = {}
+
+            def pf():
+                xc = hp.view(1, gt, gh, 256, d)
+                y = GF.conv3d(xc.permute(0, 4, 1, 2, 3), w[:, :, None, None, None], b, op).permute(0, 2, 3, 4, 1)
+                po['loss'] = GF.masked_cross_entropy(y, tp.view(1, gt, gh, 256), valid)
+
+            def pb():
+                w.grad = None
+                b.grad = None
+                hp.grad = None
+                po['loss'].backward(retain_graph=True)
+
+            pf_ms = timed(pf, args.reps)
+            pb_ms = timed(pb, args.reps)
+            rec.update({'plain_fwd_ms': round(pf_ms, 3), 'plain_bwd_ms': round(pb_ms, 3), 'plain_ms': round(pf_ms + pb_ms, 3),
+                        'plain_frac_algorithmic_6MVD': round(3 * flops / ((pf_ms + pb_ms) * 1e-3) / PEAK, 4), 'plain_loss': po['loss'].item(),
+                        'speedup': round((pf_ms + pb_ms) / (f_ms + b_ms), 3)})
+            del po, hp
+        print(json.dumps(rec), flush=True)
+        del h, out
+        torch.cuda.empty_cache()
+
+
+if __name__ == '__main__':
+    main()
