@@ -25,6 +25,7 @@
 #include "common.h"
 #include "genie_hip.h"
 #include "attn_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -86,6 +87,28 @@ __device__ __forceinline__ void lce_mfma_v(f32x16_t& c, const bf16x8_t a, const 
 __device__ __forceinline__ void lce_mfma_v0(f32x16_t& c, const bf16x8_t a, const bf16x8_t b) {
     asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b));
 }
+// One step of the first product as ONE asm statement: next = LDS[addr + IMM] (read-ahead), optional s_waitcnt lgkmcnt(W) (W < 0: none),
+// acc (+)= cur x b.  ZERO: C = literal 0 (the first step of each accumulator).
+template <int IMM, int W, bool ZERO>
+__device__ __forceinline__ void lce_step_a(bf16x8_t& next, f32x16_t& acc, const bf16x8_t cur, const bf16x8_t b, uint32_t addr) {
+    if constexpr (ZERO) {
+        if constexpr (W >= 0) asm volatile("ds_read_b128 %0, %4 offset:%5\n\ts_waitcnt lgkmcnt(%6)\n\tv_mfma_f32_32x32x16_bf16 %1, %2, %3, 0" : "=&v"(next), "=&v"(acc) : "v"(cur), "v"(b), "v"(addr), "i"(IMM), "n"(W));
+        else asm volatile("ds_read_b128 %0, %4 offset:%5\n\tv_mfma_f32_32x32x16_bf16 %1, %2, %3, 0" : "=&v"(next), "=&v"(acc) : "v"(cur), "v"(b), "v"(addr), "i"(IMM));
+    } else {
+        if constexpr (W >= 0) asm volatile("ds_read_b128 %0, %4 offset:%5\n\ts_waitcnt lgkmcnt(%6)\n\tv_mfma_f32_32x32x16_bf16 %1, %2, %3, %1" : "=&v"(next), "+&v"(acc) : "v"(cur), "v"(b), "v"(addr), "i"(IMM), "n"(W));
+        else asm volatile("ds_read_b128 %0, %4 offset:%5\n\tv_mfma_f32_32x32x16_bf16 %1, %2, %3, %1" : "=&v"(next), "+&v"(acc) : "v"(cur), "v"(b), "v"(addr), "i"(IMM));
+    }
+}
+template <int W, bool ZERO>
+__device__ __forceinline__ void lce_step_a_tail(f32x16_t& acc, const bf16x8_t cur, const bf16x8_t b) {      // the last RA - 1 steps: nothing left to read ahead
+    if constexpr (ZERO) {
+        if constexpr (W >= 0) asm volatile("s_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(cur), "v"(b), "n"(W));
+        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(cur), "v"(b));
+    } else {
+        if constexpr (W >= 0) asm volatile("s_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+&v"(acc) : "v"(cur), "v"(b), "n"(W));
+        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+&v"(acc) : "v"(cur), "v"(b));
+    }
+}
 template <int IMM>
 __device__ __forceinline__ bf16x8_t lce_read128(uint32_t lds_addr) {      // ds_read_b128 hipcc neither hoists nor waits for: the caller counts lgkmcnt
     bf16x8_t v;
@@ -103,7 +126,7 @@ __device__ __forceinline__ bf16x8_t lce_read128(uint32_t lds_addr) {      // ds_
 //            the softmax VALU work runs in the matrix pipe's shadow instead of between the two products;
 // one extra iteration at t = t_end (zero tile, every row masked) drains the last B.  A row maximum that moves by more than 2^8 (rare after
 // the first tiles) first finishes B(t-1) on its own, rescales O and l, and then runs the common path with P_(t-1) = 0.
-template <int DH, int MODE, bool WITH_ACC>
+template <int DH, int MODE, bool WITH_ACC, int ABL = 0>
 __global__ void __attribute__((amdgpu_waves_per_eu(1, 1))) __launch_bounds__(256) lce_kernel(const LceArgs a) {
     constexpr int KT = 32, ROWB = DH * 2, CPR = DH / 8, TILE = KT * ROWB, KS = DH / 16, DT = DH / 32;
     constexpr int SLABS = TILE / 1024, LPW = SLABS / 4;          // 1-KB LDS-DMA pieces per tile / per wave
@@ -112,11 +135,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(1, 1))) __launch_bounds__(256
     constexpr int VSTEP = NV * 4 * RPS;                          // ... advancing this many rows
     constexpr int STAGE = TILE + 1024;                           // + one 256-B copy of the tile's per-row vector per wave
     constexpr int NK8 = KS < 8 ? KS : 8, ND4 = DT < 4 ? DT : 4;
-    constexpr int GQ = (DT + 3) / 4, NGB = 2 * GQ;               // B: groups of up to four feature tiles per 16-row step
-    constexpr int NGA = KS / 4;                                  // A: groups of four 16-feature steps
-    static_assert(SLABS % 4 == 0 && KS % 4 == 0, "every wave stages the same number of pieces; A groups are whole");
-    static_assert(16 % NGB == 0, "the 16 exponentials of a lane are dealt evenly over the B groups");
-    constexpr int EPG = 16 / NGB;                                // exponentials per B group
+    static_assert(SLABS % 4 == 0, "every wave stages the same number of pieces");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -155,13 +174,18 @@ __global__ void __attribute__((amdgpu_waves_per_eu(1, 1))) __launch_bounds__(256
     }
 
     // staging offsets (see the file header of attention_lean.hip): LDS slot `slot` of row `row` holds source chunk slot ^ key(row)
-    uint32_t st_voff[NV];
+    constexpr int NVR = DH == 512 ? 1 : NV;
+    uint32_t st_voff[NVR];
+    if constexpr (DH == 512) st_voff[0] = (uint32_t)((lane ^ lce_key<CPR>(wave)) * 16);       // row = wave + 4 i: key = (wave << 2) | (i & 3)
+    else {
 #pragma unroll
-    for (int j = 0; j < NV; ++j) {
-        const int idx = (wave + 4 * j) * 64 + lane;
-        const int row = idx / CPR, slot = idx % CPR;
-        st_voff[j] = (uint32_t)((long long)row * a.t_pitch * 2) + (uint32_t)((slot ^ lce_key<CPR>(row)) * 16);
+        for (int j = 0; j < NV; ++j) {
+            const int idx = (wave + 4 * j) * 64 + lane;
+            const int row = idx / CPR, slot = idx % CPR;
+            st_voff[j] = (uint32_t)((long long)row * a.t_pitch * 2) + (uint32_t)((slot ^ lce_key<CPR>(row)) * 16);
+        }
     }
+    const int row_bytes = (int)(a.t_pitch * 2);
     const uint32_t vstep_bytes = (uint32_t)((long long)VSTEP * a.t_pitch * 2);
     const int tile_bytes = (int)(KT * a.t_pitch * 2);
     const int all_bytes = (int)((long long)(a.NT - 1) * a.t_pitch * 2) + DH * 2;          // first byte behind the last row (host: < 2^31)
@@ -173,7 +197,10 @@ __global__ void __attribute__((amdgpu_waves_per_eu(1, 1))) __launch_bounds__(256
         const bf16_t* base = a.T + (long long)t * (tile_bytes / 2);
 #pragma unroll
         for (int i = 0; i < LPW; ++i)
-            lce_dma16(base, left, dst + (wave + 4 * i) * 1024, lce_opaque(st_voff[i % NV]) + (uint32_t)(i / NV) * vstep_bytes);
+            if constexpr (DH == 512) {
+                const int rb = (wave + 4 * i) * row_bytes, l2 = left - rb;
+                lce_dma16((const char*)base + rb, l2 > 0 ? l2 : 0, dst + (wave + 4 * i) * 1024, st_voff[0] ^ (uint32_t)((i & 3) << 4));
+            } else lce_dma16(base, left, dst + (wave + 4 * i) * 1024, st_voff[i % NV] + (uint32_t)(i / NV) * vstep_bytes);
         int vleft = (a.tvec_len - t * KT) * 4;
         vleft = (a.tvec && t < t_end && vleft > 0) ? vleft : 0;
         lce_dma4(a.tvec ? (const void*)(a.tvec + (long long)t * KT) : (const void*)a.T, vleft, dst + TILE + wave * 256, (uint32_t)lane * 4u);
@@ -202,113 +229,163 @@ __global__ void __attribute__((amdgpu_waves_per_eu(1, 1))) __launch_bounds__(256
         v_base1 = smem_off + (uint32_t)(r1 * ROWB + (((c ^ lce_key<CPR>(r1)) & 3) << 4) + (qq & 1) * 8);
         v_key = (uint32_t)((lce_key<CPR>(r0) & 12) << 4);        // (rows r0 and r0 + 8 share key bits 2..3)
     }
-    uint32_t pw_prev[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) pw_prev[e] = 0u;
+    u32x4_t pw_prev[2] = {u32x4_t{0u, 0u, 0u, 0u}, u32x4_t{0u, 0u, 0u, 0u}};      // P of the previous tile, one MFMA operand per 16-row step
 
     auto tile_body = [&](auto slot_c, int t) {
         constexpr int SLOT = decltype(slot_c)::value;
         constexpr int KBASE = SLOT * STAGE, PBASE = ((SLOT + 3) & 3) * STAGE;
+        constexpr int NP = LPW + 1;                              // DMA pieces a wave issues per tile
         const bool live = t < t_end;
-        stage(t + 2, (SLOT + 2) & 3);
+        // With ONE wave per SIMD nothing runs beside this wave but the matrix pipe: whatever is not issued in the shadow of an MFMA is
+        // serial time (ablation, 24576 rows: both products at the pipe's pace, 3.3 of 11.3 ms in the code between them).  So:
+        //   * the LDS-DMA of tile t + 2 is issued piece by piece BETWEEN the steps of the first product (1.5 instructions per MFMA there);
+        //   * the first product starts from literal zeros -- the per-row vector joins in y;
+        //   * y, the row maximum and the rescale decision are computed after the first HB MFMAs of the second product have been issued
+        //     (they do not depend on tile t), the exponentials between the remaining ones.
+        char* dma_dst = smem + ((SLOT + 2) & 3) * STAGE;
+        int dma_left = all_bytes - (t + 2) * tile_bytes;
+        dma_left = (t + 2 < t_end && dma_left > 0) ? dma_left : 0;
+        const bf16_t* dma_base = a.T + (long long)(t + 2) * (tile_bytes / 2);
+        int dma_vleft = (a.tvec_len - (t + 2) * KT) * 4;
+        dma_vleft = (a.tvec && t + 2 < t_end && dma_vleft > 0) ? dma_vleft : 0;
+        auto dma_piece = [&](auto pc) {
+            constexpr int i = decltype(pc)::value;
+            if constexpr (i < LPW && DH == 512) {
+                // one row per piece: the row's byte offset is wave-uniform and moves into the descriptor (base up, bytes left down), the
+                // lane part is st_voff[0] ^ ((i & 3) << 4) -- one persistent register instead of four
+                const int rb = (wave + 4 * i) * row_bytes;
+                const int l2 = dma_left - rb;
+                lce_dma16((const char*)dma_base + rb, l2 > 0 ? l2 : 0, dma_dst + (wave + 4 * i) * 1024, lce_opaque(st_voff[0]) ^ (uint32_t)((i & 3) << 4));
+            } else if constexpr (i < LPW) lce_dma16(dma_base, dma_left, dma_dst + (wave + 4 * i) * 1024, lce_opaque(st_voff[i % NV]) + (uint32_t)(i / NV) * vstep_bytes);
+            else lce_dma4(a.tvec ? (const void*)(a.tvec + (long long)(t + 2) * KT) : (const void*)a.T, dma_vleft, dma_dst + TILE + wave * 256, (uint32_t)lane * 4u);
+        };
 
-        // ---- A(t): S^T[streamed row, stationary row] over the DH features ----
+        // ---- A(t): S^T[streamed row, stationary row] over the DH features, two accumulators over even / odd 16-feature steps ----
         f32x16_t s0, s1;
         {
-            // accumulator input = the tile's per-row vector (MODE 0: bias; MODE 1: -lse + bias of this lane's vocabulary row, -inf in
-            // the drain iteration).  Row r of lane half h is 8 (r >> 2) + 4 h + (r & 3).
-            const float addv = MODE == 1 ? (live ? bv : -INFINITY) : 0.f;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4_t tv = *reinterpret_cast<const f32x4_t*>(smem + KBASE + TILE + wave * 256 + (8 * g + 4 * h) * 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) s0[4 * g + e] = MODE == 1 ? tv[e] + addv : tv[e];
-            }
+            // (opaque: hipcc would otherwise hoist all four stages' offsets out of the tile loop -- 64 registers this kernel does not have)
+            const uint32_t kb_t = lce_opaque(k_base) + KBASE, kk_t = lce_opaque(k_key);
             uint32_t ko[NK8];
 #pragma unroll
-            for (int j = 0; j < NK8; ++j) ko[j] = (lce_opaque(k_base) + KBASE) + ((uint32_t)(32 * j) ^ lce_opaque(k_key));     // (opaque: hipcc would hoist all four stages' offsets out of the tile loop -- 64 registers)
-            bf16x8_t tf[2][4];
-            auto issue_a = [&](auto gc, auto pc) {
-                constexpr int G = decltype(gc)::value, PB = decltype(pc)::value;
-                lce_static_for<0, 4>([&](auto jc) {
-                    constexpr int ks = G * 4 + decltype(jc)::value;
-                    tf[PB][ks & 3] = lce_read128<(ks >> 3) * 256>(ko[ks & 7]);
-                });
-            };
-            issue_a(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
-            lce_static_for<0, NGA>([&](auto gc) {
-                constexpr int G = decltype(gc)::value, PB = G & 1;
-                if constexpr (G + 1 < NGA) {
-                    issue_a(std::integral_constant<int, G + 1>{}, std::integral_constant<int, PB ^ 1>{});
-                    asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
-                } else {
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (G == 0 && j == 1) lce_mfma_v0(s1, tf[PB][j], af[G * 4 + j]);       // (C = literal 0: no zero vector to keep or spill)
-                    else if (j & 1) lce_mfma_v<false>(s1, tf[PB][j], af[G * 4 + j]);
-                    else lce_mfma_v<G == 0>(s0, tf[PB][j], af[G * 4 + j]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
+            for (int j = 0; j < NK8; ++j) ko[j] = kb_t + ((uint32_t)(32 * j) ^ kk_t);
+            // one fragment read per MFMA, issued RA - 1 steps ahead of the MFMA that consumes it
+            constexpr int RA = KS < 6 ? KS : 6;
+            bf16x8_t tf[RA];
+            if constexpr (!(ABL & 4)) lce_static_for<0, RA - 1>([&](auto kc) {
+                constexpr int ks = decltype(kc)::value;
+                tf[ks % RA] = lce_read128<(ks >> 3) * 256>(ko[ks & 7]);
             });
-            // the MFMA results meet the VALU below: hipcc pads nothing behind an asm MFMA (8 passes: 11+ wait states)
-            asm volatile("s_nop 15\n\ts_nop 7" : "+v"(s0), "+v"(s1));
-        }
-        f32x16_t y;
+            if constexpr (ABL & 4) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) y[r] = s0[r] + s1[r];
-
-        // the second product of the PREVIOUS tile; `fill(e)` is called between its MFMAs, 16 / NGB times per group
-        auto prod_b = [&](auto&& fill) {
-            if constexpr (WITH_ACC) {
-                uint32_t vo[ND4][2];
-#pragma unroll
-                for (int dl = 0; dl < ND4; ++dl) {
-                    vo[dl][0] = (lce_opaque(v_base0) + PBASE) + ((uint32_t)(64 * dl) ^ lce_opaque(v_key));
-                    vo[dl][1] = (lce_opaque(v_base1) + PBASE) + ((uint32_t)(64 * dl) ^ lce_opaque(v_key));
+                for (int r = 0; r < 16; ++r) s0[r] = s1[r] = 0.f;
+            }
+            // per step ONE asm statement: the read RA - 1 steps ahead, (on even steps) the wait that retires this step's and the next
+            // step's fragments, the MFMA -- hipcc pads every asm boundary with an s_nop, and with one wave per SIMD every issue slot counts
+            lce_static_for<0, KS>([&](auto kc) {
+                constexpr int ks = decltype(kc)::value, nx = ks + RA - 1;
+                if constexpr (!(ABL & 4)) {
+                    constexpr int left = KS - 1 - ks;                                        // reads issued after this step's own
+                    constexpr int pend = (left < RA - 1 ? left : RA - 1) - ((ks & 1) == 0 && left >= 1 ? 1 : 0);
+                    constexpr int W = (ks & 1) == 0 || RA < 3 ? pend : -1;                   // odd steps were retired by the even step before
+                    f32x16_t& acc = (ks & 1) ? s1 : s0;
+                    if constexpr (nx < KS) lce_step_a<(nx >> 3) * 256, W, ks < 2>(tf[nx % RA], acc, tf[ks % RA], af[ks], ko[nx & 7]);
+                    else lce_step_a_tail<W, ks < 2>(acc, tf[ks % RA], af[ks]);
                 }
-                bf16x4_t vlo[2][ND4], vhi[2][ND4];
-                auto issue_b = [&](auto gc, auto pc) {
-                    constexpr int G = decltype(gc)::value, PB = decltype(pc)::value;
-                    constexpr int IMM = (16 * (G / GQ)) * ROWB + (G % GQ) * 256;
-#pragma unroll
-                    for (int dl = 0; dl < ND4; ++dl) {
-                        vlo[PB][dl] = attn_tr16i<IMM>(vo[dl][0]);
-                        vhi[PB][dl] = attn_tr16i<IMM>(vo[dl][1]);
-                    }
-                };
-                issue_b(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
-                lce_static_for<0, NGB>([&](auto gc) {
-                    constexpr int G = decltype(gc)::value, PB = G & 1;
-                    constexpr int s2 = G / GQ, dq = G % GQ;
-                    if constexpr (G + 1 < NGB) {
-                        issue_b(std::integral_constant<int, G + 1>{}, std::integral_constant<int, PB ^ 1>{});
-                        asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(2 * ND4) : "memory");
-                    } else {
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    u32x4_t pv4;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) pv4[e] = pw_prev[4 * s2 + e];
-                    const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pv4);
-#pragma unroll
-                    for (int dl = 0; dl < ND4; ++dl) {
-                        asm volatile("" : "+v"(vlo[PB][dl]), "+v"(vhi[PB][dl]));
-                        const bf16x8_t vf = __builtin_shufflevector(vlo[PB][dl], vhi[PB][dl], 0, 1, 2, 3, 4, 5, 6, 7);
-                        oacc[dq * 4 + dl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[dq * 4 + dl], 0, 0, 0);
-                    }
-                    lce_static_for<0, EPG>([&](auto ec) { fill(std::integral_constant<int, G * EPG + decltype(ec)::value>{}); });
-                    __builtin_amdgcn_sched_barrier(0);
+                lce_static_for<0, NP>([&](auto pc) {                                         // DMA piece p goes behind step p * KS / NP
+                    if constexpr (decltype(pc)::value * KS / NP == ks) dma_piece(pc);
                 });
+            });
+        }
+
+        // ---- B(t - 1): O^T += T_(t-1)^T P_(t-1)^T.  MFMA i: 16-row step s2 = i / DT, feature tile d = i % DT; its two transposed reads are
+        //      issued RB - 1 MFMAs ahead, even MFMAs wait for their own and the next MFMA's fragments ----
+        constexpr int NB = WITH_ACC && !(ABL & 2) ? 2 * DT : 0, RB = NB < 6 ? (NB > 0 ? NB : 1) : 6;
+        constexpr int HB = NB < 4 ? NB : 4;                      // MFMAs issued before tile t's scores are touched
+        uint32_t vo[ND4][2];
+        bf16x4_t vlo[RB], vhi[RB];
+        auto issue_b = [&](auto ic) {
+            constexpr int I = decltype(ic)::value, s2 = I / DT, d = I % DT;
+            constexpr int IMM = (16 * s2) * ROWB + (d >> 2) * 256;
+            vlo[I % RB] = attn_tr16i<IMM>(vo[d & 3][0]);
+            vhi[I % RB] = attn_tr16i<IMM>(vo[d & 3][1]);
+        };
+        auto mfma_b = [&](auto ic) {
+            constexpr int I = decltype(ic)::value, s2 = I / DT, d = I % DT;
+            if constexpr (I + RB - 1 < NB) issue_b(std::integral_constant<int, I + RB - 1>{});
+            constexpr int left = NB - 1 - I;
+            constexpr int pend = 2 * ((left < RB - 1 ? left : RB - 1) - ((I & 1) == 0 && left >= 1 ? 1 : 0));
+            if constexpr ((I & 1) == 0 || RB < 3) {
+                asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(pend) : "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pw_prev[s2]);
+            asm volatile("" : "+v"(vlo[I % RB]), "+v"(vhi[I % RB]));
+            const bf16x8_t vf = __builtin_shufflevector(vlo[I % RB], vhi[I % RB], 0, 1, 2, 3, 4, 5, 6, 7);
+            oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[d], 0, 0, 0);
+        };
+        // per-row vector of tile t (MODE 0: bias; MODE 1: -lse): row r of lane half h is 8 (r >> 2) + 4 h + (r & 3).  Read FIRST: LDS
+        // returns in order, so the first counted wait of the MFMAs below also covers these four reads
+        f32x4_t tv[4];
+        {
+            const uint32_t tva = lce_opaque(smem_off + (uint32_t)(TILE + 16 * h)) + (uint32_t)KBASE + (uint32_t)wave * 256u;
+            lce_static_for<0, 4>([&](auto gc) { tv[decltype(gc)::value] = __builtin_bit_cast(f32x4_t, lce_read128<32 * decltype(gc)::value>(tva)); });
+        }
+        if constexpr (NB > 0) {
+            const uint32_t vb0_t = lce_opaque(v_base0) + PBASE, vb1_t = lce_opaque(v_base1) + PBASE, vk_t = lce_opaque(v_key);
+#pragma unroll
+            for (int dl = 0; dl < ND4; ++dl) {
+                vo[dl][0] = vb0_t + ((uint32_t)(64 * dl) ^ vk_t);
+                vo[dl][1] = vb1_t + ((uint32_t)(64 * dl) ^ vk_t);
+            }
+            lce_static_for<0, RB - 1>([&](auto ic) { issue_b(ic); });
+            lce_static_for<0, HB>([&](auto ic) { mfma_b(ic); });
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // the rest of the second product with `fill(e)`, e = 0..15, dealt over its MFMAs
+        auto tail_b = [&](auto&& fill) {
+            if constexpr (NB > HB) {
+                constexpr int NT_ = NB - HB;
+                lce_static_for<HB, NB>([&](auto ic) {
+                    constexpr int I = decltype(ic)::value, J = I - HB;
+                    mfma_b(ic);
+                    lce_static_for<0, 16>([&](auto ec) {             // exponential e goes behind tail MFMA e * NT_ / 16
+                        if constexpr (decltype(ec)::value * NT_ / 16 == J) fill(ec);
+                    });
+                });
+                __builtin_amdgcn_sched_barrier(0);
             } else {
                 lce_static_for<0, 16>([&](auto ec) { fill(ec); });
             }
         };
 
+        // the first product's results meet the VALU here: hipcc pads nothing behind an asm MFMA (8 passes: 11+ wait states; with the HB
+        // MFMAs above in between the s_nop is a formality)
+        asm volatile("s_nop 7" : "+v"(s0), "+v"(s1), "+v"(tv[0]), "+v"(tv[1]), "+v"(tv[2]), "+v"(tv[3]));
+        f32x16_t y;
+        {
+            const float addv = MODE == 1 ? (live ? bv : -INFINITY) : 0.f;     // MODE 1: bias of this lane's vocabulary row (-inf in the drain iteration)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) y[r] = (s0[r] + s1[r]) + (MODE == 1 ? tv[r >> 2][r & 3] + addv : tv[r >> 2][r & 3]);
+        }
+
+        float pe[16];
+        float ps0 = 0.f, ps1 = 0.f;
+        u32x4_t pw_new[2];
         float mc = 0.f;
+        auto fill = [&](auto ec) {
+            constexpr int E = decltype(ec)::value;
+            if constexpr (ABL & 1) pe[E] = y[E];
+            else pe[E] = __builtin_amdgcn_exp2f(MODE == 0 ? __builtin_fmaf(y[E], LCE_LOG2E, -mc) : y[E] * LCE_LOG2E);
+            if constexpr (E & 1) {
+                ps1 += pe[E];
+                pw_new[E >> 3][(E >> 1) & 3] = pack_bf16x2(pe[E - 1], pe[E]);
+            } else {
+                ps0 += pe[E];
+            }
+        };
         if constexpr (MODE == 0) {
             const int k0 = t * KT;
             if (k0 + KT > a.NT || !live) {                       // streamed rows past the end (or the drain iteration): these logits do not exist
@@ -324,45 +401,35 @@ __global__ void __attribute__((amdgpu_waves_per_eu(1, 1))) __launch_bounds__(256
             }
             tmax = lce_xmax32(tmax);
             const float m_new = fmaxf(m_run, tmax);
-            // deferred maximum (cdna_hip_programming.md T13): rescale only when some row's maximum moved by more than 2^8 (the first tile does)
+            // deferred maximum (cdna_hip_programming.md T13): rescale only when some row's maximum moved by more than 2^8 (the first tile does).
+            // Everything still at the old scale -- the rest of P_(t-1) T_(t-1) -- goes into O first; the common path then repeats those MFMAs with P = 0.
             if (__builtin_amdgcn_ballot_w64((m_new - m_run) * LCE_LOG2E > 8.f) != 0) {
-                prod_b([](auto) {});                             // everything still at the old scale goes into O first
-#pragma unroll
-                for (int e = 0; e < 8; ++e) pw_prev[e] = 0u;
+                tail_b([](auto) {});
                 const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LCE_LOG2E);
                 l_run *= alpha;
                 if constexpr (WITH_ACC) {
 #pragma unroll
                     for (int d = 0; d < DT; ++d) {               // one accumulator block at a time (the scheduler would otherwise pull all 256
-#pragma unroll                                                   // accumulator registers into VGPRs at once: 200+ spills)
+#pragma unroll                                                   // accumulator registers into VGPRs at once)
                         for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
                 m_run = m_new;
+                pw_prev[0] = pw_prev[1] = u32x4_t{0u, 0u, 0u, 0u};   // the common path below then adds zeros (the fragments it re-reads are finite)
             }
             mc = m_run * LCE_LOG2E;
         }
-        float pe[16];
-        float ps0 = 0.f, ps1 = 0.f;
-        uint32_t pw_new[8];
-        prod_b([&](auto ec) {
-            constexpr int E = decltype(ec)::value;
-            pe[E] = __builtin_amdgcn_exp2f(MODE == 0 ? __builtin_fmaf(y[E], LCE_LOG2E, -mc) : y[E] * LCE_LOG2E);
-            if constexpr (E & 1) {
-                ps1 += pe[E];
-                pw_new[E >> 1] = pack_bf16x2(pe[E - 1], pe[E]);
-            } else {
-                ps0 += pe[E];
-            }
-        });
+        tail_b(fill);
         if constexpr (MODE == 0) l_run += lce_xsum32(ps0 + ps1);
         else l_run += ps0 + ps1;                                 // this lane's half of the column sum; the halves meet in the epilogue
-#pragma unroll
-        for (int e = 0; e < 8; ++e) pw_prev[e] = pw_new[e];
+        pw_prev[0] = pw_new[0];
+        pw_prev[1] = pw_new[1];
 
-        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LPW + 1) : "memory");
-        __builtin_amdgcn_s_barrier();
+        if constexpr (!(ABL & 8)) {
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LPW + 1) : "memory");
+            __builtin_amdgcn_s_barrier();
+        }
         asm volatile("" ::: "memory");
     };
     for (int t = t_begin; t <= t_end; t += 4) {
@@ -561,6 +628,17 @@ template <int DH, int MODE, bool ACC>
 int lce_launch(const LceArgs& a, hipStream_t s) {
     constexpr int LDS = 4 * (32 * DH * 2 + 1024);
     auto k = lce_kernel<DH, MODE, ACC>;
+#ifdef LCE_ABLATE                      // timing probe (wrong results): GENIE_LCE_ABL = bit mask, see lce_kernel's ABL
+    if constexpr (DH == 512 && MODE == 1) {
+        const char* e = getenv("GENIE_LCE_ABL");
+        const int abl = e ? atoi(e) : 0;
+        constexpr int LDSA = 4 * (32 * DH * 2 + 1024);
+#define LCE_ABL_CASE(N) if (abl == N) { auto ka = lce_kernel<DH, MODE, ACC, N>; hipFuncSetAttribute((const void*)ka, hipFuncAttributeMaxDynamicSharedMemorySize, LDSA); \
+            ka<<<dim3((unsigned)(a.n_atiles * a.nsplit)), 256, LDSA, s>>>(a); return GENIE_OK; }
+        LCE_ABL_CASE(1) LCE_ABL_CASE(2) LCE_ABL_CASE(4) LCE_ABL_CASE(6) LCE_ABL_CASE(8) LCE_ABL_CASE(9) LCE_ABL_CASE(3)
+#undef LCE_ABL_CASE
+    }
+#endif
     static bool attr_done = false;                               // per instantiation
     if (!attr_done) {
         const hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
