@@ -233,6 +233,8 @@ def side_kernels(batch: int = 64):
     # (not under the profiler: the probe launches the dominant kernel itself and would mix into its rocprofv3 / PMC averages)
     return {**({} if os.environ.get('GENIE_BENCH_NO_PROBE') else {'power_cap': power_cap_probe(batch)}),
             'st_attention': {'peak_tflops': BF16_MFMA_PEAK_TFLOPS, 'flop_count': 'dense 4 S^2 C per sequence forward, 2.5x that backward',
+                             'causal_skipping': 'none credited and none present: both shapes are SPATIAL attention (non-causal, every key tile is executed), so the dense count '
+                                                'IS the executed count; causal attention here is temporal, T <= 32, on the packed traffic-bound kernels (priced in GB/s, not TFLOP/s)',
                              'best_fwd_mfma_frac': best, 'best_bwd_mfma_frac': best_bwd, 'kernel_family': fam, 'kernels': att},
             'hbm_kernels': {'peak_gbps': 8000.0, 'bytes': 'what the passes of the call move (stated per entry); *_min: the minimal traffic of the operation', 'kernels': hbm}}
 
@@ -256,6 +258,9 @@ def main():
                     help='gradient all-reduce payload: fp32 (exact, default) or bf16 (half the xGMI bytes)')
     ap.add_argument('--async-wgrad', type=int, default=int(os.environ.get('GENIE_ASYNC_WGRAD', 0)),
                     help='1: weight-gradient kernels on a side stream, overlapping the HBM-bound GroupNorm / element-wise passes of backward (conv launches wait for it); 2: unordered; 0: off')
+    ap.add_argument('--no-other-configs', action='store_true', help='skip the configs[2] / configs[3] side measurements (`other_configs`)')
+    ap.add_argument('--lam-batch', type=int, default=16)
+    ap.add_argument('--dyn-batch', type=int, default=32)
     ap.add_argument('--dp-loopback', action='store_true', help='N = 1 only: run the RCCL bucket all-reduces on a single-rank group (side-stream path on one GPU)')
     args = ap.parse_args()
 
@@ -399,8 +404,15 @@ def main():
         if dom is not None:
             d = summ[dom]
             ach = d['flops'] / (d['ms'] * 1e-3) / 1e12
+            ach_x = d.get('flops_exec', d['flops']) / (d['ms'] * 1e-3) / 1e12
             out['roofline'] = {'kernel': dom, 'bound': 'mfma', 'achieved': round(ach, 2), 'peak': BF16_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                                'frac': round(ach / BF16_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
+                               # `achieved` / `frac` price the ALGORITHMIC count (2 M Cout Cin 27 per launch, zero padding included);
+                               # the kernel skips the (frame, dt) pairs whose source frame is time padding (tri_trim_range: 2 of 48 at 16
+                               # frames, 2 of 24 at 8, 3 of 48 causal), so what the matrix pipe EXECUTES is this much less:
+                               'flop_count': 'algorithmic: dense 2*M*Cout*Cin*27 per launch incl. zero time-padding (SURVEY 8d); flops_executed excludes the (frame, dt) pairs the kernel skips',
+                               'flops_algorithmic': d['flops'], 'flops_executed': d.get('flops_exec', d['flops']),
+                               'achieved_executed': round(ach_x, 2), 'frac_executed': round(ach_x / BF16_MFMA_PEAK_TFLOPS, 4),
                                'launches': d['launches'], 'avg_launch_ms': round(d['ms'] / d['launches'], 4),
                                'share_of_step_time': round(d['ms'] / (elapsed * 1e3), 4)}
         if dom is not None and prof_inorder is not None:
@@ -432,7 +444,9 @@ def main():
     # profiles/rNN_summary.json) -- and only if that profile was taken on the same kernel sources and batch; otherwise it is stale and
     # stays null (a silently carried-over number is worse than none).
     # the newest round's summary first: profiles/r04_summary.json, r03_..., ...
-    prof_summary = next((os.path.join(ROOT, 'profiles', f) for f in sorted((f for f in os.listdir(os.path.join(ROOT, 'profiles')) if f.startswith('r') and f.endswith('_summary.json')), reverse=True)), '')
+    import re
+    rounds = {int(mt.group(1)): f for f in os.listdir(os.path.join(ROOT, 'profiles')) for mt in [re.match(r'r(\d+)_summary\.json$', f)] if mt}
+    prof_summary = os.path.join(ROOT, 'profiles', rounds[max(rounds)]) if rounds else ''      # newest round by NUMBER (r10 after r9)
     if 'roofline' in out and prof_summary:
         try:
             ps = json.load(open(prof_summary))
@@ -447,6 +461,23 @@ def main():
                                                     'why': f"profile taken at batch {meta.get('batch')} / kernel sources {meta.get('csrc_sha16')}, this run: batch {B} / {csrc_sha16()}"}
         except Exception:
             pass
+    if world == 1 and not args.no_kernel_events and not os.environ.get('GENIE_BENCH_NO_PROBE') and not args.no_other_configs:
+        # BASELINE configs[2] and [3] at chip-filling batches, one training step each on THIS box (a driver-run record
+        # for them): ms per step, units per second and the kernel family with the largest share, priced like `roofline`.  Side
+        # measurements AFTER the timed region; the headline above is unaffected.
+        try:
+            clips.clear()
+            model.zero_grad(set_to_none=True)
+            torch.cuda.empty_cache()
+            import scripts.bench_models as bm
+            oc = {}
+            for key, fn, b in (('configs[2] LatentAction', bm.bench_lam, args.lam_batch), ('configs[3] DynamicsModel', bm.bench_dyn, args.dyn_batch)):
+                r = bm.run_quiet(fn, b)
+                oc[key] = {'model': r['model'], 'batch': b, 'ms_per_step': r['ms_per_step'], 'units_per_s': r['units_per_s'], 'peak_mem_GB': r['peak_mem_GB'],
+                           'roofline': r.get('roofline'), 'top_kernels': dict(list(r.get('kernels', {}).items())[:4])}
+            out['other_configs'] = oc
+        except Exception as ex:                            # a side measurement must never cost the headline line
+            out['other_configs'] = {'error': f'{type(ex).__name__}: {ex}'}
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline()
     if world > 1 or dist.is_initialized():

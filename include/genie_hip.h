@@ -404,7 +404,9 @@ int genie_attention_fwd(const void* q, const void* k, const void* v, const void*
 /* `out` must be the attention output WITHOUT the residual (o_attn of the forward) when resid is NULL; with resid given,
  * out - resid is used (less accurate).  Self-attention (q == k == v): dq receives dQ + dK + dV.  Otherwise dq gets dQ and
  * dk / dv (addressed by dkv_map, which must not alias across sequences) get dK / dV.  D_ws: fp32 [3][out_tokens][nhead] scratch
- * (ABI 10: D = rowsum(dO * O), then lse * log2 e and -D -- the forms the exp2-domain backward kernels consume). */
+ * (ABI 10: D = rowsum(dO * O), then lse * log2 e and -D -- the forms the exp2-domain backward kernels consume).  ALL THREE planes are
+ * written for EVERY d_head >= 32 and every kernel family (the preprocess kernel does not know which family follows): a caller that still
+ * allocates the ABI <= 9 size [out_tokens][nhead] gets out-of-bounds writes.  d_head 8 / 16 (attention_narrow.hip) use the first plane only. */
 int genie_attention_bwd(const void* q, const void* k, const void* v, const void* out, const void* resid, const void* dO,
                         const float* lse, float* D_ws, void* dq, void* dk, void* dv, int nseq, int nhead, int d_head, int Sq, int Sk,
                         const int64_t* q_map, const int64_t* kv_map, const int64_t* out_map, const int64_t* dkv_map, float scale,

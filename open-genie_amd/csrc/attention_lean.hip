@@ -930,6 +930,8 @@ int genie_attn_lean_bwd_dq(const AttnBwdArgs& a_in, hipStream_t s) {
     int nw = (a.Sq + 31) / 32;
     nw = nw >= 3 ? 4 : nw;
     const int qtiles = (a.Sq + 32 * nw - 1) / (32 * nw);
+    // (attn_block_of forms nseq * nhead * tiles in an int; one- and two-wave blocks on short sequences make MORE tiles than the forward's)
+    GENIE_CHECK_ARG((long long)a.nseq * qtiles * a.nhead < (1ll << 31) - 8 && a.nhead <= 65535, "genie_attention_bwd (dQ): grid too large");
     const int tile = 64 * 64 * 2;
     const int lds = 3 * (a.kv_same ? tile : 2 * tile);
     const dim3 grid = lean_grid(a.nseq, a.nhead, qtiles, &a.xcd_swizzle);
@@ -949,6 +951,7 @@ int genie_attn_lean_bwd_dkv(const AttnBwdArgs& a_in, hipStream_t s) {
     int nw = (a.Sk + 31) / 32;
     nw = nw >= 3 ? 4 : nw;
     const int ktiles = (a.Sk + 32 * nw - 1) / (32 * nw);
+    GENIE_CHECK_ARG((long long)a.nseq * ktiles * a.nhead < (1ll << 31) - 8 && a.nhead <= 65535, "genie_attention_bwd (dK / dV): grid too large");
     const int tile = 64 * 64 * 2;
     const int lds = 3 * (2 * tile + 512);
     const dim3 grid = lean_grid(a.nseq, a.nhead, ktiles, &a.xcd_swizzle);

@@ -41,21 +41,24 @@ class LaunchProfiler:
         ev.record(torch.cuda.current_stream())
         return ev
 
-    def end(self, variant: str, label: str, flops: float, start, bytes_: float = 0.0) -> None:
-        """`bytes_`: algorithmic HBM bytes of the launch (traffic-bound kernels: attention on short sequences); 0 = priced by `flops` alone."""
+    def end(self, variant: str, label: str, flops: float, start, bytes_: float = 0.0, flops_exec: Optional[float] = None) -> None:
+        """`flops`: the ALGORITHMIC (dense) count of the launch, 2 M Cout Cin taps -- SURVEY.md 8(d)'s formula, zero padding included.
+        `flops_exec`: what the kernel actually issues -- the kw-triple kernels skip the (frame, dt) pairs whose source frame is time
+        padding (tri_trim_range): 2 of 48 at 16 frames, 3 of 48 for a causal conv (None = the same as `flops`).
+        `bytes_`: algorithmic HBM bytes of the launch (traffic-bound kernels: attention on short sequences); 0 = priced by `flops` alone."""
         ev = torch.cuda.Event(enable_timing=True)
         ev.record(torch.cuda.current_stream())
-        self.records.append((variant, label, flops, start, ev, bytes_))
+        self.records.append((variant, label, flops, start, ev, bytes_, flops if flops_exec is None else flops_exec))
 
     def summary(self):
         torch.cuda.synchronize()
         out = {}
-        for variant, label, flops, s, e, nbytes in self.records:
+        for variant, label, flops, s, e, nbytes, fexec in self.records:
             ms = s.elapsed_time(e)
-            v = out.setdefault(variant, {'launches': 0, 'ms': 0.0, 'flops': 0.0, 'bytes': 0.0, 'by_label': {}})
-            v['launches'] += 1; v['ms'] += ms; v['flops'] += flops; v['bytes'] += nbytes
-            b = v['by_label'].setdefault(label, {'launches': 0, 'ms': 0.0, 'flops': 0.0, 'bytes': 0.0})
-            b['launches'] += 1; b['ms'] += ms; b['flops'] += flops; b['bytes'] += nbytes
+            v = out.setdefault(variant, {'launches': 0, 'ms': 0.0, 'flops': 0.0, 'bytes': 0.0, 'flops_exec': 0.0, 'by_label': {}})
+            v['launches'] += 1; v['ms'] += ms; v['flops'] += flops; v['bytes'] += nbytes; v['flops_exec'] += fexec
+            b = v['by_label'].setdefault(label, {'launches': 0, 'ms': 0.0, 'flops': 0.0, 'bytes': 0.0, 'flops_exec': 0.0})
+            b['launches'] += 1; b['ms'] += ms; b['flops'] += flops; b['bytes'] += nbytes; b['flops_exec'] += fexec
         return out
 
 
@@ -206,7 +209,36 @@ def tri_schedule(key, taps, hs: int, ws: int, cs: int):
     rows = tri_rows(taps, hs, ws, cs)
     out = None if rows is None else (torch.tensor(rows, dtype=torch.int32).cuda(), len(rows))
     _tri_cache[ck] = out
+    _tri_meta[ck] = None if rows is None else (rows[0][6], rows[0][7], len(rows))      # (rows per dt, smallest dt, rows): what tri_trim_range reads
     return out
+
+
+_tri_meta = {}
+
+
+def tri_executed_fraction(meta, frames: int, hw: int, rows_total: int, bm: int) -> float:
+    """Share of a kw-triple launch's step-table rows that its row tiles actually execute -- the host restatement of tri_trim_range
+    (csrc/conv_igemm3.hip): a tile of `bm` output rows that lies inside ONE frame t skips the table rows whose source frame t + dt is
+    time padding.  meta = (rows per dt, smallest dt, table rows) of the schedule (rows per dt 0: nothing is skipped)."""
+    if meta is None or meta[0] <= 0 or frames <= 0:
+        return 1.0
+    rpd, dmin, nrows = meta
+    ndt = nrows // rpd
+    done = total = 0
+    per = frames * hw                                    # the pattern repeats per sample when a sample is whole tiles
+    span = per if per % bm == 0 else rows_total
+    for m0 in range(0, span, bm):
+        last = min(m0 + bm - 1, rows_total - 1)
+        f0, f1 = m0 // hw, last // hw
+        lo, hi = max(0, -(f0 % frames) - dmin), min(ndt, frames - (f0 % frames) - dmin)
+        done += (hi - lo) if (f0 == f1 and hi > lo) else ndt
+        total += ndt
+    return done / total if total else 1.0
+
+
+def _tri_bm_of_last_launch() -> int:
+    """Row-tile height of the kernel genie_conv_igemm just launched (VARIANT_NAMES: 4 = the 128-row kw-triple kernel, the others 256)."""
+    return 128 if _hip.load_library().genie_last_conv_variant() == 4 else 256
 
 
 def _fwd_tap_list(spec: ConvSpec):
@@ -535,8 +567,12 @@ def conv_forward(x: Tensor, wpack: Tensor, bias: Optional[Tensor], spec: ConvSpe
         gn_sums.append(sums)
     if t0 is not None:
         flops = 2.0 * n * to * ho * wo * spec.cout * spec.cin * spec.ntaps
+        fexec = flops
+        if d.n_tri_steps > 0:
+            meta = _tri_meta.get((torch.cuda.current_device(), ('fwd', spec), h, w, pitch_of(x)))
+            fexec = flops * tri_executed_fraction(meta, to, ho * wo, n * to * ho * wo, _tri_bm_of_last_launch())
         PROFILER.end(_variant('fwd', spec, spec.cout if spec.shuffle is not None else spec.cout, bool(d.small_c)),
-                     f'fwd {spec.cin}->{spec.cout} k{spec.kernel} s{spec.stride} @{(t, h, w)}', flops, t0)
+                     f'fwd {spec.cin}->{spec.cout} k{spec.kernel} s{spec.stride} @{(t, h, w)}', flops, t0, flops_exec=fexec)
     return out
 
 
@@ -586,6 +622,7 @@ def conv_dgrad(dy: Tensor, wpack_bwd: Tensor, spec: ConvSpec, in_size: Triple, r
     tri_ok = (TRI_BM >= 0 and st == (1, 1, 1) and spec.shuffle is None and tuple(dy.shape[2:]) == (t, h, w) and pitch_of(dy) % 64 == 0
               and spec.kernel[2] == 3)
     t0 = PROFILER.begin() if PROFILER is not None and (tri_ok or not PROFILER.only_triple) else None
+    exec_frac = 1.0
     for rt in range(st[0]):
         for rh in range(st[1]):
             for rw in range(st[2]):
@@ -635,11 +672,15 @@ def conv_dgrad(dy: Tensor, wpack_bwd: Tensor, spec: ConvSpec, in_size: Triple, r
                 _hip.check(lib.genie_conv_igemm(C.byref(d), _hip.stream_ptr()), 'genie_conv_igemm(dgrad)')
                 if want_gnb:
                     gnb.fused = bool(lib.genie_last_conv_gn_fused() & 2)
+                if t0 is not None and d.n_tri_steps > 0:
+                    exec_frac = tri_executed_fraction(_tri_meta.get((torch.cuda.current_device(), ('dgrad', spec), h, w, pitch_of(dy))), t, h * w, n * t * h * w,
+                                                      _tri_bm_of_last_launch())
                 first = False
     if t0 is not None:
         to, ho, wo = spec.out_size((t, h, w))
         flops = 2.0 * n * to * ho * wo * spec.cout * spec.cin * spec.ntaps
-        PROFILER.end(_variant('dgrad', spec, spec.cin, False), f'dgrad {spec.cin}->{spec.cout} k{spec.kernel} s{spec.stride} @{(t, h, w)}', flops, t0)
+        PROFILER.end(_variant('dgrad', spec, spec.cin, False), f'dgrad {spec.cin}->{spec.cout} k{spec.kernel} s{spec.stride} @{(t, h, w)}', flops, t0,
+                     flops_exec=flops * exec_frac)
     return dx
 
 

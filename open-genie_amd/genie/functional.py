@@ -643,9 +643,16 @@ class _LinearCEFn(torch.autograd.Function):
         acc = torch.zeros(1, dtype=torch.float32, device=dev)
         dh = torch.empty((m, d), dtype=torch.float32, device=dev) if need else None
         b = None if bias is None else bias.detach()
+        prof = _conv.PROFILER if _conv.PROFILER is not None and not _conv.PROFILER.only_triple else None
+        t0 = prof.begin() if prof is not None else None
         _hip.check(lib.genie_linear_ce_fwd(h.data_ptr(), h.stride(0), m, d, wp.data_ptr(), wp.stride(0), v, _hip.ptr(b), tgt.data_ptr(), _hip.ptr(vk),
                                            ws.data_ptr(), ws.numel(), lse.data_ptr(), row_e.data_ptr(), acc.data_ptr(), _hip.ptr(dh), _hip.stream_ptr()),
                    'genie_linear_ce_fwd')
+        if prof is not None:
+            # algorithmic = the reference's products this launch replaces (logits, and d loss / d h when a gradient is wanted): 2 M V D each;
+            # executed = the same here (the forward sweep computes S and, with a gradient, softmax(S) W)
+            fl = 2.0 * m * v * d * (2 if need else 1)
+            prof.end('linear_ce[mfma]', f'linear_ce fwd{"+dh" if need else ""} rows={m} D={d} V={v}', fl, t0, flops_exec=fl)
         count = (vk.sum(dtype=torch.float32) if vk is not None else torch.full((), float(m), device=dev)).reshape(1)
         ctx.save_for_backward(h, wp, b, tgt, row_e, dh, count)
         ctx.weight, ctx.bias = weight, bias
@@ -672,9 +679,14 @@ class _LinearCEFn(torch.autograd.Function):
                 gw = dw = torch.zeros((v, d), dtype=torch.float32, device=h.device)
                 gb = db = torch.zeros(v, dtype=torch.float32, device=h.device) if need_b else None
             assert gw.is_contiguous() and gw.dtype == torch.float32
+        prof = _conv.PROFILER if _conv.PROFILER is not None and not _conv.PROFILER.only_triple else None
+        t0 = prof.begin() if prof is not None else None
         _hip.check(lib.genie_linear_ce_bwd(h.data_ptr(), h.stride(0), m, d, wp.data_ptr(), wp.stride(0), v, _hip.ptr(b), tgt.data_ptr(), row_e.data_ptr(),
                                            scale.data_ptr(), _hip.ptr(dh) if need_h else None, _hip.ptr(dhb), d, _hip.ptr(gw), _hip.ptr(gb),
                                            _hip.stream_ptr()), 'genie_linear_ce_bwd')
+        if prof is not None and gw is not None:
+            # algorithmic: d loss / d W = one product of the reference (2 M V D); executed: the scores are recomputed (4 M V D)
+            prof.end('linear_ce[mfma]', f'linear_ce bwd dW rows={m} D={d} V={v}', 2.0 * m * v * d, t0, flops_exec=4.0 * m * v * d)
         return dhb, dw, db, None, None, None
 
 

@@ -80,7 +80,9 @@ class GroupedConv3d(nn.Module):
         self.spec = ConvSpec(ci, co, spec.kernel, spec.stride, spec.dilation, spec.pad_front, spec.pad_back, None)
         self.ops = [GF.ConvOp(self.spec) for _ in range(groups)]
 
-    def forward(self, inp: Tensor) -> Tensor:
+    def forward(self, inp: Tensor, resid: Optional[Tensor] = None) -> Tensor:
+        """`resid` (output-shaped, optional) is added to the result -- the same call signature as Conv3d.forward, so that callers which hand a
+        residual to `.conv3d` (VideoResidualBlock's tail) work with either."""
         inp = to_cl(inp)
         ci, co = self.spec.cin, self.spec.cout
         outs = []
@@ -89,7 +91,8 @@ class GroupedConv3d(nn.Module):
             if ci % 8:
                 xg = xg.clone(memory_format=torch.contiguous_format)
             outs.append(GF.conv3d(xg, self.weight[g * co:(g + 1) * co], None if self.bias is None else self.bias[g * co:(g + 1) * co], op))
-        return to_cl(torch.cat(outs, dim=1))
+        out = to_cl(torch.cat(outs, dim=1))
+        return out if resid is None else to_cl(out + to_cl(resid))
 
     def extra_repr(self) -> str:
         return f'{self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, groups={self.groups}, stride={self.spec.stride}'
@@ -168,14 +171,23 @@ class CausalConv3d(nn.Module):
         # negative amount, video.py:154-164, 189)
         self.time_crop = causal_time_crop(kernel_size, stride, dilation)
 
-    def forward(self, inp: Tensor) -> Tensor:
+    def forward(self, inp: Tensor, resid: Optional[Tensor] = None) -> Tensor:
+        """`resid` (output-shaped, optional): added in the conv's epilogue.  Callers that want the fused add MUST come through here and not
+        through `.conv3d`: the time crop and the non-zero pad modes live in this method (VideoResidualBlock called `.conv3d`
+        directly and ran reflect / replicate / circular convs unpadded)."""
         if self.time_crop:
             if inp.shape[2] <= self.time_crop:
                 raise ValueError(f'CausalConv3d: {inp.shape[2]} frames, the causal padding of this layer removes {self.time_crop}')
             inp = to_cl(inp)[:, :, self.time_crop:].contiguous(memory_format=torch.channels_last_3d)     # a dense CL copy of the kept frames
         if self._pads is not None:
             inp = torch.nn.functional.pad(to_cl(inp), self._pads, mode=self.pad_mode)
-        return self.conv3d(inp)
+        return self.conv3d(inp) if resid is None else self.conv3d(inp, resid=resid)
+
+    @property
+    def plain(self) -> bool:
+        """Is this layer exactly its inner dense Conv3d (zero padding as a gather predicate, no crop, no groups)?  Only then may a caller
+        unwrap `.conv3d` into a fused node."""
+        return self._pads is None and not self.time_crop and isinstance(self.conv3d, Conv3d)
 
     @property
     def inp_dim(self) -> int:
@@ -318,7 +330,10 @@ class VideoResidualBlock(nn.Module):
 
     def forward(self, inp: Tensor) -> Tensor:
         inp = to_cl(inp)
-        if self.use_norm and self.act_code == 1 and isinstance(self.res[0], nn.Identity) and isinstance(self.main[3], nn.Identity):
+        convs = (self.main[2], self.main[6], self.res[1])
+        # the fused node takes the inner dense convs: only when every CausalConv3d IS its inner conv (no F.pad mode, no crop, no groups)
+        fusable = all(m.plain if isinstance(m, CausalConv3d) else isinstance(m, Conv3d) for m in convs)
+        if fusable and self.use_norm and self.act_code == 1 and isinstance(self.res[0], nn.Identity) and isinstance(self.main[3], nn.Identity):
             unwrap = lambda m: m.conv3d if isinstance(m, CausalConv3d) else m
             out = GF.residual_block(inp, self.main[0], unwrap(self.main[2]), self.main[4], unwrap(self.main[6]), unwrap(self.res[1]))
             if out is not None:
@@ -327,10 +342,7 @@ class VideoResidualBlock(nn.Module):
         h = self.main[2](self._norm_act(inp, self.main[0], self.main[1]))
         h = self.main[3](h)
         h = self._norm_act(h, self.main[4], self.main[5])
-        last = self.main[6]
-        if isinstance(last, CausalConv3d):
-            return last.conv3d(h, resid=res)
-        return last(h, resid=res)
+        return self.main[6](h, resid=res)                  # Conv3d / CausalConv3d / (inside it) GroupedConv3d all take `resid`
 
     @property
     def inp_dim(self) -> int:

@@ -9,7 +9,9 @@ resident in HBM.  Each line also carries
   cpu_baseline -- (`--cpu-baseline`, configs[2] / [3]) the same training step on the host cores, ONE step after one warm-up: the reference's own
                   modules where /root/reference exists and the model can be built from them (kind "reference"), else the oracle (kind "port")
 
-  python scripts/bench_models.py [lam] [dyn] [repr] [genie4] [smallbatch] [--cpu-baseline]
+  python scripts/bench_models.py [lam] [dyn] [repr] [genie4] [smallbatch] [--cpu-baseline] [--lam-batch=16] [--dyn-batch=32]
+Batches (round 5): LatentAction 16 clips, DynamicsModel 32 token grids per step -- chip-filling; rounds 1-4 ran 2 / 4 (the vocabulary head's
+logits were materialised then: 0.5 GB per grid and 2^31 elements at most, i.e. 8 grids).
 (`smallbatch`: the tokenizer step at 4 / 8 clips and the LatentAction step, eager launches vs one hipGraph replay)
 The per-kernel rocprofv3 tables of the same runs: scripts/profile_models.sh -> profiles/rNN_models_*_kernel_stats.csv."""
 import json
@@ -29,7 +31,7 @@ from genie.trainer import ParamArena
 PEAK, PEAK_HBM = 2500.0, 8000.0
 
 
-def run(name, model, step_fn, units, steps=4, warm=2, cpu=None):
+def run(name, model, step_fn, units, steps=4, warm=2, cpu=None, quiet=False):
     arena = ParamArena(model)
     arena.attach_weight_packs(model)
     for _ in range(warm):
@@ -63,6 +65,9 @@ def run(name, model, step_fn, units, steps=4, warm=2, cpu=None):
             bound, ach, peak, unit = price(v)
             out['kernels'][k] = {'launches_per_step': v['launches'] // steps, 'ms_per_step': round(v['ms'] / steps, 3), 'share_of_step_time': round(v['ms'] / steps / ms, 4),
                                  'bound': bound, 'achieved': round(ach, 1) if ach is not None else None, 'unit': unit, 'frac': round(ach / peak, 4) if ach is not None else None}
+            if bound == 'mfma' and v['ms'] > 0 and abs(v.get('flops_exec', v['flops']) - v['flops']) > 1e-6 * v['flops']:
+                # executed FLOPs differ from the algorithmic count: zero-frame skipping in the kw-triple convs (fewer), score recomputation in the fused head (more)
+                out['kernels'][k]['frac_executed'] = round(v['flops_exec'] / (v['ms'] * 1e-3) / 1e12 / peak, 4)
         # `roofline` = the kernel family with the largest share of the step, attention included (configs[2] / [4] are
         # attention-dominated; round 3 reported a conv variant with 8-12 % of the step there)
         dom = max(summ, key=lambda k: summ[k]['ms'])
@@ -70,13 +75,15 @@ def run(name, model, step_fn, units, steps=4, warm=2, cpu=None):
         bound, ach, peak, unit = price(d)
         timed = sum(v['ms'] for v in summ.values()) / steps
         out['roofline'] = {'kernel': dom, 'bound': bound, 'achieved': round(ach, 1), 'peak': peak, 'unit': unit, 'frac': round(ach / peak, 4),
+                           **({'frac_executed': out['kernels'][dom]['frac_executed']} if 'frac_executed' in out['kernels'][dom] else {}),
                            'launches_per_step': d['launches'] // steps, 'share_of_step_time': round(d['ms'] / steps / ms, 4),
                            'timed_kernels_share_of_step_time': round(timed / ms, 4),
                            'note': 'HIP events around every conv / GEMM / attention launch of the step (attention: dense 4 S Sk C forward, 2.5 x that backward; '
                                    '[hbm] families priced by their tensor passes); GroupNorm, LFQ and element-wise kernels are in the rocprofv3 table of the same run'}
     if cpu is not None:
         out['cpu_baseline'] = cpu()
-    print(json.dumps(out), flush=True)
+    if not quiet:
+        print(json.dumps(out), flush=True)
     del arena
     torch.cuda.empty_cache(); torch.cuda.reset_peak_memory_stats()
     return out
@@ -107,48 +114,62 @@ def cpu_step(build, units, what, build_ref=None):
     return go
 
 
+def bench_lam(B, want_cpu=False, quiet=False, steps=4):
+    """BASELINE configs[2]: LatentAction (R-lam, n_embd 256, 8-action codebook) training on B clips of 16x64x64."""
+    lam = LatentAction(LATENT_ACT_ENC, LATENT_ACT_DEC, d_codebook=8, inp_channels=3, inp_shape=(64, 64), n_embd=256).cuda().train()
+    v = torch.randn(B, 3, 16, 64, 64, device='cuda')
+    def lam_cpu():
+        from oracle import genie_oracle as O
+        sd = {k: (t.detach().float().cpu().clone().requires_grad_(t.is_floating_point() and 'freq' not in k)) for k, t in lam.state_dict().items()}
+        x = torch.randn(1, 3, 16, 64, 64)
+        return lambda: O.latent_action_forward(x, sd, LATENT_ACT_ENC, LATENT_ACT_DEC, 8, training=True)[1].backward()
+    return run(f'LatentAction (configs[2]: R-lam, n_embd 256, 16x64x64, B={B}) [frames/s]', lam, lambda: lam(v)[1], B * 16, steps=steps,
+               cpu=cpu_step(lam_cpu, 16, 'video-frames/sec (one 16x64x64 clip)') if want_cpu else None, quiet=quiet)
+
+
+def bench_dyn(B, want_cpu=False, quiet=False, steps=4):
+    """BASELINE configs[3]: DynamicsModel (8 x ST(8x64), V = 2^18) MaskGIT training step on B (16, 8, 8) token grids, mask rate 0.75."""
+    desc = (('space-time_attn', {'n_rep': 8, 'n_head': 8, 'd_head': 64}),)
+    dyn = DynamicsModel(desc, tok_vocab=2 ** 18, act_vocab=8, embed_dim=512).cuda().train()
+    tok = torch.randint(0, 2 ** 18, (B, 16, 8, 8), device='cuda'); act = torch.randint(0, 8, (B, 16), device='cuda')
+    g = torch.Generator().manual_seed(1)
+    mask = (torch.rand(B, 16, 8, 8, generator=g) < 0.75)
+    def dyn_cpu():
+        from oracle import genie_oracle as O
+        sd = {k: (t.detach().float().cpu().clone().requires_grad_(t.is_floating_point() and 'freq' not in k)) for k, t in dyn.state_dict().items()}
+        tk, ac, mk = tok[:2].cpu(), act[:2].cpu(), mask[:2]
+        return lambda: O.dynamics_loss(tk, ac, mk, sd, desc).backward()
+    def dyn_ref():
+        # the reference's own DynamicsModel (genie/dynamics.py:14-99) with our weights; its compute_loss draws its own mask (same rate on average)
+        from oracle.ref_import import import_reference
+        ref = import_reference()
+        rm = ref.DynamicsModel(desc, tok_vocab=2 ** 18, act_vocab=8, embed_dim=512)
+        rm.load_state_dict({k: t.detach().float().cpu() for k, t in dyn.state_dict().items()}, strict=False)
+        tk, ac = tok[:2].cpu(), act[:2].cpu()
+        return lambda: rm.compute_loss(tk, ac).backward()
+    return run(f'DynamicsModel (configs[3]: 8 x ST(8x64), V=2^18, (16,8,8) tokens, B={B}) [latent frames/s]', dyn,
+               lambda: dyn.compute_loss(tok, act, mask=mask), B * 16, steps=steps,
+               cpu=cpu_step(dyn_cpu, 2 * 16, 'latent frames/sec (two (16,8,8) token grids)', build_ref=dyn_ref) if want_cpu else None, quiet=quiet)
+
+
+def run_quiet(fn, batch):
+    """bench.py's entry: one of bench_lam / bench_dyn without the JSON print, fewer steps."""
+    torch.manual_seed(0)
+    return fn(batch, False, quiet=True, steps=3)
+
+
 def main():
     torch.manual_seed(0)
     res = []
     argv = [a for a in sys.argv[1:] if not a.startswith('--')]
     want_cpu = '--cpu-baseline' in sys.argv
+    opt = {a.split('=')[0]: int(a.split('=')[1]) for a in sys.argv[1:] if a.startswith('--') and '=' in a}
+    lam_batch, dyn_batch = opt.get('--lam-batch', 16), opt.get('--dyn-batch', 32)
     which = argv or ['lam', 'dyn', 'repr']
     if 'lam' in which:
-        B = 2
-        lam = LatentAction(LATENT_ACT_ENC, LATENT_ACT_DEC, d_codebook=8, inp_channels=3, inp_shape=(64, 64), n_embd=256).cuda().train()
-        v = torch.randn(B, 3, 16, 64, 64, device='cuda')
-        def lam_cpu():
-            from oracle import genie_oracle as O
-            sd = {k: (t.detach().float().cpu().clone().requires_grad_(t.is_floating_point() and 'freq' not in k)) for k, t in lam.state_dict().items()}
-            x = torch.randn(1, 3, 16, 64, 64)
-            return lambda: O.latent_action_forward(x, sd, LATENT_ACT_ENC, LATENT_ACT_DEC, 8, training=True)[1].backward()
-        res.append(run(f'LatentAction (configs[2]: R-lam, n_embd 256, 16x64x64, B={B}) [frames/s]', lam, lambda: lam(v)[1], B * 16,
-                       cpu=cpu_step(lam_cpu, 16, 'video-frames/sec (one 16x64x64 clip)') if want_cpu else None))
-        del lam
+        res.append(bench_lam(lam_batch, want_cpu))
     if 'dyn' in which:
-        B = 4
-        desc = (('space-time_attn', {'n_rep': 8, 'n_head': 8, 'd_head': 64}),)
-        dyn = DynamicsModel(desc, tok_vocab=2 ** 18, act_vocab=8, embed_dim=512).cuda().train()
-        tok = torch.randint(0, 2 ** 18, (B, 16, 8, 8), device='cuda'); act = torch.randint(0, 8, (B, 16), device='cuda')
-        g = torch.Generator().manual_seed(1)
-        mask = (torch.rand(B, 16, 8, 8, generator=g) < 0.75)
-        def dyn_cpu():
-            from oracle import genie_oracle as O
-            sd = {k: (t.detach().float().cpu().clone().requires_grad_(t.is_floating_point() and 'freq' not in k)) for k, t in dyn.state_dict().items()}
-            tk, ac, mk = tok[:2].cpu(), act[:2].cpu(), mask[:2]
-            return lambda: O.dynamics_loss(tk, ac, mk, sd, desc).backward()
-        def dyn_ref():
-            # the reference's own DynamicsModel (genie/dynamics.py:14-99) with our weights; its compute_loss draws its own mask (same rate on average)
-            from oracle.ref_import import import_reference
-            ref = import_reference()
-            rm = ref.DynamicsModel(desc, tok_vocab=2 ** 18, act_vocab=8, embed_dim=512)
-            rm.load_state_dict({k: t.detach().float().cpu() for k, t in dyn.state_dict().items()}, strict=False)
-            tk, ac = tok[:2].cpu(), act[:2].cpu()
-            return lambda: rm.compute_loss(tk, ac).backward()
-        res.append(run(f'DynamicsModel (configs[3]: 8 x ST(8x64), V=2^18, (16,8,8) tokens, B={B}) [latent frames/s]', dyn,
-                       lambda: dyn.compute_loss(tok, act, mask=mask), B * 16,
-                       cpu=cpu_step(dyn_cpu, 2 * 16, 'latent frames/sec (two (16,8,8) token grids)', build_ref=dyn_ref) if want_cpu else None))
-        del dyn
+        res.append(bench_dyn(dyn_batch, want_cpu))
     if 'repr' in which:
         B = 2
         tokz = VideoTokenizer(REPR_TOK_ENC, REPR_TOK_DEC, d_codebook=10, gan_loss_weight=0., perc_loss_weight=0.).cuda().train()

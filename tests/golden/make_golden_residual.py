@@ -32,6 +32,11 @@ def main():
         'relu': dict(in_channels=16, out_channels=32, act_fn='relu'),
         'gelu_groups2': dict(in_channels=16, out_channels=16, num_groups=2, act_fn='gelu'),
         'silu_groups2_down': dict(in_channels=16, out_channels=32, num_groups=2, downsample=(1, 2)),
+        # causal convs with the non-zero F.pad modes (video.py:560-566 `partial(CausalConv3d, pad_mode=pad_mode)`, :160-164 F.pad): round 4's
+        # block ran these convs unpadded -- appended AFTER the cases above so that their random draws are unchanged
+        'causal_reflect': dict(in_channels=16, out_channels=32, use_causal=True, pad_mode='reflect'),
+        'causal_replicate_same_width': dict(in_channels=16, out_channels=16, use_causal=True, pad_mode='replicate'),
+        'causal_circular_leaky': dict(in_channels=16, out_channels=32, use_causal=True, pad_mode='circular', act_fn='leaky'),
     }
     for name, kw in cases.items():
         m = V.VideoResidualBlock(**kw)

@@ -113,7 +113,8 @@ def test_residual_block_options_vs_reference():
     downsample -- outputs AND gradients of the real reference modules (tests/golden/make_golden_residual.py)."""
     from genie.module.video import VideoResidualBlock
     g = load('residual_options.pt')
-    assert set(g) >= {'leaky_down', 'leaky_causal_groups2_down', 'relu', 'gelu_groups2', 'silu_groups2_down'}
+    assert set(g) >= {'leaky_down', 'leaky_causal_groups2_down', 'relu', 'gelu_groups2', 'silu_groups2_down',
+                      'causal_reflect', 'causal_replicate_same_width', 'causal_circular_leaky'}      # (the last three: F.pad modes inside the block, ADVICE r4)
     for name, e in g.items():
         m = VideoResidualBlock(**e['kw'])
         assert sorted(m.state_dict()) == sorted(e['sd']), (name, sorted(m.state_dict()), sorted(e['sd']))

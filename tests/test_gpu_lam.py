@@ -167,3 +167,45 @@ def test_latent_action_configs2_size_parity():
     the K = 262144 projection, the quantised-action condition of the decoder -- the launches scripts/bench_models.py times."""
     from genie import LATENT_ACT_DEC, LATENT_ACT_ENC
     check_lam('latent_action_configs2', LATENT_ACT_ENC, LATENT_ACT_DEC, 8, 256, (1, 16, 64, 64), 5, tol_fp32=0.03)
+
+
+def test_latent_action_vs_reference_pieces_fixture():
+    """The HIP LatentAction against outputs AND gradients of the reference's own pieces run through action.py:111-176
+    (tests/golden/lam_pieces.pt, tests/golden/make_golden_lam.py): same state_dict keys, every stage output, the action ids wherever the
+    pre-quantisation value is not within bf16 noise of zero, both losses, every parameter gradient (the R-lam
+    composition had been checked against the oracle only)."""
+    import os
+    from genie import LatentAction
+    g = torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'lam_pieces.pt'), weights_only=False)
+    m = LatentAction(g['enc_desc'], g['dec_desc'], d_codebook=g['d_codebook'], inp_shape=g['inp_shape'], n_embd=g['n_embd'])
+    assert sorted(m.state_dict()) == sorted(g['sd']), sorted(set(m.state_dict()) ^ set(g['sd']))
+    m.load_state_dict(g['sd'])
+    m = m.cuda().train()
+    h = lam_stages_hip(m, g['x'])
+    o = g['out']
+    assert rel_rms(h['enc_video'], o['enc_video']) < 2e-2, rel_rms(h['enc_video'], o['enc_video'])
+    act, act_ref = h['act'].detach().float().cpu(), o['act_pre']
+    assert rel_rms(act, act_ref) < 3e-2, rel_rms(act, act_ref)
+    # action bits: equal wherever |value| is clear of the end-to-end bf16 noise of the projection
+    margin = 8 * (act - act_ref).abs().max().item()
+    bits_hip = (h['q_act'].detach().float().cpu() > 0)
+    bits_ref = (o['q_act'] > 0)
+    decided = act_ref.abs() > margin
+    assert decided.float().mean() > 0.7 and torch.equal(bits_hip[decided], bits_ref[decided])
+    same = bool(torch.equal(h['idxs'].cpu(), o['idxs']))
+    report('lam_vs_reference_pieces', enc_video=rel_rms(h['enc_video'], o['enc_video']), act=rel_rms(act, act_ref), ids_equal=same,
+           rec_loss_hip=h['rec_loss'].item(), rec_loss_ref=o['rec_loss'].item(), q_loss_hip=h['q_loss'].item(), q_loss_ref=o['q_loss'].item())
+    if same:                                              # downstream of the quantiser only comparable when no allowed flip happened
+        assert rel_rms(h['rec'], o['recon']) < 3e-2, rel_rms(h['rec'], o['recon'])
+        assert abs(h['rec_loss'].item() - o['rec_loss'].item()) < 2e-2 * abs(o['rec_loss'].item())
+        assert abs(h['q_loss'].item() - o['q_loss'].item()) < 2e-2 * abs(o['q_loss'].item()) + 1e-4
+        worst = ('', 0.)
+        for k, p in m.named_parameters():
+            gr = g['grads'].get(k)
+            if gr is None or gr.abs().max() == 0:
+                continue
+            assert p.grad is not None, k
+            r = rel_rms(p.grad, gr)
+            worst = max(worst, (k, r), key=lambda kv: kv[1])
+            assert r < 8e-2, (k, r)
+        report('lam_vs_reference_pieces_grads', worst_param=worst[0], worst_rel_rms=worst[1])

@@ -207,3 +207,19 @@ def test_graph_capture_declarations():
     fresh = VideoTokenizer(g['enc_desc'], g['dec_desc'], d_codebook=g['d_codebook'], gan_loss_weight=0., perc_loss_weight=0.)   # (Genie froze `tok`)
     with pytest.raises(ValueError, match='CUDA'):
         GraphedTrainStep(fresh, ParamArena(fresh), torch.zeros(1, 3, 4, 16, 16))
+
+
+def test_tri_executed_fraction_matches_the_kernels_trim_rule():
+    """Host restatement of tri_trim_range (csrc/conv_igemm3.hip): a 256-row tile inside one frame skips the step-table rows whose source
+    frame is time padding.  'same' 3x3x3 conv: 2 of 3 T (frame, dt) pairs; causal: 3; tiles that straddle frames skip nothing."""
+    from genie.conv import tri_executed_fraction
+    # symmetric padding: dt in {-1, 0, 1} -> dt_min -1; 3 dt x 3 dh x 2 channel blocks = 18 rows, 6 per dt
+    assert abs(tri_executed_fraction((6, -1, 18), 16, 32 * 32, 64 * 16 * 1024, 256) - 46 / 48) < 1e-12
+    assert abs(tri_executed_fraction((6, -1, 18), 8, 16 * 16, 64 * 8 * 256, 256) - 22 / 24) < 1e-12
+    # causal: dt in {-2, -1, 0}
+    assert abs(tri_executed_fraction((6, -2, 18), 16, 32 * 32, 4 * 16 * 1024, 256) - 45 / 48) < 1e-12
+    # 4 x 8 x 8 frames: a 256-row tile spans four frames -> nothing is trimmed; no trim table -> 1
+    assert tri_executed_fraction((6, -1, 18), 4, 64, 64 * 4 * 64, 256) == 1.0
+    assert tri_executed_fraction((0, 0, 18), 16, 1024, 16384, 256) == 1.0 and tri_executed_fraction(None, 16, 1024, 16384, 256) == 1.0
+    # 128-row tiles on a 16 x 16 frame: two tiles per frame, both inside it
+    assert abs(tri_executed_fraction((3, -1, 9), 8, 256, 2 * 8 * 256, 128) - 22 / 24) < 1e-12

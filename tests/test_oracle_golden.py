@@ -111,3 +111,31 @@ def test_gan_critic_path():
     sd = {'gan_crit.' + k: v for k, v in e['sd'].items()}
     close(O.gan_loss(e['rec'], e['video'], True, e['gen']['frame_idxs'], sd, **e['kw']), e['gen']['loss'], 1e-4)
     close(O.gan_loss(e['rec'], e['video'], False, e['dis']['frame_idxs'], sd, **e['kw']), e['dis']['loss'], 1e-4)
+
+
+def test_latent_action_composition_vs_reference_pieces():
+    """R-lam pinned to the reference's OWN pieces: tests/golden/lam_pieces.pt was produced by executing action.py:111-176
+    on modules built from the reference's classes with the repaired blueprints (tests/golden/make_golden_lam.py) -- encoder stack,
+    `to_act`, LFQ, decoder with the quantised action as temporal condition, `proj_out`, both losses and every parameter gradient."""
+    g = load('lam_pieces.pt')
+    sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and 'freq' not in k and 'codebook' not in k and 'bit_mask' not in k else v)
+          for k, v in g['sd'].items()}
+    trace = {}
+    idxs, loss, (rec_loss, q_loss), recon = O.latent_action_forward(g['x'], sd, g['enc_desc'], g['dec_desc'], g['d_codebook'], training=True, trace=trace)
+    o = g['out']
+    close(trace['enc_video'], o['enc_video'])
+    close(trace['act'], o['act_pre'])
+    assert torch.equal(idxs, o['idxs'])
+    close(recon, o['recon'])
+    close(rec_loss, o['rec_loss'], 1e-5)
+    close(q_loss, o['q_loss'], 1e-5)
+    close(loss, o['loss'], 1e-5)
+    loss.backward()
+    checked = 0
+    for k, gr in g['grads'].items():
+        if gr.abs().max() == 0:
+            continue
+        assert sd[k].grad is not None, k
+        close(sd[k].grad, gr, 2e-4)
+        checked += 1
+    assert checked >= 40, checked

@@ -263,3 +263,28 @@ def test_gan_critic_path():
             torch.randperm = real_randperm
         idx = torch.cat([p[:2] for p in ps])
         close(O.gan_loss(rec, vid, train_gen, idx, sd, **disc_kw), want.detach(), 1e-4)
+
+
+def test_latent_action_composition_vs_live_reference_pieces():
+    """The R-lam composition against the LIVE reference: the pieces of `LatentAction` (action.py:60-105) built from the reference's own
+    classes with the repaired blueprints and run through action.py:111-176 (tests/golden/make_golden_lam.py::build_reference_pieces) vs
+    oracle.latent_action_forward on the same weights and a fresh input (the committed fixture covers one input; this covers another)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location('make_golden_lam', os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'make_golden_lam.py'))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    torch.manual_seed(99)
+    m = gen.build_reference_pieces().train()
+    x = torch.randn(2, 3, 4, *gen.SHAPE)
+    out = m(x)
+    trace = {}
+    idxs, loss, (rec_loss, q_loss), recon = O.latent_action_forward(x, sd_of(m), gen.ENC, gen.DEC, gen.D_CODE, training=True, trace=trace)
+    close(trace['enc_video'], out['enc_video'])
+    close(trace['act'], out['act_pre'])
+    assert torch.equal(idxs, out['idxs'])
+    close(recon, out['recon'])
+    close(loss.detach(), out['loss'].detach(), 1e-5)
+    # eval mode: no quantisation loss, same indices
+    m.eval()
+    out_e = m(x) if False else None      # (the reference's forward adds q_loss = None * weight in eval mode: it only runs in training mode)
