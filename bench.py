@@ -256,6 +256,8 @@ def main():
     ap.add_argument('--no-in-order-pass', action='store_true', help='skip the three extra in-order steps behind roofline_in_order (rocprofv3 runs: keeps every launch of the trace in the timed regime)')
     ap.add_argument('--grad-compress', choices=['none', 'bf16'], default=os.environ.get('GENIE_GRAD_COMPRESS', 'none'),
                     help='gradient all-reduce payload: fp32 (exact, default) or bf16 (half the xGMI bytes)')
+    ap.add_argument('--allreduce', choices=['allreduce', 'rs_ag'], default=os.environ.get('GENIE_DP_ALGORITHM', 'allreduce'),
+                    help='N > 1: one all_reduce per bucket (default) or an explicit reduce-scatter + all-gather over all ranks (SURVEY.md 5 / 8e)')
     ap.add_argument('--async-wgrad', type=int, default=int(os.environ.get('GENIE_ASYNC_WGRAD', 0)),
                     help='1: weight-gradient kernels on a side stream, overlapping the HBM-bound GroupNorm / element-wise passes of backward (conv launches wait for it); 2: unordered; 0: off')
     ap.add_argument('--no-other-configs', action='store_true', help='skip the configs[2] / configs[3] side measurements (`other_configs`)')
@@ -302,7 +304,7 @@ def main():
     arena = ParamArena(model)
     sync_replicas(arena, model)                            # every rank starts from rank 0's weights (not from "everybody seeded alike")
     arena.attach_weight_packs(model)                       # bf16 packs ride on the optimiser kernel + one batched transpose
-    dp = DataParallel(arena.grads, compress=args.grad_compress, loopback=args.dp_loopback)
+    dp = DataParallel(arena.grads, compress=args.grad_compress, loopback=args.dp_loopback, algorithm=args.allreduce)
     if dp.active:                                          # decoder gradients reduce while the encoder is still in backward
         # the same cut rule Trainer.fit applies (genie/trainer.py::Trainer.bucket_modules): the bench measures the path users run
         dp.install_overlap_hooks(arena, model, Trainer.bucket_modules(arena, model, max(1, args.buckets)))
@@ -392,7 +394,7 @@ def main():
                                'step = encode + LFQ(train) + decode + MSE + quant loss + backward + AdamW (R-fwd loss)',
                    'clips_per_gpu': B, 'global_batch': B * world, 'clip': list(CLIP), 'params': 375554837, 'parallelism': f'dp{world}',
                    'wgrad_stream': {0: 'in order', 1: 'on (conv launches wait for it: overlaps GroupNorm / element-wise passes only)', 2: 'on (unordered)'}.get(int(args.async_wgrad)),
-                   'grad_allreduce': {'payload': 'fp32' if args.grad_compress == 'none' else 'bf16', 'buckets': len(dp.buckets),
+                   'grad_allreduce': {'algorithm': args.allreduce, 'payload': 'fp32' if args.grad_compress == 'none' else 'bf16', 'buckets': len(dp.buckets),
                                       'bytes_per_step': dp.bytes_reduced // max(1, args.steps + args.warmup), 'overlapped_with_backward': dp.active,
                                       'loopback': bool(args.dp_loopback and world == 1)},
                    'final_loss': round(scal[0].item(), 5), 'peak_mem_GB': round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)},

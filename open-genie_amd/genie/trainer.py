@@ -235,9 +235,18 @@ class DataParallel:
     torch DDP's ``bf16_compress_hook`` does; off by default (the fp32 reduction is exact).  ``loopback=True`` issues the
     collectives even when the group has a single rank, so that the side-stream path can be exercised and timed on one GPU."""
 
-    def __init__(self, grads: Tensor, boundaries: Sequence[int] = (), group=None, compress: Optional[str] = None, loopback: bool = False) -> None:
+    def __init__(self, grads: Tensor, boundaries: Sequence[int] = (), group=None, compress: Optional[str] = None, loopback: bool = False,
+                 algorithm: str = 'allreduce') -> None:
         if compress not in (None, 'none', 'bf16'):
             raise ValueError(f"DataParallel: compress must be None or 'bf16', got {compress!r}")
+        if algorithm not in ('allreduce', 'rs_ag'):
+            raise ValueError(f"DataParallel: algorithm must be 'allreduce' or 'rs_ag', got {algorithm!r}")
+        # 'allreduce': one all_reduce per bucket (RCCL picks ring / tree).  'rs_ag': the same sum as an explicit reduce-scatter over all ranks
+        # followed by an all-gather (SURVEY.md 5 / 8e: every rank sums 1 / N of the bucket, each of the 7 xGMI links of a GPU carries one
+        # peer's shard in each phase -- no ring order, 2 (N - 1) / N of the bytes per GPU as in the ring); the mean's 1 / N scaling runs on the
+        # rank's OWN shard between the two phases, i.e. on 1 / N of the elements.  Same result up to fp32 summation order.
+        self.algorithm = algorithm
+        self._rs_out = None                              # rs_ag: this rank's reduced shard (staging, grown on demand)
         self.grads = grads
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
@@ -257,20 +266,44 @@ class DataParallel:
         self._events: list = []                          # per step: {'issue': {i: ev}, 'comm': {i: (ev0, ev1)}, 'wait': (ev0, ev1)}
         self._cur: Optional[dict] = None
 
+    def _sum_over_ranks(self, buf: Tensor, scale: float) -> None:
+        """buf <- scale * sum over the ranks of buf, in place, by the configured algorithm."""
+        w = self.world
+        if self.algorithm == 'rs_ag' and buf.numel() >= w:
+            main = buf.numel() - buf.numel() % w
+            shard = main // w
+            if self._rs_out is None or self._rs_out.numel() < shard or self._rs_out.dtype != buf.dtype:
+                self._rs_out = torch.empty(shard, dtype=buf.dtype, device=buf.device)
+            out = self._rs_out[:shard]
+            dist.reduce_scatter_tensor(out, buf[:main], op=dist.ReduceOp.SUM, group=self.group)
+            if scale != 1.0:
+                out.mul_(scale)
+            dist.all_gather_into_tensor(buf[:main], out, group=self.group)
+            if main < buf.numel():                       # the few elements that do not divide by the world size
+                tail = buf[main:]
+                dist.all_reduce(tail, op=dist.ReduceOp.SUM, group=self.group)
+                if scale != 1.0:
+                    tail.mul_(scale)
+            return
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+        if scale != 1.0:
+            buf.mul_(scale)
+
     def _all_reduce_mean(self, chunk: Tensor, lo: int) -> None:
+        scale = 1.0 / self.world if self.world > 1 else 1.0
         if self.compress == 'bf16':
             if self._stage is None:
                 self._stage = torch.empty(self.grads.numel(), dtype=torch.bfloat16, device=self.grads.device)
             st = self._stage[lo:lo + chunk.numel()]
             st.copy_(chunk)
-            dist.all_reduce(st, op=dist.ReduceOp.SUM, group=self.group)
+            self._sum_over_ranks(st, 1.0)                # (the mean's scaling in fp32, after the expansion: bf16 would round it twice)
             chunk.copy_(st)
+            if scale != 1.0:
+                chunk.mul_(scale)
             self.bytes_reduced += chunk.numel() * 2
         else:
-            dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group)
+            self._sum_over_ranks(chunk, scale)
             self.bytes_reduced += chunk.numel() * 4
-        if self.world > 1:
-            chunk.mul_(1.0 / self.world)
 
     def _reduce(self, lo: int, hi: int) -> None:
         if not self.active or hi <= lo:
@@ -350,7 +383,8 @@ class DataParallel:
                             'issued_before_backward_end_ms': round(d.get('issued_before_backward_end_ms', 0.0) / n, 3),
                             'allreduce_ms': round(d.get('allreduce_ms', 0.0) / n, 3)})
         tot = sum(b['allreduce_ms'] for b in buckets)
-        return {'steps_traced': n, 'exposed_ms_per_step': round(exposed / n, 3), 'allreduce_ms_per_step': round(tot, 3),
+        return {'algorithm': self.algorithm, 'payload': 'bf16' if self.compress == 'bf16' else 'fp32', 'world': self.world,
+                'steps_traced': n, 'exposed_ms_per_step': round(exposed / n, 3), 'allreduce_ms_per_step': round(tot, 3),
                 'hidden_fraction': round(1.0 - (exposed / n) / tot, 4) if tot > 0 else None,
                 'bus_GBps': round(sum(b['payload_MB'] for b in buckets) * 1e-3 * 2 * (self.world - 1) / max(self.world, 1) / (tot * 1e-3), 1) if tot > 0 else None,
                 'buckets': buckets}
@@ -476,7 +510,7 @@ class Trainer:
     per GPU is launched by ``torch.distributed.run``; arithmetic is bf16 with fp32 masters; ``save_last`` is always on)."""
 
     def __init__(self, max_epochs: int = 1, max_steps: int = -1, log_every_n_steps: int = 16, val_check_interval: int | None = None,
-                 limit_val_batches: int | None = None, default_root_dir: str = 'runs', grad_compress: Optional[str] = None,
+                 limit_val_batches: int | None = None, default_root_dir: str = 'runs', grad_compress: Optional[str] = None, grad_algorithm: str = 'allreduce',
                  graph: bool = False, grad_buckets: int = 8, **ignored) -> None:
         # graph: after two eager steps the training step (forward, backward, AdamW) is captured in a hipGraph and replayed per batch
         # (genie/graph.py; single-GPU runs, batches of the captured shape -- anything else takes the eager path)
@@ -485,6 +519,7 @@ class Trainer:
         self.max_epochs, self.max_steps = max_epochs, (max_steps if max_steps and max_steps > 0 else None)
         self.log_every_n_steps, self.val_check_interval, self.limit_val_batches = max(1, log_every_n_steps), val_check_interval, limit_val_batches
         self.default_root_dir, self.grad_compress, self.ignored = default_root_dir, grad_compress, dict(ignored)
+        self.grad_algorithm = grad_algorithm               # 'allreduce' | 'rs_ag' (DataParallel)
         self.global_step = 0
         self.history: List[dict] = []
 
@@ -589,7 +624,7 @@ class Trainer:
         sync_replicas(arena, model, seed=seed)
         arena.attach_weight_packs(model)
         self.arena = arena
-        dp = DataParallel(arena.grads, compress=self.grad_compress)
+        dp = DataParallel(arena.grads, compress=self.grad_compress, algorithm=self.grad_algorithm)
         if dp.active and hasattr(model, 'forward_order'):
             dp.install_overlap_hooks(arena, model, self.bucket_modules(arena, model, self.grad_buckets))
         done = self.max_steps is not None and self.global_step >= self.max_steps

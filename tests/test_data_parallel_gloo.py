@@ -48,6 +48,24 @@ def _worker(rank: int, world: int, port: int, q):
                 + ((torch.arange(1000, dtype=torch.float32) * 0.37 + 1.0) * 2).to(torch.bfloat16).float()).to(torch.bfloat16).float() / 2
         assert torch.allclose(g2, want, rtol=2 ** -7), (g2 - want).abs().max()
         assert dpc.bytes_reduced == 1000 * 2
+        # explicit reduce-scatter + all-gather (--allreduce rs_ag) == the all-reduce, bucket sizes that do and do not divide by the world
+        # size (odd buckets: the tail goes through a small all-reduce), early + late buckets, fp32 and bf16 payload
+        base = torch.arange(1003, dtype=torch.float32) * 0.37 + 1.0
+        ga, gr = base * (rank + 1), base * (rank + 1)
+        da = DataParallel(ga, boundaries=[257, 641])
+        dr = DataParallel(gr, boundaries=[257, 641], algorithm='rs_ag')
+        for d_ in (da, dr):
+            d_.bucket_ready(2)
+            d_.finish()
+        assert torch.equal(ga, gr), (ga - gr).abs().max()              # two ranks: the sums are the same two addends in either order
+        assert dr.last_fired == [2, 1, 0] and dr.bytes_reduced == da.bytes_reduced
+        gb_a, gb_r = base * (rank + 1), base * (rank + 1)
+        DataParallel(gb_a, boundaries=[500], compress='bf16').finish()
+        DataParallel(gb_r, boundaries=[500], compress='bf16', algorithm='rs_ag').finish()
+        assert torch.equal(gb_a, gb_r)
+        tiny = torch.ones(1) * (rank + 1)                                # a bucket smaller than the world: plain all-reduce
+        DataParallel(tiny, algorithm='rs_ag').finish()
+        assert tiny.item() == 1.5
         q.put((rank, clips, dp.bytes_reduced))
     finally:
         dist.destroy_process_group()

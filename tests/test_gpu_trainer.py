@@ -94,7 +94,7 @@ PROJ_DEC = (('causal-conv3d', {'in_channels': 16, 'out_channels': 128, 'kernel_s
            (('adaptive_group_norm', {'dim_cond': 16, 'num_groups': 8, 'num_channels': 128, 'has_ext': True}),) + DEC[3:]
 
 
-def _step_grads(build, run, dp_cuts, loopback):
+def _step_grads(build, run, dp_cuts, loopback, compress='bf16', algorithm='allreduce'):
     """One forward/backward of a freshly built model; returns (gradient arena copy, DataParallel or None, arena)."""
     from genie.trainer import DataParallel, ParamArena
     m = build()
@@ -102,7 +102,7 @@ def _step_grads(build, run, dp_cuts, loopback):
     m._arena_for_cuts = arena
     dp = None
     if loopback:
-        dp = DataParallel(arena.grads, compress='bf16', loopback=True)
+        dp = DataParallel(arena.grads, compress=compress, loopback=True, algorithm=algorithm)
         dp.install_overlap_hooks(arena, m, dp_cuts(m))
         dp.trace = True                                      # HIP events around every bucket's all-reduce and finish()'s wait (comm_report)
     loss = run(m)
@@ -175,12 +175,24 @@ def test_data_parallel_loopback_on_real_models():
             assert sum(b_['elements'] for b_ in rep['buckets']) == arena.numel
             assert all(b_['allreduce_ms'] > 0 and b_['issued_before_backward_end_ms'] >= 0 for b_ in rep['buckets'])
             assert rep['exposed_ms_per_step'] >= 0 and rep['allreduce_ms_per_step'] > 0
+            assert rep['algorithm'] == 'allreduce' and rep['payload'] == 'bf16' and rep['world'] == 1
+            assert set(rep['buckets'][0]) >= {'elements', 'payload_MB', 'issued_before_backward_end_ms', 'allreduce_ms'}
             assert torch.equal(g_dp, g_dp.to(torch.bfloat16).float()), 'a gradient was written after its bucket had been reduced'
             for name, (off, n) in arena.slots.items():
                 a, b = g_dp[off:off + n], g_ref[off:off + n]
                 assert b.abs().max() > 0 or 'bias' in name or 'freq' in name, f'{name}: no gradient'
                 err = (a - b).abs().max().item()
                 assert err <= 2 ** -7 * b.abs().max().item() + 1e-6, (name, err, b.abs().max().item())
+        # the reduce-scatter + all-gather form (bench.py --allreduce rs_ag) through the same side-stream machinery: RCCL's reduce_scatter /
+        # all_gather on a one-rank group are copies, so with fp32 payload the gradients must equal the un-parallel run's up to the order
+        # of the weight-gradient kernels' fp32 atomics
+        build, run, cuts = cases[0]
+        g_ref, _, _ = _step_grads(build, run, cuts, loopback=False)
+        g_rs, dp, arena = _step_grads(build, run, cuts, loopback=True, compress=None, algorithm='rs_ag')
+        rep = dp.comm_report()
+        assert rep['algorithm'] == 'rs_ag' and rep['payload'] == 'fp32' and len(rep['buckets']) == len(dp.buckets)
+        assert dp.bytes_reduced == arena.numel * 4
+        assert (g_rs - g_ref).abs().max().item() <= 1e-5 * g_ref.abs().max().item()
     finally:
         dist.destroy_process_group()
 
