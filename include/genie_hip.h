@@ -320,6 +320,13 @@ int genie_linear_ce_bwd(const void* h_bf16, int64_t h_pitch, int64_t M, int D, c
                         const float* bias, const int64_t* target, const float* row_e, const float* scale, const float* dh_f32,
                         void* dh_bf16, int64_t dh_pitch, float* dW, float* dbias, void* stream);
 
+/* Guard-page device allocations for the memory-safety harness (guard.hip; tests/guard.py).  *ptr: `bytes` bytes of device memory whose last byte
+ * (up to 15 bytes of alignment slack) is the last byte of a mapping with an UNMAPPED page on either side -- an out-of-bounds access of a
+ * kernel in either direction is a GPU page fault on every run, not only when the caching allocator happens to leave a hole there.
+ * Test infrastructure (ABI 11); nothing on the product path calls these. */
+int genie_guard_alloc(int64_t bytes, void** ptr, void** handle);
+int genie_guard_free(void* handle);
+
 /* MaskGIT sampling step (maskgit.hip).   replaces: softmax(logits / temp) + torch.multinomial + gather (confidence) and
  * topk + gather + scatter_ of DynamicsModel.generate, dynamics.py:138-158.  The multinomial draw is an inverse-CDF draw from an
  * INJECTED uniform per row (device RNG streams are not reproducible across devices; oracle/genie_oracle.py::sample_from_uniform):

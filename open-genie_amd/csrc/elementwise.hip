@@ -582,7 +582,11 @@ __global__ void __launch_bounds__(256) chan_sum_kernel(const bf16_t* __restrict_
     // and walking the pitch from the view's first channel ran past the end of the tensor on its last pixels (found with rocgdb as a memory
     // fault that depended on where the allocator had placed the tensor)
     const int lane = threadIdx.x & 63, sub = lane & 7;
+#ifdef GENIE_REINTRODUCE_CHANSUM_OOB
+    const int nch = Cp >> 3;                              // round 4's bug, kept ONLY for lib/libgenie_hip_oobprobe.so: the guard harness must catch it
+#else
     const int nch = (C + 7) >> 3;
+#endif
     for (long long p = ((long long)blockIdx.x * 256 + threadIdx.x) >> 3; p < npix; p += ((long long)gridDim.x * 256) >> 3) {
         float s = 0.f;
         for (int ch = sub; ch < nch; ch += 8) {

@@ -15,6 +15,7 @@
 #   variants the bench on the same box with (a) the RCCL bucket all-reduces on a single-rank group, fp32 and bf16 payload, (b) the weight
 #            gradients on a side stream -- the side measurements DESIGN.md quotes next to the default line
 #                                                                          -> <tag>_bench_variants.jsonl
+#   guard    kernel-level suite under guard-page allocations, two file orders + the deliberate-overrun regression -> <tag>_guard_*.log
 #   pmc      SQ counters of the attention families and of the dominant conv layer (separate rocprofv3 passes)
 #                                                                          -> <tag>_pmc_attn.txt, <tag>_pmc_conv.txt
 # (Rounds 1-3 used one-off scripts/exp_r*.sh files for the same jobs; they are in the history up to commit 7bfe1bc.)
@@ -80,6 +81,15 @@ PY
     pmc)
       timeout 400 bash scripts/pmc_attn.sh > $OUT/pmc_attn.log 2>&1; cp gpurun_out/pmc_attn/summary.txt $OUT/${TAG}_pmc_attn.txt 2>/dev/null
       MB_BATCH=64 timeout 500 bash scripts/pmc_conv.sh > $OUT/${TAG}_pmc_conv.txt 2>&1 ;;
+    guard)
+      # kernel-level suite with every Python-side allocation behind guard pages (tests/guard.py), in TWO file orders (round 4's overrun showed
+      # in one order only), then the regression: the library with that overrun compiled back in must die under the harness
+      F1="tests/test_gpu_kernels.py tests/test_gpu_golden.py tests/test_gpu_attention.py tests/test_gpu_maskgit.py tests/test_gpu_linear_ce.py"
+      F2="tests/test_gpu_linear_ce.py tests/test_gpu_maskgit.py tests/test_gpu_golden.py tests/test_gpu_attention.py tests/test_gpu_kernels.py"
+      timeout 1500 python scripts/guard_run.py $F1 -q -m gpu -p no:cacheprovider -x 2>&1 | tail -6 > $OUT/${TAG}_guard_order1.log
+      timeout 1500 python scripts/guard_run.py $F2 -q -m gpu -p no:cacheprovider -x 2>&1 | tail -6 > $OUT/${TAG}_guard_order2.log
+      GENIE_GUARD_REGRESSION=1 timeout 600 python -m pytest tests/test_gpu_guard.py -q -m gpu -p no:cacheprovider 2>&1 | tail -4 > $OUT/${TAG}_guard_regression.log
+      tail -2 $OUT/${TAG}_guard_order1.log $OUT/${TAG}_guard_order2.log $OUT/${TAG}_guard_regression.log ;;
     *) echo "unknown stage $st" ;;
   esac
 done
