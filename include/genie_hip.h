@@ -320,6 +320,11 @@ int genie_linear_ce_bwd(const void* h_bf16, int64_t h_pitch, int64_t M, int D, c
                         const float* bias, const int64_t* target, const float* row_e, const float* scale, const float* dh_f32,
                         void* dh_bf16, int64_t dh_pitch, float* dW, float* dbias, void* stream);
 
+/* uint8 video frames [npix = N T H W][C] (what a decoder / a .npy frame array holds) -> CL bf16 [npix][cpitch], value / 255, pad channels zero
+ * (elementwise.hip; ABI 11).   replaces: `video / 255.` + rearrange 't h w c -> c t h w' of Platformer2D.load_video_slice (genie/module/data.py:218-231)
+ * done on the host, followed by the model-boundary layout conversion.  Same numbers as that path (fp32 quotient, one rounding to bf16). */
+int genie_u8_frames_to_cl(const void* src_u8, int64_t npix, int C, void* dst_cl, int cpitch, void* stream);
+
 /* Guard-page device allocations for the memory-safety harness (guard.hip; tests/guard.py).  *ptr: `bytes` bytes of device memory whose last byte
  * (up to 15 bytes of alignment slack) is the last byte of a mapping with an UNMAPPED page on either side -- an out-of-bounds access of a
  * kernel in either direction is a GPU page fault on every run, not only when the caching allocator happens to leave a hole there.

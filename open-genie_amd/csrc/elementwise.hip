@@ -101,6 +101,33 @@ extern "C" int genie_to_channels_last(const void* src, int src_dtype, const int6
     return GENIE_OK;
 }
 
+// Decoded video frames -> the internal activation layout, on the DEVICE (data path in front of the hot path): the reference
+// divides the uint8 frames by 255 on the host and rearranges 't h w c -> c t h w' (genie/module/data.py:218-231); at the ~145 clips/s one
+// MI355X consumes that is 113 MB/s of fp32 through the loader's pipes, the pinned staging and PCIe, plus a layout pass on arrival.  The
+// frames stay uint8 until they are in HBM (a quarter of the bytes) and become the model's own bf16 channels-last tensor in ONE pass:
+// dst[n][t][h][w][c] = bf16(float(src[n][t][h][w][c]) / 255) for c < C, zeros up to the pitch -- the very numbers the reference's fp32
+// division followed by this library's to_channels_last produces (same fp32 quotient, same round-to-nearest-even).  One pixel per thread.
+__global__ void __launch_bounds__(256) u8_frames_to_cl_kernel(const uint8_t* __restrict__ src, bf16_t* __restrict__ dst, long long npix, int C, int cpitch) {
+    for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long long)gridDim.x * 256) {
+        const uint8_t* s = src + p * C;
+        for (int c0 = 0; c0 < cpitch; c0 += 8) {
+            float f[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = (c0 + j < C) ? (float)s[c0 + j] / 255.f : 0.f;
+            *reinterpret_cast<u32x4_t*>(dst + p * cpitch + c0) = pack8(f);
+        }
+    }
+}
+
+extern "C" int genie_u8_frames_to_cl(const void* src_u8, int64_t npix, int C, void* dst_cl, int cpitch, void* stream) {
+    GENIE_CHECK_ARG(src_u8 && dst_cl, "genie_u8_frames_to_cl: null pointer");
+    GENIE_CHECK_ARG(C >= 1 && cpitch % 8 == 0 && cpitch >= C, "genie_u8_frames_to_cl: channel pitch %d must be a multiple of 8 and >= C=%d", cpitch, C);
+    if (npix == 0) return GENIE_OK;
+    u8_frames_to_cl_kernel<<<ew_grid(npix), 256, 0, (hipStream_t)stream>>>((const uint8_t*)src_u8, (bf16_t*)dst_cl, npix, C, cpitch);
+    GENIE_CHECK_LAUNCH();
+    return GENIE_OK;
+}
+
 // Inverse of the depth-to-space-time rearrange on a CL tensor (reference video.py:403-408 'b (c p q r) t h w -> b c (t p)(h q)(w r)'):
 // src CL [N][T P][H Q][W R][sp] (cf channels) -> dst CL [N][T][H][W][P Q R cf], channel ((p Q + q) R + r) cf + c -- the sub-pixel-major
 // order of the transposed weight pack, so that the backward-data pass of an upsample conv becomes a PLAIN conv over dst (kw-triple

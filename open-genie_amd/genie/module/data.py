@@ -103,8 +103,15 @@ class Platformer2D(Dataset):
     last frame ('repeat'), with zeros ('zero') or with one random frame ('random'); values / 255; axes per `output_format`."""
 
     def __init__(self, root: str, split: str = 'train', env_name: str = 'Coinrun', padding: str = 'none', randomize: bool = False,
-                 transform: Callable | None = None, num_frames: int = 16, output_format: str = 't c h w') -> None:
+                 transform: Callable | None = None, num_frames: int = 16, output_format: str = 't c h w', device_decode: bool = False) -> None:
+        """`device_decode=True` (not in the reference): return the clip as the decoder produced it -- uint8 (t, h, w, c) -- and leave the division
+        by 255, the axis order and the cast to ``DevicePrefetcher`` (``genie_u8_frames_to_cl`` on the GPU): a quarter of the bytes through the
+        loader, the pinned staging and PCIe, no float pass on the host.  `output_format` must then be 'c t h w' (what the models take) and
+        `transform` unset; 'random' padding draws its frame in uint8."""
         super().__init__()
+        self.device_decode = bool(device_decode)
+        if self.device_decode and (exists(transform) or output_format.lower().replace(' ', '') != 'cthw'):
+            raise ValueError("Platformer2D(device_decode=True) needs output_format='c t h w' and no transform (the GPU produces that layout)")
         if padding not in ('none', 'repeat', 'zero', 'random'):
             raise ValueError(f'Invalid padding type: {padding}')
         self.root = os.path.join(root, env_name, split)
@@ -133,6 +140,12 @@ class Platformer2D(Dataset):
         got = frames.shape[0]
         if got == 0:
             raise RuntimeError(f'{video_path}: no frame could be decoded')
+        if self.device_decode:                               # uint8 (t, h, w, c), padded the same way; DevicePrefetcher finishes the job on the GPU
+            if got < want and self.padding != 'none':
+                last = frames[-1:]
+                fill = {'repeat': last, 'zero': torch.zeros_like(last), 'random': torch.randint(0, 256, last.shape, dtype=torch.uint8)}[self.padding]
+                frames = torch.cat([frames, fill.expand(want - got, *last.shape[1:])])
+            return frames.contiguous()
         video = frames.float() / 255.
         if got < want and self.padding != 'none':
             last = video[-1:]
@@ -201,6 +214,24 @@ class LightningDataset(LightningDataModule):
         return self._loader(self.test__dataset, self.test__sampler, self.val_batch_size, self.val_shuffle)
 
 
+def decode_frames_on_device(frames_u8: Tensor) -> Tensor:
+    """uint8 (N, T, H, W, C) frames on the GPU -> the models' input: a bf16 channels-last (CL, genie/cl.py) tensor of logical shape (N, C, T, H, W)
+    with value / 255 -- reference data.py:218-231 (`video / 255.`, 't h w c -> c t h w') fused with the model-boundary layout conversion, on the
+    current stream (genie_u8_frames_to_cl)."""
+    from .. import _hip
+    from ..cl import empty_cl, pitch_of
+    _hip.require_gpu(frames_u8, 'decode_frames_on_device')
+    if frames_u8.dtype != torch.uint8 or frames_u8.dim() != 5:
+        raise ValueError(f'decode_frames_on_device: expected uint8 (N, T, H, W, C), got {frames_u8.dtype} {tuple(frames_u8.shape)}')
+    f = frames_u8.contiguous()
+    n, t, h, w, c = f.shape
+    out = empty_cl(n, c, t, h, w, f.device, zero_pad=False)          # the kernel writes the pad channels
+    _hip.check(_hip.load_library().genie_u8_frames_to_cl(f.data_ptr(), n * t * h * w, c, out.data_ptr(), pitch_of(out), _hip.stream_ptr()),
+               'genie_u8_frames_to_cl')
+    f.record_stream(torch.cuda.current_stream(f.device))
+    return out
+
+
 class DevicePrefetcher:
     """Iterate a loader with the NEXT batch's host -> device copy already in flight on a side stream (pinned source memory, so the
     copy is a real DMA that overlaps kernels).  On a CPU-only box it is a plain pass-through."""
@@ -213,14 +244,22 @@ class DevicePrefetcher:
     def __len__(self) -> int:
         return len(self.loader)
 
+    def _one(self, b):
+        if not isinstance(b, Tensor):
+            return b
+        d = b.to(self.device, non_blocking=True)
+        if d.dtype == torch.uint8 and d.dim() == 5:          # (N, T, H, W, C) raw frames of Platformer2D(device_decode=True): -> CL bf16 (N, C, T, H, W) / 255
+            d = decode_frames_on_device(d)
+        return d
+
     def _to_device(self, batch):
         if self.stream is None:
             return batch
         with torch.cuda.stream(self.stream):
             if isinstance(batch, Tensor):
-                return batch.to(self.device, non_blocking=True)
+                return self._one(batch)
             if isinstance(batch, (list, tuple)):
-                return type(batch)(b.to(self.device, non_blocking=True) if isinstance(b, Tensor) else b for b in batch)
+                return type(batch)(self._one(b) for b in batch)
         return batch
 
     def __iter__(self) -> Iterator:
