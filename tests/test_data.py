@@ -202,3 +202,42 @@ def test_platformer2d_matches_the_reference_reader(mp4_clips, monkeypatch):
         R.Platformer2D(mp4_clips, padding='random', num_frames=16)[2]
     v = D.Platformer2D(mp4_clips, padding='random', num_frames=16)[2]
     assert tuple(v.shape) == (14, 3, 6, 10) and 0 <= v.min() and v.max() <= 1
+
+
+def test_platformer2d_device_decode_returns_raw_frames(clips, monkeypatch):
+    """device_decode=True: the clip leaves the dataset as the decoder produced it -- uint8 (t, h, w, c), same frames, same padding rule --
+    and the float / layout work is left to the GPU (DevicePrefetcher, genie_u8_frames_to_cl; its numbers are checked on the GPU in
+    tests/test_gpu_data.py)."""
+    from genie.module import data as D
+    ds = D.Platformer2D(clips, split='train', num_frames=6, output_format='c t h w', device_decode=True)
+    ref = D.Platformer2D(clips, split='train', num_frames=6, output_format='c t h w')
+    for i in range(len(ds)):
+        raw, flt = ds[i], ref[i]
+        assert raw.dtype == torch.uint8 and tuple(raw.shape) == (6, 8, 12, 3) and raw.is_contiguous()
+        assert torch.equal(raw.float().div(255.).permute(3, 0, 1, 2), flt)
+    with pytest.raises(ValueError):
+        D.Platformer2D(clips, device_decode=True)                              # default 't c h w' is not what the models take
+    with pytest.raises(ValueError):
+        D.Platformer2D(clips, output_format='c t h w', device_decode=True, transform=lambda x: x)
+    # truncated read + 'repeat' padding in uint8
+    real = D.open_video
+
+    class Short:
+        def __init__(self, path):
+            self.rd = real(path)
+
+        def __len__(self):
+            return len(self.rd)
+
+        def read(self, start, count):
+            return self.rd.read(start, count)[:4]
+
+        def close(self):
+            self.rd.close()
+    monkeypatch.setattr(D, 'open_video', Short)
+    v = D.Platformer2D(clips, num_frames=6, padding='repeat', output_format='c t h w', device_decode=True)[0]
+    assert tuple(v.shape) == (6, 8, 12, 3) and torch.equal(v[4], v[3]) and torch.equal(v[5], v[3])
+    # the prefetcher's CPU form passes raw batches through untouched
+    batch = torch.stack([ds[0], ds[1]])
+    if not torch.cuda.is_available():
+        assert torch.equal(next(iter(D.DevicePrefetcher([batch]))), batch)
