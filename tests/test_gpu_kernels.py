@@ -777,12 +777,14 @@ WIDE_CASES = [
 ]
 
 
+@pytest.mark.parametrize('four_waves', [False, True])
 @pytest.mark.parametrize('cin,cout,kernel,causal,size,resid', WIDE_CASES)
-def test_conv_triple_wide_kernel(G, cin, cout, kernel, causal, size, resid, monkeypatch):
+def test_conv_triple_wide_kernel(G, cin, cout, kernel, causal, size, resid, four_waves, monkeypatch):
     """igemm3w_kernel (256 x 256 tile, 32-channel weight half-tiles): forward (with and without the residual epilogue) and
-    backward-data against the oracle; the library must report that the wide kernel ran (variant 12)."""
+    backward-data against the oracle; the library must report that the wide kernel ran (variant 12).  four_waves: the same tile as four
+    waves of 128 x 128, one per SIMD (conv_igemm3x.hip, tri_flags bit 12)."""
     monkeypatch.setattr(G.conv, 'TRI_BM', 256)
-    monkeypatch.setattr(G.conv, 'TRI_FLAGS', 1024 | 2048)
+    monkeypatch.setattr(G.conv, 'TRI_FLAGS', 1024 | 2048 | (4096 if four_waves else 0))
     torch.manual_seed(13)
     n, t, h, w = size
     x = bf16_round(torch.randn(n, cin, t, h, w))
