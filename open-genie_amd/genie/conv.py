@@ -171,6 +171,7 @@ def set_deterministic(on: bool) -> bool:
     return old
 
 
+TRI_DH_INNER = os.environ.get('GENIE_TRI_DH_INNER', '1') not in ('0', '')   # step-table order inside a dt: (channel block, dh) instead of (dh, channel block)
 TRI_TRIM = os.environ.get('GENIE_TRI_TRIM', '1') not in ('0', '')       # A/B switch: 0 = padding frames are staged and multiplied like any other
 
 
@@ -183,15 +184,21 @@ def tri_rows(taps, hs: int, ws: int, cs: int):
         groups.setdefault((dt, dh, c0, nch), {})[dw] = wofs
     if not groups or len(taps) != 3 * len(groups):
         return None
-    rows = []
+    rows, chan = [], []
     for (dt, dh, c0, nch), by_dw in groups.items():
         if sorted(by_dw) != [-1, 0, 1] or nch % 64 != 0 or c0 % 8 != 0:
             return None
         for cb in range(nch // 64):
             rows.append([((dt * hs + dh) * ws) * cs + c0 + cb * 64, dt, dh, by_dw[-1] + cb * 64, by_dw[0] + cb * 64, by_dw[1] + cb * 64, 0, 0])
+            chan.append(c0 + cb * 64)
     # rows sorted by dt, every dt owning the same number of consecutive rows: a row tile inside frame t can then skip the rows whose
-    # frame t + dt is padding (GenieTriStep.rows_per_dt / dt_min; 2 of 48 (frame, dt) pairs of a 16-frame 'same' conv, 3 of a causal one)
-    rows.sort(key=lambda r: r[1])
+    # frame t + dt is padding (GenieTriStep.rows_per_dt / dt_min; 2 of 48 (frame, dt) pairs of a 16-frame 'same' conv, 3 of a causal one).
+    # Inside a dt: channel block OUTER, dh INNER (TRI_DH_INNER, default) -- the three images of a (dt, channel block) are the same image rows
+    # shifted by one (7 of 8 rows shared), so the second and third come out of the XCD's L2 while it still holds them (40 KB per block in
+    # between); in the (dh, channel block) order of rounds 2-4 four channel-block images per resident block (5 MB per XCD > its 4-MB L2) sat
+    # between two reads of a row and every one of them went back to the fabric: FETCH_SIZE 5.3 x the input of a 256 -> 256 @16x32x32 launch.
+    order = sorted(range(len(rows)), key=(lambda i: (rows[i][1], chan[i], rows[i][2])) if TRI_DH_INNER else (lambda i: rows[i][1]))
+    rows = [rows[i] for i in order]
     dts = [r[1] for r in rows]
     lo, n = dts[0], dts.count(dts[0])
     if TRI_TRIM and all(dts[i] == lo + i // n for i in range(len(rows))):

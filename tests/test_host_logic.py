@@ -135,7 +135,13 @@ def test_kw_triple_schedule_host_logic():
     assert len(rows) == 9 * 2                                        # 9 (dt, dh) pairs x 2 channel blocks
     a_delta, dt, dh, w0, w1, w2, rows_per_dt, dt_min = rows[0]
     assert (dt, dh) == (-1, -1) and a_delta == ((-1 * 8 - 1) * 16) * 128 and (w0, w1, w2) == (0, 128, 256)
-    assert rows[1][0] == rows[0][0] + 64 and rows[1][3:6] == [64, 192, 320]          # second 64-channel block of the same triple
+    # inside a dt: channel block outer, dh inner (the three row-shifted images of one channel block back to back: L2 reuse, TRI_DH_INNER)
+    assert [(r[1], r[2]) for r in rows[:6]] == [(-1, -1), (-1, 0), (-1, 1)] * 2
+    assert rows[1][0] == rows[0][0] + 16 * 128 and rows[3][0] == rows[0][0] + 64 and rows[3][3:6] == [64, 192, 320]   # row 3: second 64-channel block of the first triple
+    old_order = __import__('unittest.mock').mock.patch.object(gconv, 'TRI_DH_INNER', False)
+    with old_order:
+        r_old = gconv.tri_rows(taps, hs=8, ws=16, cs=128)
+    assert r_old[1][0] == r_old[0][0] + 64 and sorted(map(tuple, r_old)) == sorted(map(tuple, rows))                 # same rows, (dh, channel block) order
     # sorted by dt, every dt owning rows_per_dt consecutive rows (what lets a row tile inside one frame skip the padding frames)
     assert (rows_per_dt, dt_min) == (6, -1) and all(r[6:8] == [6, -1] for r in rows)
     assert [r[1] for r in rows] == [-1] * 6 + [0] * 6 + [1] * 6
@@ -147,7 +153,7 @@ def test_kw_triple_schedule_host_logic():
     # backward-data taps of a stride-1 conv: offsets flipped, still complete triples (dw = +1, 0, -1 order)
     dtaps = gconv.dgrad_taps(spec, (0, 0, 0), 64, want_list=True)
     drows = gconv.tri_rows(dtaps, 8, 16, 64)
-    assert len(drows) == 9 and drows[-1][1:3] == [1, -1] and drows[0][1] == -1 and drows[0][3] > drows[0][5]   # dw = -1 reads the LAST kw slice
+    assert len(drows) == 9 and drows[-1][1] == 1 and drows[0][1] == -1 and drows[0][3] > drows[0][5]   # dw = -1 reads the LAST kw slice
     assert sorted((r[1], r[2]) for r in drows) == [(a, b) for a in (-1, 0, 1) for b in (-1, 0, 1)]
     # not eligible: 1-wide kernels, channel counts that are not whole 64-blocks, dilated w taps
     assert gconv.tri_rows(gconv._fwd_tap_list(gconv.same_spec(64, 64, (1, 1, 1))), 8, 8, 64) is None
