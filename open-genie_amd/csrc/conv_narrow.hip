@@ -369,6 +369,234 @@ __global__ void __launch_bounds__(256) conv_narrow_out_kernel(const NarrowOutArg
 
 
 // ------------------------------------------------------------------------------------------------------------------------------
+// Head conv forward, second cut (round 5) -- images up to 64 pixels wide.
+// The kernel above is bound by the LDS port: per 32 pixels and input frame a wave issues 144 ds_read_b128 (one per 16x16x32 MFMA
+// and column half, 9 of 16 MFMA rows used) -- 2304 LDS cycles per 32-KB slab and CU, which is the time HBM needs to deliver it.
+// Here the column tap joins the frame tap in the M dimension:
+//     C[(dt, dw, co)][x] = sum_{dh, ci} W[co][(dt, dh, dw)][ci] * X[tin][h + dh - 1][x][ci]          (27 of 32 rows, K = 3 * 128 = 384)
+// with x the INPUT column, one v_mfma_f32_32x32x16_bf16 per 16 channels, row tap and 32 columns: 24 MFMAs and 24 fragment reads
+// per 32 pixels and frame (was 72 and 144).  The output is out[t][h][p] = sum_dw C_(dt = 2, accumulated)[dw][p + dw - 1]: a wave
+// owns a whole image row (two 32-column tiles for W = 64, one for W = 32), so the dw shift is a LANE shift of the finished
+// accumulator rows with zeros entering at both ends = the conv's zero padding; no halo columns.
+//   * rows: row = 8 dt + s for s = 3 dw + co < 8, row = 24 + dt for (dw, co) = (2, 2).  In the 32x32 C layout (row = 8 (i / 4) + 4 (lane / 32)
+//     + i % 4) the frame tap dt is then the register quad i / 4: carrying partial sums to the next input frame (dt -> dt + 1) is a
+//     register move, and the finished quad dt = 2 holds slots s = 0..3 in lanes 0-31 and s = 4..7 in lanes 32-63.  One
+//     v_permlane32_swap per register between the two column tiles turns that into "lane = column 0..63" for every slot, and
+//     the shift is one DPP wave_shr / wave_shl (bound_ctrl: zero fill) per outer column tap and channel.
+//   * the input tile of a frame (6 rows x W pixels x 256 B) is consumed in four channel quarters: a stage is 6 x W x 64 B (24 KB),
+//     three stages in LDS (72 KB: TWO workgroups per CU -- one's barriers and epilogues are covered by the other), DMA'd two stages
+//     ahead, 16-byte chunks XOR-swizzled with bits 2-3 of the pixel (conflict-free ds_read_b128 at a 64-byte pixel stride);
+//   * weights: the [16][1152] pack of the kernel above, read with this kernel's row mapping into 24 A fragments per lane.
+// ------------------------------------------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float nout2_shift(float v) {             // 0x138: lane l <- lane l - 1; 0x130: lane l <- lane l + 1; zero fill
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+template <int IMM>
+__device__ __forceinline__ bf16x8_t nout2_read128(unsigned lds_addr) {
+    bf16x8_t v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "n"(IMM));
+    return v;
+}
+
+template <int NT>
+__global__ void __launch_bounds__(256, 2) conv_narrow_out2_kernel(const NarrowOutArgs a) {
+    constexpr int PXR = 32 * NT;                        // pixels per tile row = image width
+    constexpr int ROWB = PXR * 64;                      // bytes per tile row and stage
+    constexpr int STAGE = 6 * ROWB;                     // 24576 / 12288
+    constexpr int DPS = STAGE / 1024;                   // DMA instructions per stage (16 pixels x 64 B each)
+    constexpr int DPW = DPS / 4;                        // ... per wave: 6 / 3
+    constexpr int DPR = PXR / 16;                       // ... per tile row
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n32 = lane & 31, kh = lane >> 5;
+    const int W = a.W, H = a.H;
+    const unsigned lds0 = nout_lds_offset(smem);
+
+    // consecutive logical blocks (row blocks of one sample: shared halo rows) on ONE XCD: hardware block b runs on XCD b % 8
+    int b = blockIdx.x;
+    if ((gridDim.x & 7) == 0) b = (b & 7) * (int)(gridDim.x >> 3) + (b >> 3);
+    const int seg = b % a.tsegs; b /= a.tsegs;
+    const int hb = b % a.hblocks;
+    const int n = b / a.hblocks;
+    const int h0 = hb * 4;
+    const int h = h0 + wave;
+    const bool row_ok = h < H;                                                 // wave-uniform
+    const int ts0 = seg * a.tseg_len, ts1 = (ts0 + a.tseg_len < a.T) ? ts0 + a.tseg_len : a.T;
+    const int nf = ts1 - ts0 + 2;
+    const int tin_first = ts0 + a.t_lo;
+
+    // weights: A fragments.  MFMA row = lane & 31 -> (dt, dw, co); k-step ks = (quarter * 3 + dh) * 2 + j covers channels quarter * 32 + j * 16 ..
+    bf16x8_t wf[24];
+    {
+        int dt, sl;
+        if (n32 < 24) { dt = n32 >> 3; sl = n32 & 7; } else { dt = n32 - 24; sl = 8; }
+        const int dw = sl / 3, co = sl - 3 * dw;
+        const bool used = n32 < 27;
+        const bf16_t* wrow = a.wpack + (4 * (used ? dt : 0) + co) * NOUT_WROW + dw * 128 + kh * 8;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(wrow + dh * 384 + q * 32 + j * 16);
+                    if (!used) v = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+                    wf[(q * 3 + dh) * 2 + j] = v;
+                }
+    }
+    float bias_r[3] = {0.f, 0.f, 0.f};
+    if (a.bias) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) if (c < a.cout) bias_r[c] = a.bias[c];
+    }
+    // pin the completion of these loads HERE (see the kernel above: counted vmcnt and the inline-asm DMA stream)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) asm volatile("" : "+v"(bias_r[c]));
+#pragma unroll
+    for (int ks = 0; ks < 24; ++ks) asm volatile("" : "+v"(wf[ks]));
+
+    // DMA piece d = wave + 4 i: tile row d / DPR, pixels 16 (d % DPR) .. + 15; lane -> pixel + (lane >> 2), LDS slot lane & 3 holds chunk slot ^ key(pixel)
+    unsigned dma_off[DPW];
+#pragma unroll
+    for (int i = 0; i < DPW; ++i) {
+        const int d = wave + 4 * i;
+        const int rr = d / DPR, p = (d % DPR) * 16 + (lane >> 2);
+        const int hin = h0 - 1 + rr;
+        const bool ok = hin >= 0 && hin < H && p < W;
+        dma_off[i] = ok ? (unsigned)((hin * W + p) * 256 + (((lane & 3) ^ ((p >> 2) & 3)) << 4)) : 0xffffffffu;
+    }
+    const char* const zero_ptr = reinterpret_cast<const char*>(g_zero_page_n) + (lane & 3) * 16;
+    // fragment reads: B column = pixel n32 (+ 32 for the second tile), 8 channels kh of k-step j: chunk (2 j + kh) ^ key
+    const unsigned key = (unsigned)((n32 >> 2) & 3);
+    const unsigned rd0 = (unsigned)((wave * PXR + n32) * 64) + (((unsigned)kh ^ key) << 4);
+    const unsigned rd1 = (unsigned)((wave * PXR + n32) * 64) + (((unsigned)(2 + kh) ^ key) << 4);
+
+    auto issue_stage = [&](int f, int q, int buf) {
+        const int tin = tin_first + f;
+        const bool fv = f < nf && tin >= 0 && tin < a.T;                       // wave-uniform
+        const char* base = reinterpret_cast<const char*>(a.src) + (((long long)n * a.T + (fv ? tin : 0)) * H * W) * 256 + q * 64;
+        const unsigned dst0 = lds0 + (unsigned)buf * STAGE + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < DPW; ++i) {
+            const char* p = (fv && dma_off[i] != 0xffffffffu) ? base + dma_off[i] : zero_ptr;
+            const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(dst0 + i * 4096));
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(p), "s"(dst) : "memory", "m0");
+        }
+    };
+
+    f32x16_t acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+    u32x4_t pend = u32x4_t{0u, 0u, 0u, 0u};
+    int pend_t = -1;
+    const int pcol = lane;                                                     // output column of this lane after the half swap
+    auto flush = [&]() {
+        if (pend_t >= 0 && pcol < W)
+            *reinterpret_cast<u32x4_t*>(a.dst + ((((long long)n * a.T + pend_t) * H + h) * W + pcol) * 8) = pend;
+        pend_t = -1;
+    };
+
+    issue_stage(0, 0, 0);
+    issue_stage(0, 1, 1);
+    int buf = 0;                                                               // buffer of the stage being consumed
+    for (int f = 0; f < nf; ++f) {
+        const int tin = tin_first + f;
+        const bool live = row_ok && tin >= 0 && tin < a.T;                     // wave-uniform
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if constexpr (DPW == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                                      // stage (f, q) landed for everyone; everyone is done with the stage before it
+            asm volatile("" ::: "memory");
+            if (q == 0) flush();                                               // the store goes out BEFORE the next DMA batch (counted wait above)
+            {
+                const int b2 = buf >= 1 ? buf - 1 : 2;                         // (buf + 2) % 3: the buffer the previous stage left
+                issue_stage(f + (q + 2) / 4, (q + 2) & 3, b2);
+            }
+            if (live) {
+                const unsigned vb = lds0 + (unsigned)buf * STAGE;
+                const unsigned a0 = vb + rd0, a1 = vb + rd1;
+                bf16x8_t x[6][NT];
+#pragma unroll
+                for (int dh = 0; dh < 3; ++dh) {
+                    x[2 * dh][0] = (dh == 0) ? nout2_read128<0>(a0) : (dh == 1) ? nout2_read128<ROWB>(a0) : nout2_read128<2 * ROWB>(a0);
+                    if constexpr (NT == 2) x[2 * dh][1] = (dh == 0) ? nout2_read128<2048>(a0) : (dh == 1) ? nout2_read128<ROWB + 2048>(a0) : nout2_read128<2 * ROWB + 2048>(a0);
+                    x[2 * dh + 1][0] = (dh == 0) ? nout2_read128<0>(a1) : (dh == 1) ? nout2_read128<ROWB>(a1) : nout2_read128<2 * ROWB>(a1);
+                    if constexpr (NT == 2) x[2 * dh + 1][1] = (dh == 0) ? nout2_read128<2048>(a1) : (dh == 1) ? nout2_read128<ROWB + 2048>(a1) : nout2_read128<2 * ROWB + 2048>(a1);
+                }
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    // reads complete in order: k-step k needs the first (k + 1) NT of the 6 NT
+                    if constexpr (NT == 2) {
+                        if (k == 0) asm volatile("s_waitcnt lgkmcnt(10)" ::: "memory");
+                        if (k == 1) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+                        if (k == 2) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+                        if (k == 3) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+                        if (k == 4) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+                        if (k == 5) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    } else {
+                        if (k == 0) asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory");
+                        if (k == 1) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+                        if (k == 2) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+                        if (k == 3) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+                        if (k == 4) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
+                        if (k == 5) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    }
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        asm volatile("" : "+v"(x[k][t]));
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[q * 6 + k], x[k][t], acc[t], 0, 0, 0);
+                    }
+                }
+            }
+            buf = buf == 2 ? 0 : buf + 1;
+        }
+        // the quad dt = 2 (registers 8-11, and register 14 for slot 8) now holds out[ts0 + f - 2]: slots 0-3 in lanes 0-31, 4-7 in lanes 32-63
+        if (f >= 2 && row_ok) {
+            float y[9];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float flo = acc[0][8 + r], fhi = acc[NT - 1][8 + r];       // (__builtin_bit_cast of a vector ELEMENT reads element 0: copy first)
+                const unsigned lo = __float_as_uint(flo);
+                const unsigned hi = NT == 2 ? __float_as_uint(fhi) : 0u;
+                const auto sw = __builtin_amdgcn_permlane32_swap(lo, hi, false, false);    // [0]: lower halves of both tiles, [1]: upper halves
+                const unsigned s0 = sw[0], s1 = sw[1];
+                y[r] = __uint_as_float(s0);
+                y[4 + r] = __uint_as_float(s1);
+            }
+            {
+                const float flo = acc[0][14], fhi = acc[NT - 1][14];
+                const unsigned lo = __float_as_uint(flo);
+                const unsigned hi = NT == 2 ? __float_as_uint(fhi) : 0u;
+                const auto sw = __builtin_amdgcn_permlane32_swap(lo, hi, false, false);
+                const unsigned s0 = sw[0];
+                y[8] = __uint_as_float(s0);
+            }
+            float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                if (c < a.cout) o[c] = (nout2_shift<0x138>(y[c]) + y[3 + c]) + (nout2_shift<0x130>(y[6 + c]) + bias_r[c]);
+            pend = pack8(o);
+            pend_t = ts0 + f - 2;
+        }
+        // partial sums move to the next frame tap: quad dt -> quad dt + 1, slot 8: register 12 -> 13 -> 14
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { acc[t][8 + r] = acc[t][4 + r]; acc[t][4 + r] = acc[t][r]; acc[t][r] = 0.f; }
+            acc[t][14] = acc[t][13]; acc[t][13] = acc[t][12]; acc[t][12] = 0.f;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    flush();
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------------------
 // Weight gradients of the two narrow convolutions: stem CausalConv3d(3 -> 128) and head CausalConv3d(128 -> 3) (tokenizer.py:25,172).
 // Both are      G[ch][(tap, c)] += sum_pixels BIG[pixel][ch] * SMALL[pixel + tap][c]              (ch < 128, 27 taps, c < 4)
 // with BIG the 128-channel tensor (stem: the output gradient; head: the input) and SMALL the <= 4-channel one (stem: the input; head:
@@ -573,6 +801,28 @@ extern "C" int genie_conv_narrow_out(const void* src_cl, const void* wpack, cons
     a.src = (const bf16_t*)src_cl; a.wpack = (const bf16_t*)wpack; a.bias = bias; a.dst = (bf16_t*)dst_cl;
     a.N = N; a.T = T; a.H = H; a.W = W; a.cout = cout; a.t_lo = t_lo;
     a.hblocks = (H + 3) / 4;
+    hipStream_t s = (hipStream_t)stream;
+    static const int cut = [] { const char* e = getenv("GENIE_NARROW_OUT_CUT"); return e ? atoi(e) : 2; }();
+    if (W <= 64 && cut == 2) {
+        // second cut: a wave owns a whole image row; 72 KB (W = 64) / 36 KB of LDS: two workgroups per CU
+        a.wblocks = 1;
+        int tsegs = 1;
+        while ((long long)N * a.hblocks * tsegs < 512 && (T + tsegs) / (tsegs + 1) >= 4) ++tsegs;
+        a.tseg_len = (T + tsegs - 1) / tsegs;
+        a.tsegs = (T + a.tseg_len - 1) / a.tseg_len;
+        const long long blocks = (long long)N * a.hblocks * a.tsegs;
+        GENIE_CHECK_ARG(blocks < (1ll << 31), "genie_conv_narrow_out: too many workgroups");
+        static bool configured2 = false;
+        if (!configured2) {
+            GENIE_CHECK_ARG(hipFuncSetAttribute((const void*)conv_narrow_out2_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess,
+                            "hipFuncSetAttribute failed");
+            configured2 = true;
+        }
+        if (W == 64) conv_narrow_out2_kernel<2><<<(unsigned)blocks, 256, 3 * 6 * 64 * 64, s>>>(a);
+        else conv_narrow_out2_kernel<1><<<(unsigned)blocks, 256, 3 * 6 * 32 * 64, s>>>(a);
+        GENIE_CHECK_LAUNCH();
+        return GENIE_OK;
+    }
     a.wblocks = W / 32;
     // every frame segment re-reads two input frames: split time only while the chip is not yet filled twice over
     int tsegs = 1;
@@ -582,7 +832,6 @@ extern "C" int genie_conv_narrow_out(const void* src_cl, const void* wpack, cons
     const long long blocks = (long long)N * a.hblocks * a.wblocks * a.tsegs;
     GENIE_CHECK_ARG(blocks < (1ll << 31), "genie_conv_narrow_out: too many workgroups");
     const int lds = NOUT_NBUF * NOUT_BUF_BYTES;
-    hipStream_t s = (hipStream_t)stream;
     static bool configured = false;
     if (!configured) {
         GENIE_CHECK_ARG(hipFuncSetAttribute((const void*)conv_narrow_out_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess,
