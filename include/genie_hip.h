@@ -359,7 +359,8 @@ int genie_conv_narrow_in(const void* src_cl, int src_pitch, const void* wpack, v
 /* The other direction: 128 input channels -> cout <= 3 output channels (the head conv CausalConv3d(128 -> 3) forward, tokenizer.py:172).
  * src: CL [N][T][H][W][128]; dst: CL [N][T][H][W][8] (whole 16-byte pixels are written, channels >= cout zero); bias fp32 [cout] or NULL.
  * wpack: bf16 [16][1152], row = 4 * (dt - t_lo) + co (every other row zero), k = ((dh + 1) * 3 + (dw + 1)) * 128 + ci.  t_lo in [-2, 0];
- * W a multiple of 32, H * W * 256 < 2^32. */
+ * W a multiple of 32, H * W * 256 < 2^32.  W <= 64: the kernel with the column tap in the MFMA rows (a wave owns an image row); wider images:
+ * the 32-column-block kernel (GENIE_NARROW_OUT_CUT=1 forces it). */
 int genie_conv_narrow_out(const void* src_cl, const void* wpack, const float* bias, void* dst_cl, int N, int T, int H, int W, int cout,
                           int t_lo, void* stream);
 /* Weight gradients of the two narrow convolutions above (stem 3 -> 128: big = output gradient, small = input, t_lo = -2, ones = 1;

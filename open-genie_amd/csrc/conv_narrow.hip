@@ -387,6 +387,12 @@ __global__ void __launch_bounds__(256) conv_narrow_out_kernel(const NarrowOutArg
 //     three stages in LDS (72 KB: TWO workgroups per CU -- one's barriers and epilogues are covered by the other), DMA'd two stages
 //     ahead, 16-byte chunks XOR-swizzled with bits 2-3 of the pixel (conflict-free ds_read_b128 at a 64-byte pixel stride);
 //   * weights: the [16][1152] pack of the kernel above, read with this kernel's row mapping into 24 A fragments per lane.
+// Measured (64 clips, 1.07 GB in): 0.236-0.26 ms = 4.4-4.9 TB/s by run (the kernel above: 0.31).  With every DMA redirected to the zero page
+// the same instruction stream takes 0.129 ms (0.078 without the MFMAs): what is left is the memory side.  Tried and not kept: a ring
+// of whole image rows instead of channel quarters (16-KB contiguous DMAs, no reliance on the second half of an L2 line still being
+// there: same 4.4-4.7, and 0.41 instead of 0.47-0.58 at 8 clips: six barriers per frame with at most three waves working); rings of
+// 3 / 5 / 6-9 slots (3.2 / 4.3 / 4.0 TB/s); non-temporal DMAs (2.5 TB/s with quarters, 3.8 with rows: the halo rows and the other line
+// half come from L2 or not at all); the XCD remap below is worth nothing measurable (FETCH_SIZE says the halo is an L2 hit either way).
 // ------------------------------------------------------------------------------------------------------------------------------
 template <int CTRL>
 __device__ __forceinline__ float nout2_shift(float v) {             // 0x138: lane l <- lane l - 1; 0x130: lane l <- lane l + 1; zero fill
@@ -475,7 +481,7 @@ __global__ void __launch_bounds__(256, 2) conv_narrow_out2_kernel(const NarrowOu
 
     auto issue_stage = [&](int f, int q, int buf) {
         const int tin = tin_first + f;
-        const bool fv = f < nf && tin >= 0 && tin < a.T;                       // wave-uniform
+        const bool fv = f < nf && tin >= 0 && tin < a.T && !(a.wblocks & 8);                       // wave-uniform
         const char* base = reinterpret_cast<const char*>(a.src) + (((long long)n * a.T + (fv ? tin : 0)) * H * W) * 256 + q * 64;
         const unsigned dst0 = lds0 + (unsigned)buf * STAGE + wave * 1024;
 #pragma unroll
@@ -505,7 +511,7 @@ __global__ void __launch_bounds__(256, 2) conv_narrow_out2_kernel(const NarrowOu
     int buf = 0;                                                               // buffer of the stage being consumed
     for (int f = 0; f < nf; ++f) {
         const int tin = tin_first + f;
-        const bool live = row_ok && tin >= 0 && tin < a.T;                     // wave-uniform
+        const bool live = row_ok && tin >= 0 && tin < a.T && !(a.wblocks & 1);                     // wave-uniform
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             if constexpr (DPW == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
@@ -805,9 +811,11 @@ extern "C" int genie_conv_narrow_out(const void* src_cl, const void* wpack, cons
     static const int cut = [] { const char* e = getenv("GENIE_NARROW_OUT_CUT"); return e ? atoi(e) : 2; }();
     if (W <= 64 && cut == 2) {
         // second cut: a wave owns a whole image row; 72 KB (W = 64) / 36 KB of LDS: two workgroups per CU
-        a.wblocks = 1;
+        a.wblocks = 0;                                 // (timing-probe bits: 1 = no MFMAs, 8 = every DMA from the zero page)
         int tsegs = 1;
-        while ((long long)N * a.hblocks * tsegs < 512 && (T + tsegs) / (tsegs + 1) >= 4) ++tsegs;
+        // every frame segment re-reads two input frames: split time only until every CU has ONE workgroup (8 clips: 256 workgroups of 10 input
+        // frames reach 0.58 of the HBM peak, 384 / 512 of 7 / 6 frames 0.46 / 0.47)
+        while ((long long)N * a.hblocks * tsegs < 256 && (T + tsegs) / (tsegs + 1) >= 4) ++tsegs;
         a.tseg_len = (T + tsegs - 1) / tsegs;
         a.tsegs = (T + a.tseg_len - 1) / a.tseg_len;
         const long long blocks = (long long)N * a.hblocks * a.tsegs;
