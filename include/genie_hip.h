@@ -370,6 +370,12 @@ int genie_conv_narrow_out(const void* src_cl, const void* wpack, const float* bi
  * column 108 holds sum_pixels big[p][ch] (the bias gradient of the stem).  W in {32, 64, 128} (W = 32: even H). */
 int genie_conv_narrow_wgrad(const void* big_cl, const void* small_cl, int small_pitch, float* G, int N, int T, int H, int W, int t_lo,
                             int ones, void* stream);
+/* The same pass accumulated straight into the parameter gradients (no G, no scatter afterwards): dW fp32 with the shape of the reference's
+ * nn.Conv3d weight -- stem (stem = 1): (128, cs, 3, 3, 3), dbias [128] (or NULL); head (stem = 0): (cs, 128, 3, 3, 3) with the taps un-flipped
+ * here, dbias [cs] = the plain sum of the output gradient over all pixels (or NULL).  cs = real channels of the narrow tensor (<= 4).
+ * w_channels_last: 0 = dW dense in (co, ci, kt, kh, kw) order, 1 = dense in (co, kt, kh, kw, ci) order (torch.channels_last_3d). */
+int genie_conv_narrow_wgrad_acc(const void* big_cl, const void* small_cl, int small_pitch, float* dW, float* dbias, int N, int T, int H, int W,
+                                int t_lo, int stem, int cs, int w_channels_last, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Losses and optimiser (elementwise.hip).

@@ -621,14 +621,20 @@ struct NarrowWgradArgs {
     int t_lo;               // SMALL frame of tap plane dt = t + t_lo + dt
     int ones;               // 1: column 108 = 1.0
     int nchunks, chunks_per_block;
+    // direct mode (genie_conv_narrow_wgrad_acc): G null, the tile goes straight into the parameter gradients
+    float* dW;              // stem: [128][cs][27], head: [cs][128][27] (fp32, accumulated)
+    float* dbias;           // stem: [128], head: [cs]; or null
+    int stem, cs;           // cs = the narrow side's real channel count (<= 4)
+    int wcl;                // 0: dW in (co, ci, tap) memory order; 1: (co, tap, ci) = torch.channels_last_3d, the layout the modules keep
 };
 
 template <int CW, int RPC>      // chunk = RPC image rows of CW pixels (CW * RPC == 64); W == CW, or W == 128 with CW = 64 (half rows)
 __global__ void __launch_bounds__(256) conv_narrow_wgrad_kernel(const NarrowWgradArgs a) {
     constexpr int IR = RPC + 2, IC = CW + 2, IMG = 3 * IR * IC;            // image pixels (16 B each)
     constexpr int IMG_LOADS = (IMG + 255) / 256;
-    __shared__ __attribute__((aligned(16))) char A_[64 * 256];             // BIG tile  [64 px][128 ch], chunk c of row r at c ^ ((r & 3) << 2)
-    __shared__ __attribute__((aligned(16))) char B_[64 * 256];             // im2col    [64 px][128 cols], same swizzle
+    __shared__ __attribute__((aligned(16))) char AB_[2 * 64 * 256];
+    char* const A_ = AB_;                                                  // BIG tile  [64 px][128 ch], chunk c of row r at c ^ ((r & 3) << 2)
+    char* const B_ = AB_ + 64 * 256;                                       // im2col    [64 px][128 cols], same swizzle
     __shared__ __attribute__((aligned(16))) u32x4_t img[IMG];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -686,6 +692,10 @@ __global__ void __launch_bounds__(256) conv_narrow_wgrad_kernel(const NarrowWgra
         }
     };
     // im2col: item (px, slot): slot < 27 = tap (dt, dh, dw) -> 4 channels of image pixel (dt, px / CW + dh, px % CW + dw); slot 27 = ones column
+    // head conv in direct mode: the bias gradient is the plain sum of SMALL (= dy) -- every pixel is the (dt = -t_lo, dh = 1, dw = 1) tap of
+    // exactly one chunk pixel
+    const int self_slot = (a.G == nullptr && !a.stem && a.dbias) ? -a.t_lo * 9 + 4 : -1;
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
     auto build = [&]() {
 #pragma unroll
         for (int i = 0; i < 7; ++i) {
@@ -696,6 +706,10 @@ __global__ void __launch_bounds__(256) conv_narrow_wgrad_kernel(const NarrowWgra
                 const int dt = slot / 9, dh = (slot / 3) % 3, dw = slot % 3;
                 const u32x4_t p = img[(dt * IR + px / CW + dh) * IC + px % CW + dw];
                 v[0] = p[0]; v[1] = p[1];
+                if (slot == self_slot) {
+                    bsum[0] += __uint_as_float(v[0] << 16); bsum[1] += __uint_as_float(v[0] & 0xffff0000u);
+                    bsum[2] += __uint_as_float(v[1] << 16); bsum[3] += __uint_as_float(v[1] & 0xffff0000u);
+                }
             } else {
                 v[0] = a.ones ? 0x00003F80u : 0u; v[1] = 0u;             // {1.0, 0, 0, 0}
             }
@@ -752,17 +766,76 @@ __global__ void __launch_bounds__(256) conv_narrow_wgrad_kernel(const NarrowWgra
     }
     // D row = BIG channel (registers), col = im2col column (lane & 31)
     const int khalf = lane >> 5;
+    if (a.G) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int r16 = 0; r16 < 16; ++r16) {
-            const int ch = wm * 64 + i * 32 + (r16 & 3) + 8 * (r16 >> 2) + 4 * khalf;
+            for (int r16 = 0; r16 < 16; ++r16) {
+                const int ch = wm * 64 + i * 32 + (r16 & 3) + 8 * (r16 >> 2) + 4 * khalf;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int col = wn * 64 + j * 32 + (lane & 31);
-                if (col < 112) atomicAdd(a.G + ch * 128 + col, acc[i][j][r16]);
+                for (int j = 0; j < 2; ++j) {
+                    const int col = wn * 64 + j * 32 + (lane & 31);
+                    if (col < 112) atomicAdd(a.G + ch * 128 + col, acc[i][j][r16]);
+                }
+            }
+    } else {
+        // direct mode: the tile goes through LDS (the A / B tiles are done) in the ORDER OF THE PARAMETER, 64 BIG channels at a time, and leaves as
+        // contiguous atomics -- scattered 4-byte atomics in the parameter's order straight from the MFMA layout cost 3x the whole kernel
+        float* const stage = reinterpret_cast<float*>(AB_);               // stem: [64 ch][cs][27] (+ [64] bias sums); head: [cs][64 ch][27]
+        const int cs = a.cs, per = 64 * cs * 27;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            __syncthreads();                                              // the MFMA reads of A_ / B_ (half 0) or the previous half's atomics are done
+            if (wm == half) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r16 = 0; r16 < 16; ++r16) {
+                        const int chl = i * 32 + (r16 & 3) + 8 * (r16 >> 2) + 4 * khalf;        // channel inside the half
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const int col = wn * 64 + j * 32 + (lane & 31);
+                            const int tap = col >> 2, c = col & 3;
+                            if (col < 108) {
+                                if (c < cs) {
+                                    const int e = a.stem ? (a.wcl ? (chl * 27 + tap) * cs + c : (chl * cs + c) * 27 + tap)
+                                                         : (a.wcl ? (c * 27 + 26 - tap) * 64 + chl : (c * 64 + chl) * 27 + 26 - tap);
+                                    stage[e] = acc[i][j][r16];
+                                }
+                            } else if (col == 108) {
+                                stage[per + chl] = acc[i][j][r16];
+                            }
+                        }
+                    }
+            }
+            __syncthreads();
+            if (a.stem) {
+                float* const dst = a.dW + (long long)half * per;
+                for (int e = tid; e < per; e += 256) atomicAdd(dst + e, stage[e]);
+                if (a.dbias && tid < 64) atomicAdd(a.dbias + half * 64 + tid, stage[per + tid]);
+            } else {
+                for (int e = tid; e < per; e += 256) {
+                    int d;
+                    if (a.wcl) d = (e >> 6) * 128 + half * 64 + (e & 63);                       // (co, tap) rows of 128 input channels
+                    else { const int c = e / (64 * 27); d = (c * 128 + half * 64) * 27 + (e - c * (64 * 27)); }
+                    atomicAdd(a.dW + d, stage[e]);
+                }
             }
         }
+    }
+    if (self_slot >= 0) {
+        // ONE atomic instruction per workgroup (lanes 0 .. cs - 1, one cache line): per-wave atomics to these three addresses serialise in L2 --
+        // 6144 of them cost 65 us at 8 clips, more than the rest of the kernel
+        float* const red = reinterpret_cast<float*>(img);
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float t = wave_sum(bsum[c]);
+            if (lane == 0) red[wave * 4 + c] = t;
+        }
+        __syncthreads();
+        if (tid < a.cs) atomicAdd(a.dbias + tid, (red[tid] + red[4 + tid]) + (red[8 + tid] + red[12 + tid]));
+    }
 }
 
 }  // namespace
@@ -851,21 +924,20 @@ extern "C" int genie_conv_narrow_out(const void* src_cl, const void* wpack, cons
     return GENIE_OK;
 }
 
-extern "C" int genie_conv_narrow_wgrad(const void* big_cl, const void* small_cl, int small_pitch, float* G, int N, int T, int H, int W, int t_lo,
-                                       int ones, void* stream) {
-    GENIE_CHECK_ARG(big_cl && small_cl && G, "genie_conv_narrow_wgrad: null pointer");
-    GENIE_CHECK_ARG(W == 32 || W == 64 || W == 128, "genie_conv_narrow_wgrad: image width %d not in {32, 64, 128}", W);
-    GENIE_CHECK_ARG(small_pitch >= 4 && small_pitch % 4 == 0, "genie_conv_narrow_wgrad: pitch %d of the narrow tensor", small_pitch);
-    GENIE_CHECK_ARG(N >= 1 && T >= 1 && H >= 1 && t_lo >= -2 && t_lo <= 0, "genie_conv_narrow_wgrad: bad geometry / t_lo %d", t_lo);
-    GENIE_CHECK_ARG(W != 32 || H % 2 == 0, "genie_conv_narrow_wgrad: W = 32 needs an even image height (64-pixel chunks of two rows), got %d", H);
-    NarrowWgradArgs a;
-    a.big = (const bf16_t*)big_cl; a.small_ = (const bf16_t*)small_cl; a.G = G;
-    a.N = N; a.T = T; a.H = H; a.W = W; a.sp = small_pitch; a.t_lo = t_lo; a.ones = ones;
+static int narrow_wgrad_launch(NarrowWgradArgs& a, const char* who, void* stream) {
+    const int N = a.N, T = a.T, H = a.H, W = a.W;
+    GENIE_CHECK_ARG(W == 32 || W == 64 || W == 128, "%s: image width %d not in {32, 64, 128}", who, W);
+    GENIE_CHECK_ARG(a.sp >= 4 && a.sp % 4 == 0, "%s: pitch %d of the narrow tensor", who, a.sp);
+    GENIE_CHECK_ARG(N >= 1 && T >= 1 && H >= 1 && a.t_lo >= -2 && a.t_lo <= 0, "%s: bad geometry / t_lo %d", who, a.t_lo);
+    GENIE_CHECK_ARG(W != 32 || H % 2 == 0, "%s: W = 32 needs an even image height (64-pixel chunks of two rows), got %d", who, H);
     const long long nch = (long long)N * T * H * W / 64;
-    GENIE_CHECK_ARG(nch >= 1 && nch < (1ll << 31), "genie_conv_narrow_wgrad: chunk count");
+    GENIE_CHECK_ARG(nch >= 1 && nch < (1ll << 31), "%s: chunk count", who);
     a.nchunks = (int)nch;
-    // two workgroups per CU (48 KB LDS each), a few rounds for balance; >= 8 chunks per workgroup to amortise the 64-KB atomics tail
-    long long blocks = 1024;
+    // three workgroups fit a CU (42 KB LDS, 162 VGPRs): one full round of 768 when there are >= 16 chunks for each, else two per CU; >= 8 chunks per
+    // workgroup to amortise the 57-KB atomics tail (8 clips: 512 workgroups 0.058 ms, 768 0.063, 1024 0.072; 64 clips: 0.281 / 0.270 / 0.265 stem,
+    // 0.256 / 0.246 / 0.247 head)
+    long long blocks = 768;
+    if (blocks * 16 > nch) blocks = 512;
     if (blocks * 8 > nch) blocks = (nch + 7) / 8;
     a.chunks_per_block = (int)((nch + blocks - 1) / blocks);
     blocks = (nch + a.chunks_per_block - 1) / a.chunks_per_block;
@@ -874,4 +946,25 @@ extern "C" int genie_conv_narrow_wgrad(const void* big_cl, const void* small_cl,
     else conv_narrow_wgrad_kernel<64, 1><<<(unsigned)blocks, 256, 0, s>>>(a);
     GENIE_CHECK_LAUNCH();
     return GENIE_OK;
+}
+
+extern "C" int genie_conv_narrow_wgrad(const void* big_cl, const void* small_cl, int small_pitch, float* G, int N, int T, int H, int W, int t_lo,
+                                       int ones, void* stream) {
+    GENIE_CHECK_ARG(big_cl && small_cl && G, "genie_conv_narrow_wgrad: null pointer");
+    NarrowWgradArgs a;
+    a.big = (const bf16_t*)big_cl; a.small_ = (const bf16_t*)small_cl; a.G = G;
+    a.N = N; a.T = T; a.H = H; a.W = W; a.sp = small_pitch; a.t_lo = t_lo; a.ones = ones;
+    a.dW = nullptr; a.dbias = nullptr; a.stem = 0; a.cs = 0; a.wcl = 0;
+    return narrow_wgrad_launch(a, "genie_conv_narrow_wgrad", stream);
+}
+
+extern "C" int genie_conv_narrow_wgrad_acc(const void* big_cl, const void* small_cl, int small_pitch, float* dW, float* dbias, int N, int T, int H,
+                                           int W, int t_lo, int stem, int cs, int w_channels_last, void* stream) {
+    GENIE_CHECK_ARG(big_cl && small_cl && dW, "genie_conv_narrow_wgrad_acc: null pointer");
+    GENIE_CHECK_ARG(cs >= 1 && cs <= 4 && cs <= small_pitch, "genie_conv_narrow_wgrad_acc: %d channels on the narrow side (1..4, pitch %d)", cs, small_pitch);
+    NarrowWgradArgs a;
+    a.big = (const bf16_t*)big_cl; a.small_ = (const bf16_t*)small_cl; a.G = nullptr;
+    a.N = N; a.T = T; a.H = H; a.W = W; a.sp = small_pitch; a.t_lo = t_lo; a.ones = (stem && dbias) ? 1 : 0;
+    a.dW = dW; a.dbias = dbias; a.stem = stem ? 1 : 0; a.cs = cs; a.wcl = w_channels_last ? 1 : 0;
+    return narrow_wgrad_launch(a, "genie_conv_narrow_wgrad_acc", stream);
 }

@@ -403,30 +403,30 @@ def narrow_wgrad_ok(spec: ConvSpec, x: Tensor, dy: Tensor) -> bool:
 
 
 def conv_narrow_wgrad(x: Tensor, dy: Tensor, spec: ConvSpec, dweight: Tensor, dbias: Optional[Tensor], label: str = '') -> None:
-    """dW (+ dbias) of a narrow conv accumulated from ONE pass over the 128-channel tensor (genie_conv_narrow_wgrad):
-    G[ch][tap * 4 + c] = sum_p big[p][ch] * small[p + tap][c].  Stem: big = dy, small = x, G[co][tap, ci] is dW[co][ci][tap] and column
-    108 the bias gradient.  Head: big = x, small = dy with the taps flipped, G[ci][tap', co] is dW[co][ci][2 - tap']."""
+    """dW (+ dbias) of a narrow conv accumulated from ONE pass over the 128-channel tensor (genie_conv_narrow_wgrad_acc): the kernel forms
+    G[ch][tap * 4 + c] = sum_p big[p][ch] * small[p + tap][c] per workgroup and adds it straight into the parameter gradients.  Stem: big = dy,
+    small = x, G[co][tap, ci] is dW[co][ci][tap], a ones column gives db.  Head: big = x, small = dy, G[ci][tap', co] is dW[co][ci][26 - tap'], db is
+    the plain sum of dy (taken from the centre tap while the im2col tile is built)."""
     n, _, t, h, w = x.shape
-    G = torch.zeros((128, 128), dtype=torch.float32, device=x.device)
     stem = spec.cin <= 4
     big, small = (dy, x) if stem else (x, dy)
     t_lo = -spec.pad_front[0] if stem else spec.pad_front[0] - 2
+    cs = spec.cin if stem else spec.cout
+    wcl = 0 if dweight.is_contiguous() else 1 if dweight.permute(0, 2, 3, 4, 1).is_contiguous() else -1        # channels_last_3d is what the modules keep
+    if wcl < 0 or not (dbias is None or dbias.is_contiguous()):                              # any other strided view: through temporaries
+        dw_c = torch.zeros(dweight.shape, dtype=torch.float32, device=dweight.device)
+        db_c = None if dbias is None else torch.zeros(dbias.shape, dtype=torch.float32, device=dbias.device)
+        conv_narrow_wgrad(x, dy, spec, dw_c, db_c, label)
+        dweight += dw_c
+        if dbias is not None:
+            dbias += db_c
+        return
     t0 = PROFILER.begin() if PROFILER is not None and not PROFILER.only_triple else None
-    _hip.check(_hip.load_library().genie_conv_narrow_wgrad(big.data_ptr(), small.data_ptr(), pitch_of(small), G.data_ptr(), n, t, h, w, int(t_lo),
-                                                           int(stem and dbias is not None), _hip.stream_ptr()), 'genie_conv_narrow_wgrad')
+    # straight into dW / db (the kernel's epilogue knows both parameter layouts): no G tile to zero, no scatter, no torch reduction for the head's bias
+    _hip.check(_hip.load_library().genie_conv_narrow_wgrad_acc(big.data_ptr(), small.data_ptr(), pitch_of(small), dweight.data_ptr(), _hip.ptr(dbias),
+                                                               n, t, h, w, int(t_lo), int(stem), int(cs), wcl, _hip.stream_ptr()), 'genie_conv_narrow_wgrad_acc')
     if t0 is not None:
         PROFILER.end('conv_narrow_wgrad_kernel', label, 2.0 * n * t * h * w * 128 * min(spec.cin, spec.cout) * 27, t0)
-    taps = G[:, :108].view(128, 3, 3, 3, 4)
-    if stem:
-        dweight += taps[..., :spec.cin].permute(0, 4, 1, 2, 3)                  # (co, ci, dt, dh, dw)
-        if dbias is not None:
-            dbias += G[:, 108]
-    else:
-        dweight += taps[..., :spec.cout].flip(1, 2, 3).permute(4, 0, 1, 2, 3)   # (co, ci, dt, dh, dw) <- G[ci][2 - dt, 2 - dh, 2 - dw][co]
-        if dbias is not None:
-            cp = pitch_of(dy)
-            rows = dy.as_strided((n * t * h * w, cp), (cp, 1))                     # the CL storage as (pixels, channel pitch): a view
-            dbias += rows.sum(0, dtype=torch.float32)[:spec.cout]
 
 
 def narrow_out_ok(spec: ConvSpec, x: Tensor) -> bool:

@@ -510,17 +510,24 @@ def test_conv_narrow_wgrad_kernel(G, cin, cout, causal, size):
     spec = G.conv.causal_spec(cin, cout, (3, 3, 3)) if causal else G.conv.same_spec(cin, cout, (3, 3, 3))
     xc, dyc = G.cl.to_cl(x.cuda()), G.cl.to_cl(dy.cuda())
     assert G.conv.narrow_wgrad_ok(spec, xc, dyc)
-    dw = torch.full((cout, cin, 3, 3, 3), 0.5, device='cuda').contiguous(memory_format=torch.channels_last_3d)
-    db = torch.full((cout,), -1.0, device='cuda')
-    G.conv.PROFILER = prof = G.conv.LaunchProfiler()
-    try:
-        G.conv.conv_wgrad(xc, dyc, spec, dw, db)
-    finally:
-        G.conv.PROFILER = None
-    assert 'conv_narrow_wgrad_kernel' in prof.summary(), list(prof.summary())
     sw, sb = wt.grad.abs().max().item(), b.grad.abs().max().item()
-    torch.testing.assert_close(dw.cpu() - 0.5, wt.grad, rtol=1e-3, atol=1e-3 * sw)
-    torch.testing.assert_close(db.cpu() + 1.0, b.grad, rtol=1e-3, atol=1e-3 * sb)
+    # the gradient buffer in the layout the modules keep (channels_last_3d), dense (co, ci, taps), and an arbitrary strided view (through temporaries)
+    for layout in ('channels_last', 'dense', 'strided'):
+        if layout == 'channels_last':
+            dw = torch.full((cout, cin, 3, 3, 3), 0.5, device='cuda').contiguous(memory_format=torch.channels_last_3d)
+        elif layout == 'dense':
+            dw = torch.full((cout, cin, 3, 3, 3), 0.5, device='cuda')
+        else:
+            dw = torch.full((cout, cin, 3, 3, 6), 0.5, device='cuda')[..., ::2]
+        db = torch.full((cout,), -1.0, device='cuda')
+        G.conv.PROFILER = prof = G.conv.LaunchProfiler()
+        try:
+            G.conv.conv_wgrad(xc, dyc, spec, dw, db)
+        finally:
+            G.conv.PROFILER = None
+        assert 'conv_narrow_wgrad_kernel' in prof.summary(), list(prof.summary())
+        torch.testing.assert_close(dw.cpu() - 0.5, wt.grad, rtol=1e-3, atol=1e-3 * sw, msg=lambda m: f'{layout}: {m}')
+        torch.testing.assert_close(db.cpu() + 1.0, b.grad, rtol=1e-3, atol=1e-3 * sb, msg=lambda m: f'{layout}: {m}')
 
 
 TRI_WGRAD_CASES = [
