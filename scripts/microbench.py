@@ -92,6 +92,8 @@ def bench_attn(iters, only=None):
         ('dynamics temporal T=16 C=512', 32, 16, 8, 8, 8, 64, 'time'),
         ('lam temporal T=16 C=256', 1, 16, 64, 64, 4, 64, 'time'),
     ]
+    if os.environ.get('MB_ATTN_CASES'):                    # "name,b,t,h,w,n_head,d_head,mode;..." replaces the table
+        cases = [(f[0], *[int(v) for v in f[1:7]], f[7]) for f in (c.split(',') for c in os.environ['MB_ATTN_CASES'].split(';'))]
     for name, b, t, h, w, nh, dh, mode in cases:
         if only is not None and not any(o in name for o in only):
             continue
