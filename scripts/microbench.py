@@ -29,6 +29,7 @@ PEAK_TF, PEAK_HBM = 2500.0, 8000.0
 RESULTS = []
 FILTER = os.environ.get('MB_FILTER', '')
 NO_WGRAD = os.environ.get('MB_NO_WGRAD', '') == '1'
+NO_RESID, NO_OATTN, NO_LSE = (os.environ.get(k, '') == '1' for k in ('MB_ATTN_NO_RESID', 'MB_ATTN_NO_OATTN', 'MB_ATTN_NO_LSE'))    # forward epilogue probes
 
 
 def timeit(fn, iters, warm=5, reps=3):
@@ -122,7 +123,8 @@ def bench_attn(iters, only=None):
             _hip.check(lib.genie_rotary_layernorm_fwd(P(x), P(u), ntok, c, c, P(table), pos_div, pos_mod, P(gamma), P(beta), 1e-5, P(stats), s), 'ln')
 
         def f_fwd():
-            _hip.check(lib.genie_attention_fwd(P(u), P(u), P(u), P(x), P(out), P(oattn), P(lse), nseq, nh, dh, S, S, qm, qm, qm, scale, causal, c, s), 'fwd')
+            _hip.check(lib.genie_attention_fwd(P(u), P(u), P(u), None if NO_RESID else P(x), P(out), None if NO_OATTN else P(oattn), None if NO_LSE else P(lse),
+                                               nseq, nh, dh, S, S, qm, qm, qm, scale, causal, c, s), 'fwd')
 
         def f_bwd():
             _hip.check(lib.genie_attention_bwd(P(u), P(u), P(u), P(oattn), None, P(dout), P(lse), P(D), P(du), None, None, nseq, nh, dh, S, S,
