@@ -63,7 +63,7 @@ PY
       cp gpurun_out/prof_models_$TAG/${TAG}_models_*_kernel_stats.csv $OUT/ 2>/dev/null ;;
     variants)
       : > $OUT/${TAG}_bench_variants.jsonl
-      for v in "" "--dp-loopback" "--dp-loopback --grad-compress bf16" "--async-wgrad 1"; do
+      for v in "" "--dp-loopback" "--dp-loopback --grad-compress bf16" "--dp-loopback --allreduce rs_ag" "--async-wgrad 1"; do
         timeout 600 python bench.py --no-cpu-baseline $v 2> $OUT/bench_variant.err | grep '^{' | tail -1 > $OUT/bench_variant.json
         python - "$OUT/bench_variant.json" "$v" >> $OUT/${TAG}_bench_variants.jsonl <<'PY'
 import json, sys
