@@ -933,6 +933,8 @@ static int narrow_wgrad_launch(NarrowWgradArgs& a, const char* who, void* stream
     const long long nch = (long long)N * T * H * W / 64;
     GENIE_CHECK_ARG(nch >= 1 && nch < (1ll << 31), "%s: chunk count", who);
     a.nchunks = (int)nch;
+    // (tried: TWO chunks in flight per workgroup in registers -- 200 VGPRs, two workgroups per CU: 0.50 instead of 0.53 at 64 clips, unchanged at 8: the
+    // chunk loop is its own chain of three barriers, the LDS tile store, the im2col build and the transposing reads, not the HBM round trip)
     // three workgroups fit a CU (42 KB LDS, 162 VGPRs): one full round of 768 when there are >= 16 chunks for each, else two per CU; >= 8 chunks per
     // workgroup to amortise the 57-KB atomics tail (8 clips: 512 workgroups 0.058 ms, 768 0.063, 1024 0.072; 64 clips: 0.281 / 0.270 / 0.265 stem,
     // 0.256 / 0.246 / 0.247 head)
