@@ -222,6 +222,8 @@ def side_kernels(batch: int = 64):
             att[r['name']] = {'ms': r['ms'], 'tflops': r['tflops'], 'mfma_frac': r['mfma_frac']}
         elif r['section'] == 'hbm' and 'gbps' in r:
             hbm[r['name']] = {'ms': r['ms'], 'gbps': r['gbps'], 'hbm_frac': r['hbm_frac']}
+            if 'hbm_frac_padded_pitch' in r:             # narrow convs: `hbm_frac` prices SURVEY 8(d)'s (3 + 128) channels, this the 8-channel pitch the kernels move
+                hbm[r['name']]['hbm_frac_padded_pitch'] = r['hbm_frac_padded_pitch']
             if 'hbm_frac_min' in r:                      # against the operation's minimal traffic (1R + 1W forward, 2R + 1W backward)
                 hbm[r['name']].update({'gbps_min': r['gbps_min'], 'hbm_frac_min': r['hbm_frac_min']})
     best = max((v['mfma_frac'] for k, v in att.items() if 'fwd' in k), default=None)
@@ -237,6 +239,27 @@ def side_kernels(batch: int = 64):
                                                 'IS the executed count; causal attention here is temporal, T <= 32, on the packed traffic-bound kernels (priced in GB/s, not TFLOP/s)',
                              'best_fwd_mfma_frac': best, 'best_bwd_mfma_frac': best_bwd, 'kernel_family': fam, 'kernels': att},
             'hbm_kernels': {'peak_gbps': 8000.0, 'bytes': 'what the passes of the call move (stated per entry); *_min: the minimal traffic of the operation', 'kernels': hbm}}
+
+
+def launcher_command(gpus: int, argv, port: int) -> list:
+    """The `torch.distributed.run` command line of `python bench.py --gpus N` started plainly: one rank per GPU of this node, rendezvous on
+    127.0.0.1 (the container hostname may not resolve) -- the same line the driver uses."""
+    return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={gpus}', '--master-addr', '127.0.0.1',
+            '--master-port', str(port), os.path.abspath(__file__), *argv]
+
+
+def become_launcher(gpus: int, argv) -> None:
+    """`python bench.py --gpus N` without a launcher around it: replace this process by the launcher (never run a smaller job under the label)."""
+    import socket
+    if torch.cuda.device_count() < gpus:
+        raise SystemExit(f'bench.py --gpus {gpus}: only {torch.cuda.device_count()} GPU(s) visible; refusing to run a smaller job under that label')
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    # dmabuf IPC is the only kind the host driver supports: without this RCCL's peer mappings fail with hipIpcGetMemHandle: invalid argument
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    cmd = launcher_command(gpus, argv, port)
+    os.execv(cmd[0], cmd)
 
 
 def main():
@@ -260,22 +283,15 @@ def main():
                     help='N > 1: one all_reduce per bucket (default) or an explicit reduce-scatter + all-gather over all ranks (SURVEY.md 5 / 8e)')
     ap.add_argument('--async-wgrad', type=int, default=int(os.environ.get('GENIE_ASYNC_WGRAD', 0)),
                     help='1: weight-gradient kernels on a side stream, overlapping the HBM-bound GroupNorm / element-wise passes of backward (conv launches wait for it); 2: unordered; 0: off')
-    ap.add_argument('--no-other-configs', action='store_true', help='skip the configs[2] / configs[3] side measurements (`other_configs`)')
+    ap.add_argument('--no-other-configs', action='store_true', help='skip the configs[2] / [3] / [4] side measurements (`other_configs`)')
     ap.add_argument('--lam-batch', type=int, default=16)
     ap.add_argument('--dyn-batch', type=int, default=32)
+    ap.add_argument('--genie-batch', type=int, default=4, help='clips of 32x128x128 in the configs[4] side measurement (16 GB each)')
     ap.add_argument('--dp-loopback', action='store_true', help='N = 1 only: run the RCCL bucket all-reduces on a single-rank group (side-stream path on one GPU)')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
-        # launched plainly (`python bench.py --gpus N`): become the launcher -- one rank per GPU, rendezvous on 127.0.0.1
-        import socket
-        if torch.cuda.device_count() < args.gpus:
-            raise SystemExit(f'bench.py --gpus {args.gpus}: only {torch.cuda.device_count()} GPU(s) visible; refusing to run a smaller job under that label')
-        with socket.socket() as sk:
-            sk.bind(('127.0.0.1', 0))
-            port = sk.getsockname()[1]
-        os.execv(sys.executable, [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
-                                  '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__), *sys.argv[1:]])
+        become_launcher(args.gpus, sys.argv[1:])
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -345,6 +361,15 @@ def main():
     # ~4 % but a forward / backward-data kernel's wall time then includes the share of the chip a concurrent weight-gradient kernel
     # took; three more steps OUTSIDE the timed region report that variant next to the headline (`wgrad_side_stream`).
     prof_inorder, side_alt = None, None
+    # what the HIP events around the kw-triple launches cost the headline: three more steps with the profiler off, same
+    # data, same stream -- outside the timed region, reported as `event_overhead`
+    no_events = None
+    if prof is not None and world == 1:
+        t_ne = time.perf_counter()
+        for i in range(3):
+            step(args.warmup + args.steps + i)
+        torch.cuda.synchronize()
+        no_events = (time.perf_counter() - t_ne) / 3 * 1e3
     if prof is not None and world == 1 and not args.no_in_order_pass:
         if GF.ASYNC_WGRAD:                                 # --async-wgrad 1 / 2: the in-order kernel rates next to the timed region
             GF.join_wgrad()
@@ -400,6 +425,11 @@ def main():
                    'final_loss': round(scal[0].item(), 5), 'peak_mem_GB': round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)},
         'model_tflops_per_gpu': round(TRAIN_GFLOP_PER_CLIP * B * args.steps / elapsed / 1e3, 2),
     }
+    if no_events is not None:
+        out['event_overhead'] = {'ms_per_step_without_events': round(no_events, 3), 'video_frames_per_sec_without_events': round(B * CLIP[1] / no_events * 1e3, 2),
+                                 'event_overhead_pct': round((ms_per_step / no_events - 1.0) * 100, 2), 'steps': 3, 'inside_timed_region': False,
+                                 'what': 'the timed region records two HIP events around every kw-triple conv launch (the `roofline` measurement); '
+                                         'these three extra steps run without them'}
     if prof is not None:
         summ = prof.summary()
         dom = max(summ, key=lambda k: summ[k]['ms']) if summ else None      # the kernel variant with the largest share of the step
@@ -464,7 +494,7 @@ def main():
         except Exception:
             pass
     if world == 1 and not args.no_kernel_events and not os.environ.get('GENIE_BENCH_NO_PROBE') and not args.no_other_configs:
-        # BASELINE configs[2] and [3] at chip-filling batches, one training step each on THIS box (a driver-run record
+        # BASELINE configs[2], [3] and [4] at chip-filling batches, one training step each on THIS box (a driver-run record
         # for them): ms per step, units per second and the kernel family with the largest share, priced like `roofline`.  Side
         # measurements AFTER the timed region; the headline above is unaffected.
         try:
@@ -473,7 +503,8 @@ def main():
             torch.cuda.empty_cache()
             import scripts.bench_models as bm
             oc = {}
-            for key, fn, b in (('configs[2] LatentAction', bm.bench_lam, args.lam_batch), ('configs[3] DynamicsModel', bm.bench_dyn, args.dyn_batch)):
+            for key, fn, b in (('configs[2] LatentAction', bm.bench_lam, args.lam_batch), ('configs[3] DynamicsModel', bm.bench_dyn, args.dyn_batch),
+                                ('configs[4] Genie 32x128x128', bm.bench_genie4, args.genie_batch)):
                 r = bm.run_quiet(fn, b)
                 oc[key] = {'model': r['model'], 'batch': b, 'ms_per_step': r['ms_per_step'], 'units_per_s': r['units_per_s'], 'peak_mem_GB': r['peak_mem_GB'],
                            'roofline': r.get('roofline'), 'top_kernels': dict(list(r.get('kernels', {}).items())[:4])}
@@ -482,6 +513,16 @@ def main():
             out['other_configs'] = {'error': f'{type(ex).__name__}: {ex}'}
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline()
+        # the GPU boxes have no copy of the reference, so the on-box figure is the oracle port; the REAL reference modules timed in the build
+        # container (scripts/cpu_baseline_reference.py, committed) ride along so that the line carries both kinds
+        recs = {int(mt.group(1)): f for f in os.listdir(os.path.join(ROOT, 'profiles')) for mt in [re.match(r'r(\d+)_cpu_baseline_reference\.json$', f)] if mt}
+        if recs and out['cpu_baseline'].get('kind') != 'reference':
+            try:
+                rr = json.load(open(os.path.join(ROOT, 'profiles', recs[max(recs)])))
+                out['cpu_baseline']['reference_record'] = {'value': rr['value'], 'unit': rr['unit'], 'cores': rr['cores'], 'kind': rr['kind'],
+                                                           'sample': rr['sample'], 'file': 'profiles/' + recs[max(recs)], 'measured': 'build container, not this box'}
+            except Exception:
+                pass
     if world > 1 or dist.is_initialized():
         dist.destroy_process_group()
     # RCCL prints its version banner through C stdio; when stdout is a file that buffer is flushed at exit, i.e. AFTER Python's prints:

@@ -236,8 +236,12 @@ class DevicePrefetcher:
     """Iterate a loader with the NEXT batch's host -> device copy already in flight on a side stream (pinned source memory, so the
     copy is a real DMA that overlaps kernels).  On a CPU-only box it is a plain pass-through."""
 
-    def __init__(self, loader, device=None) -> None:
+    def __init__(self, loader, device=None, decode_u8: Optional[bool] = None) -> None:
+        """`decode_u8`: turn 5-D uint8 tensors -- raw (N, T, H, W, C) frames -- into the models' CL bf16 (N, C, T, H, W) / 255 on the device.  Opt-in:
+        the default (None) follows the loader's dataset tag (``dataset.device_decode``, set by ``Platformer2D(device_decode=True)``); a uint8 mask or
+        label tensor of some other dataset is never reinterpreted on dtype and rank alone."""
         self.loader = loader
+        self.decode_u8 = bool(getattr(getattr(loader, 'dataset', None), 'device_decode', False)) if decode_u8 is None else bool(decode_u8)
         self.device = torch.device(device) if device is not None else (torch.device('cuda', torch.cuda.current_device()) if torch.cuda.is_available() else None)
         self.stream = torch.cuda.Stream(self.device) if self.device is not None and self.device.type == 'cuda' else None
 
@@ -248,7 +252,7 @@ class DevicePrefetcher:
         if not isinstance(b, Tensor):
             return b
         d = b.to(self.device, non_blocking=True)
-        if d.dtype == torch.uint8 and d.dim() == 5:          # (N, T, H, W, C) raw frames of Platformer2D(device_decode=True): -> CL bf16 (N, C, T, H, W) / 255
+        if self.decode_u8 and d.dtype == torch.uint8 and d.dim() == 5:          # (N, T, H, W, C) raw frames of Platformer2D(device_decode=True): -> CL bf16 (N, C, T, H, W) / 255
             d = decode_frames_on_device(d)
         return d
 

@@ -226,6 +226,17 @@ class ParamArena:
             self._refresh_packs()
 
 
+class _HostEvent:
+    """time.perf_counter() with torch.cuda.Event's elapsed_time() interface (milliseconds): DataParallel's trace on host tensors."""
+
+    def __init__(self) -> None:
+        import time
+        self.t = time.perf_counter()
+
+    def elapsed_time(self, other: '_HostEvent') -> float:
+        return (other.t - self.t) * 1e3
+
+
 class DataParallel:
     """Clip-sharded data parallelism over the gradient arena.  One process per GPU; ``torch.distributed`` is
     initialised by the caller (``nccl`` = RCCL on the GPUs, ``gloo`` in the CPU tests of the bookkeeping).
@@ -325,7 +336,15 @@ class DataParallel:
                     e1 = torch.cuda.Event(enable_timing=True); e1.record(self.comm_stream)
                     tr['comm'][lo] = (e0, e1)
         else:
+            # host tensors (the gloo tests): the collective is synchronous; host clocks stand in for the HIP events so that comm_report()
+            # has the same schema on every backend
+            tr = self._trace_step() if self.trace else None
+            t0 = _HostEvent() if tr is not None else None
+            if tr is not None:
+                tr['issue'][lo] = t0
             self._all_reduce_mean(chunk, lo)
+            if tr is not None:
+                tr['comm'][lo] = (t0, _HostEvent())
 
     def _trace_step(self) -> dict:
         if self._cur is None:
@@ -353,6 +372,12 @@ class DataParallel:
                 tr['wait'] = (w0, w1)
                 self._events.append(tr)
                 self._cur = None
+        elif self.trace and self.active:                 # host path: nothing is left to wait for at this point
+            tr = self._trace_step()
+            w = _HostEvent()
+            tr['wait'] = (w, w)
+            self._events.append(tr)
+            self._cur = None
         self._done = [False] * len(self.buckets)
         self.last_fired, self.fired = self.fired, []
         if hasattr(self, 'armed'):
@@ -511,10 +536,13 @@ class Trainer:
 
     def __init__(self, max_epochs: int = 1, max_steps: int = -1, log_every_n_steps: int = 16, val_check_interval: int | None = None,
                  limit_val_batches: int | None = None, default_root_dir: str = 'runs', grad_compress: Optional[str] = None, grad_algorithm: str = 'allreduce',
-                 graph: bool = False, grad_buckets: int = 8, **ignored) -> None:
+                 graph: bool = False, grad_buckets: int = 8, device_state_adamw: bool = False, **ignored) -> None:
         # graph: after two eager steps the training step (forward, backward, AdamW) is captured in a hipGraph and replayed per batch
         # (genie/graph.py; single-GPU runs, batches of the captured shape -- anything else takes the eager path)
         self.graph = bool(graph)
+        # device_state_adamw: the eager steps use the capture-safe AdamW (hyper-parameters read from device memory) as well -- the arithmetic
+        # of a graph=True run without the graph, for A/B runs that must agree bit for bit (tests/test_gpu_graph.py)
+        self.device_state_adamw = bool(device_state_adamw)
         self.grad_buckets = max(1, int(grad_buckets))
         self.max_epochs, self.max_steps = max_epochs, (max_steps if max_steps and max_steps > 0 else None)
         self.log_every_n_steps, self.val_check_interval, self.limit_val_batches = max(1, log_every_n_steps), val_check_interval, limit_val_batches
@@ -635,8 +663,9 @@ class Trainer:
                              'otherwise: `graph_capture_safe`); a replayed hipGraph would repeat it.  Train it eagerly.')
         gstep, eager_steps = None, 0
         side = None
-        if use_graph:
+        if use_graph or self.device_state_adamw:
             arena.set_graph_hyperparameters(hp['lr'], hp['weight_decay'])
+        if use_graph:
             # everything before the capture runs on a NON-default stream: autograd remembers the stream every parameter's gradient was
             # last accumulated on and synchronises with it during backward -- with the legacy default stream that is illegal inside a capture
             side = torch.cuda.Stream(device=dev)
@@ -675,7 +704,7 @@ class Trainer:
                     loss = model.training_step(batch, i)
                     loss.backward()
                     dp.finish()
-                    arena.adamw_step(**hp, graph_safe=use_graph)
+                    arena.adamw_step(**hp, graph_safe=use_graph or self.device_state_adamw)
                     eager_steps += 1
                     self._train_logged = dict(getattr(model, '_last_logged', {}))
                 self.global_step += 1

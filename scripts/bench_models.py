@@ -9,7 +9,7 @@ resident in HBM.  Each line also carries
   cpu_baseline -- (`--cpu-baseline`, configs[2] / [3]) the same training step on the host cores, ONE step after one warm-up: the reference's own
                   modules where /root/reference exists and the model can be built from them (kind "reference"), else the oracle (kind "port")
 
-  python scripts/bench_models.py [lam] [dyn] [repr] [genie4] [smallbatch] [--cpu-baseline] [--lam-batch=16] [--dyn-batch=32]
+  python scripts/bench_models.py [lam] [dyn] [repr] [genie4] [smallbatch] [--cpu-baseline] [--lam-batch=16] [--dyn-batch=32] [--genie-batch=4]
 Batches (round 5): LatentAction 16 clips, DynamicsModel 32 token grids per step -- chip-filling; rounds 1-4 ran 2 / 4 (the vocabulary head's
 logits were materialised then: 0.5 GB per grid and 2^31 elements at most, i.e. 8 grids).
 (`smallbatch`: the tokenizer step at 4 / 8 clips and the LatentAction step, eager launches vs one hipGraph replay)
@@ -152,6 +152,21 @@ def bench_dyn(B, want_cpu=False, quiet=False, steps=4):
                cpu=cpu_step(dyn_cpu, 2 * 16, 'latent frames/sec (two (16,8,8) token grids)', build_ref=dyn_ref) if want_cpu else None, quiet=quiet)
 
 
+def bench_genie4(B, want_cpu=False, quiet=False, steps=3):
+    """BASELINE configs[4]: full Genie on 32x128x128 clips -- frozen MAGVIT2 tokenizer (8x16x16 tokens of 2^18 codes), latent-action model
+    over 32 frames of 128x128 pixels (spatial attention over S = 16384 positions), MaskGIT dynamics.  B >= 2 (a batch of one dies in the
+    reference's mask.squeeze() indexing, dynamics.py:89-97, and so does it here); 16 GB of HBM per clip: B = 4 is 64 GB, as much as the headline's step."""
+    tokz = VideoTokenizer(MAGVIT2_ENC_DESC, MAGVIT2_DEC_DESC, d_codebook=18, gan_loss_weight=0., perc_loss_weight=0.).cuda().eval()
+    gen = Genie(tokz, inp_shape=(128, 128)).cuda().train()
+    gen.tokenizer.eval()
+    v = torch.randn(B, 3, 32, 128, 128, device='cuda')
+    out = run(f'Genie (configs[4]: frozen MAGVIT2 tokenizer + R-lam + dynamics, 32x128x128, B={B}) [frames/s]', gen,
+              lambda: gen.compute_loss(v)[0], B * 32, steps=steps, warm=1, quiet=quiet)
+    del gen, tokz
+    torch.cuda.empty_cache()
+    return out
+
+
 def run_quiet(fn, batch):
     """bench.py's entry: one of bench_lam / bench_dyn without the JSON print, fewer steps."""
     torch.manual_seed(0)
@@ -176,17 +191,7 @@ def main():
         v = torch.randn(B, 3, 16, 64, 64, device='cuda')
         res.append(run(f'VideoTokenizer REPR_TOK (8+8 ST blocks, C=512, 16x16x16 latent, B={B}) [frames/s]', tokz, lambda: tokz(v)[0], B * 16))
     if 'genie4' in which:
-        # BASELINE configs[4]: full Genie on 32x128x128 clips -- frozen MAGVIT2 tokenizer (8x16x16 tokens of 2^18 codes), latent-action
-        # model over 32 frames of 128x128 pixels (spatial attention over S = 16384 positions), MaskGIT dynamics; two clips per GPU
-        # (a batch of one dies in the reference's mask.squeeze() indexing, dynamics.py:89-97, and so does it here)
-        B = 2
-        tokz = VideoTokenizer(MAGVIT2_ENC_DESC, MAGVIT2_DEC_DESC, d_codebook=18, gan_loss_weight=0., perc_loss_weight=0.).cuda().eval()
-        gen = Genie(tokz, inp_shape=(128, 128)).cuda().train()
-        gen.tokenizer.eval()
-        v = torch.randn(B, 3, 32, 128, 128, device='cuda')
-        res.append(run(f'Genie (configs[4]: frozen MAGVIT2 tokenizer + R-lam + dynamics, 32x128x128, B={B}) [frames/s]', gen,
-                       lambda: gen.compute_loss(v)[0], B * 32, steps=3, warm=1))
-        del gen, tokz
+        res.append(bench_genie4(opt.get('--genie-batch', 4)))
     if 'smallbatch' in which:
         # what an 8-GPU STRONG-scaling run sees per GPU: the MAGVIT2 tokenizer step at 4 / 8 clips and the LatentAction
         # step, issued from Python launch by launch vs one replay of the captured hipGraph (genie/graph.py); `host_issue_ms` = how long

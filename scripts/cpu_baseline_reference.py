@@ -3,7 +3,9 @@
 doing the benchmark's training step on this container's host cores.  /root/reference does not exist on the GPU boxes (their bench line
 carries kind = "port", the oracle restatement), so this record is taken in the build container and committed next to it:
 
-    python scripts/cpu_baseline_reference.py  ->  profiles/r04_cpu_baseline_reference.json"""
+    python scripts/cpu_baseline_reference.py [r06]  ->  profiles/r06_cpu_baseline_reference.json
+
+bench.py echoes the newest committed record next to the on-box port (`cpu_baseline.reference_record`)."""
 import json
 import os
 import platform
@@ -19,7 +21,8 @@ def main():
     r = bench.cpu_baseline(budget_s=600.0)
     r['host'] = {'cpus': os.cpu_count(), 'machine': platform.processor() or platform.machine(),
                  'where': 'build container (no GPU); /root/reference modules through oracle/ref_import.py'}
-    out = os.path.join(ROOT, 'profiles', 'r04_cpu_baseline_reference.json')
+    tag = sys.argv[1] if len(sys.argv) > 1 else 'r06'
+    out = os.path.join(ROOT, 'profiles', f'{tag}_cpu_baseline_reference.json')
     json.dump(r, open(out, 'w'), indent=1)
     print(json.dumps(r))
 

@@ -16,6 +16,7 @@
 #            gradients on a side stream -- the side measurements DESIGN.md quotes next to the default line
 #                                                                          -> <tag>_bench_variants.jsonl
 #   guard    kernel-level suite under guard-page allocations, two file orders + the deliberate-overrun regression -> <tag>_guard_*.log
+#   multigpu bench.py --gpus 2 (both all-reduce algorithms, bf16 payload) + the two-rank RCCL test, where two GPUs exist -> <tag>_bench_gpus2.jsonl
 #   pmc      SQ counters of the attention families and of the dominant conv layer (separate rocprofv3 passes)
 #                                                                          -> <tag>_pmc_attn.txt, <tag>_pmc_conv.txt
 # (Rounds 1-3 used one-off scripts/exp_r*.sh files for the same jobs; they are in the history up to commit 7bfe1bc.)
@@ -88,8 +89,23 @@ PY
       F2="tests/test_gpu_linear_ce.py tests/test_gpu_maskgit.py tests/test_gpu_golden.py tests/test_gpu_attention.py tests/test_gpu_kernels.py"
       timeout 1500 python scripts/guard_run.py $F1 -q -m gpu -p no:cacheprovider -x 2>&1 | tail -6 > $OUT/${TAG}_guard_order1.log
       timeout 1500 python scripts/guard_run.py $F2 -q -m gpu -p no:cacheprovider -x 2>&1 | tail -6 > $OUT/${TAG}_guard_order2.log
+      [ -f open-genie_amd/lib/libgenie_hip_oobprobe.so ] || make -C open-genie_amd probe -j 8 > $OUT/make_probe.log 2>&1
       GENIE_GUARD_REGRESSION=1 timeout 600 python -m pytest tests/test_gpu_guard.py -q -m gpu -p no:cacheprovider 2>&1 | tail -4 > $OUT/${TAG}_guard_regression.log
       tail -2 $OUT/${TAG}_guard_order1.log $OUT/${TAG}_guard_order2.log $OUT/${TAG}_guard_regression.log ;;
+    multigpu)
+      # first contact with more than one GPU (no gpurun box has had two so far): the plain launcher branch of bench.py, both all-reduce
+      # algorithms, fp32 and bf16 payload -> <tag>_bench_gpus2.jsonl with the `comm` object of each; skipped on a one-GPU box
+      NG=$(python -c "import torch; print(torch.cuda.device_count())")
+      if [ "$NG" -ge 2 ]; then
+        : > $OUT/${TAG}_bench_gpus2.jsonl
+        for v in "" "--allreduce rs_ag" "--grad-compress bf16"; do
+          timeout 900 python bench.py --gpus 2 --steps 6 --warmup 2 $v 2> $OUT/bench_gpus2.err | grep '^{' | tail -1 >> $OUT/${TAG}_bench_gpus2.jsonl
+        done
+        timeout 900 python -m pytest tests/test_gpu_trainer.py -q -m gpu -p no:cacheprovider -k two_rank 2>&1 | tail -3 > $OUT/${TAG}_two_rank_test.log
+        python -c "import json; [print('gpus2:', r['value'], r['ms_per_step'], r.get('comm', {}).get('algorithm'), r.get('comm', {}).get('exposed_ms_per_step')) for r in map(json.loads, open('$OUT/${TAG}_bench_gpus2.jsonl'))]"
+      else
+        echo "multigpu: $NG GPU visible, skipped"
+      fi ;;
     *) echo "unknown stage $st" ;;
   esac
 done

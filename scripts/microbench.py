@@ -175,21 +175,25 @@ def bench_hbm(iters, quick=False, B=None):
     vid = to_cl(torch.randn(B, 3, 16, 64, 64, device='cuda'))
     feat = rand_cl(B, 128, 16, 64, 64)
     npx = B * 16 * 64 * 64
+    # 17.19 MB per clip = (3 + 128) channels x 2 B x 65536 pixels + the 20.7-kB weight tensor; the kernels move the 3-channel tensor at its
+    # padded 8-channel pitch (pricing that pitch flattered the line by 3.8 %) -- reported beside it as gbps_padded_pitch
+    nb, nb_pad = npx * (3 + 128) * 2 + 128 * 3 * 27 * 2, npx * (8 + 128) * 2
+    pad = lambda ms: {'gbps_padded_pitch': round(nb_pad / ms / 1e6, 1), 'hbm_frac_padded_pitch': round(nb_pad / ms / 1e6 / PEAK_HBM, 4)}
     with torch.no_grad():
-        report('hbm', f'stem CausalConv3d 3->128 k3 B={B} fwd', timeit(lambda: stem(vid), iters), flops=2.0 * npx * 128 * 3 * 27,
-               bytes_=npx * (8 + 128) * 2)
-        report('hbm', f'head CausalConv3d 128->3 k3 B={B} fwd', timeit(lambda: head(feat), iters), flops=2.0 * npx * 128 * 3 * 27,
-               bytes_=npx * (8 + 128) * 2)
+        ms = timeit(lambda: stem(vid), iters)
+        report('hbm', f'stem CausalConv3d 3->128 k3 B={B} fwd', ms, flops=2.0 * npx * 128 * 3 * 27, bytes_=nb, **pad(ms))
+        ms = timeit(lambda: head(feat), iters)
+        report('hbm', f'head CausalConv3d 128->3 k3 B={B} fwd', ms, flops=2.0 * npx * 128 * 3 * 27, bytes_=nb, **pad(ms))
         # weight gradients of the two narrow convs: one pass over the 128-channel tensor (+ the 8-channel-pitch narrow one)
         from genie.conv import conv_wgrad
         gy = rand_cl(B, 128, 16, 64, 64)
         dws = torch.zeros_like(stem.conv3d.weight); dbs = torch.zeros(128, device='cuda')
-        report('hbm', f'stem CausalConv3d 3->128 k3 B={B} wgrad', timeit(lambda: conv_wgrad(vid, gy, stem.conv3d.spec, dws, dbs), iters),
-               flops=2.0 * npx * 128 * 3 * 27, bytes_=npx * (8 + 128) * 2)
+        ms = timeit(lambda: conv_wgrad(vid, gy, stem.conv3d.spec, dws, dbs), iters)
+        report('hbm', f'stem CausalConv3d 3->128 k3 B={B} wgrad', ms, flops=2.0 * npx * 128 * 3 * 27, bytes_=nb, **pad(ms))
         g3 = to_cl(torch.randn(B, 3, 16, 64, 64, device='cuda'))
         dwh = torch.zeros_like(head.conv3d.weight); dbh = torch.zeros(3, device='cuda')
-        report('hbm', f'head CausalConv3d 128->3 k3 B={B} wgrad', timeit(lambda: conv_wgrad(feat, g3, head.conv3d.spec, dwh, dbh), iters),
-               flops=2.0 * npx * 128 * 3 * 27, bytes_=npx * (8 + 128) * 2)
+        ms = timeit(lambda: conv_wgrad(feat, g3, head.conv3d.spec, dwh, dbh), iters)
+        report('hbm', f'head CausalConv3d 128->3 k3 B={B} wgrad', ms, flops=2.0 * npx * 128 * 3 * 27, bytes_=nb, **pad(ms))
     if quick:
         return
     # layout conversion + mse

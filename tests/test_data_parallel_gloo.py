@@ -198,6 +198,28 @@ def _sync_worker(rank: int, world: int, port: int, q):
         dist.destroy_process_group()
 
 
+def _comm_worker(rank: int, world: int, port: int, q, algorithm, compress):
+    """DataParallel.trace + comm_report() with two ranks: the N > 1 schema bench.py prints as `comm` -- host clocks
+    stand in for the HIP events on gloo."""
+    _setup(rank, world, port)
+    try:
+        from genie.trainer import DataParallel
+        grads = torch.arange(1001, dtype=torch.float32) * (rank + 1)
+        dp = DataParallel(grads, boundaries=[256, 640], algorithm=algorithm, compress=compress)
+        assert dp.active and dp.comm_report() == {}
+        dp.trace = True
+        for step in range(3):
+            grads.copy_(torch.arange(1001, dtype=torch.float32) * (rank + 1))
+            dp.bucket_ready(2)
+            dp.bucket_ready(1)
+            dp.finish()
+        dp.trace = False
+        dp.finish()                                           # an untraced step does not enter the report
+        q.put((rank, dp.comm_report()))
+    finally:
+        dist.destroy_process_group()
+
+
 def _run(target, extra=()):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
@@ -229,6 +251,23 @@ def test_world_size_2_module_arena_hooks_bf16_compress():
 def test_world_size_2_replica_sync_and_container_stages():
     res = _run(_sync_worker)
     assert res[0][1] == res[1][1]
+
+
+def test_world_size_2_comm_report_schema():
+    """`comm` of the N > 1 bench line: algorithm / payload / world, per-bucket payload + issue lead + duration, exposed time, bus bandwidth
+    -- for both algorithms and both payload types, identical structure on both ranks."""
+    for algorithm, compress, el in (('allreduce', None, 4), ('rs_ag', None, 4), ('allreduce', 'bf16', 2), ('rs_ag', 'bf16', 2)):
+        res = _run(_comm_worker, (algorithm, compress))
+        for rank, rep in res:
+            assert set(rep) == {'algorithm', 'payload', 'world', 'steps_traced', 'exposed_ms_per_step', 'allreduce_ms_per_step', 'hidden_fraction',
+                                'bus_GBps', 'buckets'}, sorted(rep)
+            assert rep['algorithm'] == algorithm and rep['payload'] == ('bf16' if compress else 'fp32') and rep['world'] == 2 and rep['steps_traced'] == 3
+            assert [b['elements'] for b in rep['buckets']] == [256, 384, 361]
+            assert [b['payload_MB'] for b in rep['buckets']] == [round(n * el / 1e6, 1) for n in (256, 384, 361)]
+            assert all(b['allreduce_ms'] > 0 and b['issued_before_backward_end_ms'] >= 0 for b in rep['buckets'])
+            assert rep['allreduce_ms_per_step'] > 0 and rep['exposed_ms_per_step'] >= 0 and rep['hidden_fraction'] is not None
+        import json
+        json.dumps(res[0][1])                                 # the report goes into the bench's JSON line as it is
 
 
 def test_fit_cuts_buckets_like_the_bench():

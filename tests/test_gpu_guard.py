@@ -49,7 +49,7 @@ def test_guard_catches_the_round4_chan_sum_overrun():
     16 bytes read behind the last pixel of the last group.  Without the harness that read hit whatever the caching allocator had placed there;
     under it the process dies -- deterministically."""
     lib = os.path.join(ROOT, 'open-genie_amd', 'lib', 'libgenie_hip_oobprobe.so')
-    assert os.path.exists(lib), 'make -C open-genie_amd builds it'
+    assert os.path.exists(lib), 'make -C open-genie_amd probe builds it (here, before gpurun ships the tree)'
     for _ in range(2):
         r = _run_case(lib)
         assert r.returncode != 0 and 'guard case ok' not in r.stdout, (r.returncode, r.stdout[-300:])

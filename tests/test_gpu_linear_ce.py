@@ -155,9 +155,50 @@ def test_linear_ce_matches_the_materialising_path():
     for n, p in m.named_parameters():
         if p.grad is not None and p.grad.abs().max() > 0:
             assert rel_rms(g_f[n], p.grad) < 3e-2, (n, rel_rms(g_f[n], p.grad))
+    ws_train = GF._LinearCEFn.last_ws_floats
     with torch.no_grad():
         ev = m.compute_loss(tok, act, mask=mask)
     assert abs(ev.item() - fused.item()) < 1e-5 * abs(fused.item())
+    # needs_input_grad mirrors requires_grad, not the grad mode: the evaluation pass must have asked for the lse-only workspace
+    assert GF._LinearCEFn.last_ws_floats < ws_train, (GF._LinearCEFn.last_ws_floats, ws_train)
+
+
+def test_linear_ce_frozen_weight_trainable_bias_and_deterministic_mode():
+    """ A frozen head weight next to a trainable bias must not get a .grad; deterministic mode must route around the fused
+    operator (its loss / dW reductions are fp32 atomics) and give bit-identical loss and head gradients run to run."""
+    from genie import functional as GF, conv as GC
+    from genie.dynamics import DynamicsModel
+    torch.manual_seed(5)
+    desc = (('space-time_attn', {'n_rep': 1, 'n_head': 2, 'd_head': 32}),)
+    m = DynamicsModel(desc, tok_vocab=1000, act_vocab=5, embed_dim=64).cuda().train()
+    tok, act = torch.randint(0, 1000, (2, 4, 8, 8)).cuda(), torch.randint(0, 5, (2, 4)).cuda()
+    mask = (torch.rand(2, 4, 8, 8) < 0.75).cuda()
+    m.head.weight.requires_grad_(False)
+    m.compute_loss(tok, act, mask=mask).backward()
+    assert m.head.weight.grad is None and m.head.bias.grad is not None and m.head.bias.grad.abs().max() > 0
+    gb_frozen = m.head.bias.grad.clone()
+    m.head.weight.requires_grad_(True)
+    m.zero_grad(set_to_none=True)
+    m.compute_loss(tok, act, mask=mask).backward()
+    assert rel_rms(gb_frozen, m.head.bias.grad) < 1e-5
+    m.zero_grad(set_to_none=True)
+    old = GC.set_deterministic(True)
+    try:
+        xr = torch.zeros(128, 64, dtype=torch.bfloat16, device='cuda')
+        assert not GF.linear_ce_supported(xr, m.head.weight)
+        runs = []
+        for _ in range(3):
+            m.zero_grad(set_to_none=True)
+            loss = m.compute_loss(tok, act, mask=mask)
+            loss.backward()
+            runs.append((loss.detach().clone(), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}))
+        for l, g in runs[1:]:
+            assert torch.equal(l, runs[0][0])
+            for n in g:
+                if not n.endswith('_emb.weight'):          # (the embedding tables' gradient is a scatter-add of its own, tested where it lives)
+                    assert torch.equal(g[n], runs[0][1][n]), n
+    finally:
+        GC.set_deterministic(old)
 
 
 @pytest.mark.parametrize('rows', [1024, 3000])

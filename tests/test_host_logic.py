@@ -2,6 +2,7 @@
 parameter arena, clip sharding, and the loud failure of the product path on CPU tensors."""
 import copy
 import os
+import sys
 
 import pytest
 import torch
@@ -229,3 +230,42 @@ def test_tri_executed_fraction_matches_the_kernels_trim_rule():
     assert tri_executed_fraction((0, 0, 18), 16, 1024, 16384, 256) == 1.0 and tri_executed_fraction(None, 16, 1024, 16384, 256) == 1.0
     # 128-row tiles on a 16 x 16 frame: two tiles per frame, both inside it
     assert abs(tri_executed_fraction((3, -1, 9), 8, 256, 2 * 8 * 256, 128) - 22 / 24) < 1e-12
+
+
+def test_bench_launcher_branch(monkeypatch):
+    """`python bench.py --gpus N` started without a launcher (this branch had never executed anywhere): it must exec
+    `torch.distributed.run` with one rank per GPU on 127.0.0.1 and the caller's own flags, keep the dmabuf-IPC switch in the environment, and
+    refuse to run when fewer GPUs are visible than the label says."""
+    import bench
+    seen = {}
+
+    class Exec(Exception):
+        pass
+
+    def fake_execv(path, argv):
+        seen['path'], seen['argv'] = path, list(argv)
+        raise Exec()
+    monkeypatch.setattr(bench.os, 'execv', fake_execv)
+    monkeypatch.delenv('WORLD_SIZE', raising=False)
+    monkeypatch.delenv('HSA_ENABLE_IPC_MODE_LEGACY', raising=False)
+    monkeypatch.setattr(bench.torch.cuda, 'device_count', lambda: 8)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '4', '--steps', '3', '--warmup', '1', '--allreduce', 'rs_ag'])
+    with pytest.raises(Exec):
+        bench.main()
+    a = seen['argv']
+    assert seen['path'] == sys.executable and a[:3] == [sys.executable, '-m', 'torch.distributed.run']
+    assert '--nnodes=1' in a and '--nproc-per-node=4' in a
+    assert a[a.index('--master-addr') + 1] == '127.0.0.1' and 1024 <= int(a[a.index('--master-port') + 1]) < 65536
+    script = a.index(os.path.join(ROOT, 'bench.py'))
+    assert a[script + 1:] == ['--gpus', '4', '--steps', '3', '--warmup', '1', '--allreduce', 'rs_ag']      # the ranks see the caller's flags
+    assert os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY') == '0'
+    assert bench.launcher_command(2, ['--gpus', '2'], 1234)[-5:] == ['--master-port', '1234', os.path.join(ROOT, 'bench.py'), '--gpus', '2']
+    # fewer GPUs than the label: refuse
+    monkeypatch.setattr(bench.torch.cuda, 'device_count', lambda: 1)
+    with pytest.raises(SystemExit) as ei:
+        bench.main()
+    assert 'only 1 GPU' in str(ei.value)
+    # a rank started by the launcher with the wrong world size is refused as well (and no GPU here: the product path has no CPU fallback)
+    monkeypatch.setenv('WORLD_SIZE', '4')
+    with pytest.raises(SystemExit):
+        bench.main()
