@@ -435,8 +435,10 @@ int genie_attention_bwd(const void* q, const void* k, const void* v, const void*
  * forward, bit 1 backward dQ, bit 2 backward dK / dV; bit 3: reserved; bit 4: the forward's running maximum is
  * deferred (O, l rescaled only when a tile's maximum exceeds it by more than 2^8 in the exp2 domain; P <= 2^8 instead of <= 1, the row's
  * largest weight is then rounded to bf16 like every other one instead of being exactly 1); bit 5: plain grid instead of the XCD-aware one;
- * bit 6: forward blocks of four waves at every length (default: eight waves from 2048 queries on; bit-identical results).
- * A negative mask only queries.  Returns the previous mask (default 23 = bits 0, 1, 2, 4, or the GENIE_ATTN_LEAN environment variable).
+ * bit 6: forward blocks of four waves at every length (default: eight waves from 2048 queries on; bit-identical results); bit 7 (with bit 4):
+ * sum-triggered form of the deferred maximum -- a tile is exponentiated against the running maximum as it is and redone with its exact
+ * maximum only when a lane's row sum exceeds 2^8 (same bound on P; no per-tile maximum in the steady state).
+ * A negative mask only queries.  Returns the previous mask (default 151 = bits 0, 1, 2, 4, 7, or the GENIE_ATTN_LEAN environment variable).
  * Process-wide; meant for A/B timing and for tests that cover both kernel families and both maximum rules. (ABI 10) */
 int genie_attention_lean_mode(int mask);
 

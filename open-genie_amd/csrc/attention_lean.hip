@@ -86,7 +86,7 @@ __device__ __forceinline__ void attn_static_for(F&& f) {
 // rescaled -- when some lane's tile maximum exceeds it by more than 2^8 in the exp2 domain (defer-max, cdna_hip_programming.md T13):
 // P is then bounded by 2^8 instead of 1, which neither fp32 sums nor bf16 P mind; on i.i.d. scores the exact rule rescales on two
 // tiles out of three (any of 32 queries meeting a new maximum), 35 VALU instructions each, in a loop that is VALU-bound.
-template <int DH, int NW, bool KVSAME, bool DEFER>
+template <int DH, int NW, bool KVSAME, int DEFER>
 __global__ void __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(64 * NW) attn_fwd4_kernel(const AttnArgs a) {
     constexpr int KT = 64, ROWB = DH * 2, CPR = DH / 8, TILE = KT * ROWB, KS = DH / 16, DT = DH / 32;
     constexpr int SLABS = TILE / 1024, LPW = SLABS / NW, LPT = KVSAME ? LPW : 2 * LPW;
@@ -245,7 +245,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(64 
         tmax = attn_xmax32(tmax);
         const float m_new = fmaxf(m_run, tmax);
         // exact rule: any lane's maximum moved.  Deferred rule: some lane's moved by more than 8 / c2 (the first tile always does: m = -1e30)
-        if (__builtin_amdgcn_ballot_w64(DEFER ? (m_new - m_run) * c2 > 8.f : m_new > m_run) != 0) {
+        if (__builtin_amdgcn_ballot_w64(DEFER == 1 ? (m_new - m_run) * c2 > 8.f : m_new > m_run) != 0) {
             const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
             l_run *= alpha;
 #pragma unroll
@@ -314,10 +314,146 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(64 
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     };
+    // DEFER == 2, "sum-triggered" running maximum (round 6).  The deferred rule above still pays the maximum of every tile (24 VALU instructions
+    // of ~150 per tile and lane in a loop that is VALU-issue-bound: 9.9 VALU per MFMA) only to find, on all but the first tiles, that nothing
+    // has to move.  Here a tile is exponentiated against the running maximum AS IT IS; the row sums, which are needed anyway, tell whether that
+    // was legitimate: every p >= 0, so a lane's partial sum <= 2^8 bounds each of its p by 2^8 -- the deferred rule's bound.  Only when some
+    // lane's sum exceeds it (or is inf / NaN: the first tile, m = -1e30) is the tile redone with its exact maximum: scores recomputed (the K
+    // tile is still in its ring slot), maximum, rescale of O and l, exponentials again.  No P V product is issued before the test, so a redo
+    // finds O untouched.  Steady state: no maximum tree, no compare chain -- 113 VALU instructions per tile instead of 150.
+    auto tile_body_s = [&](auto slot_c, int t) {
+        constexpr int SLOT = decltype(slot_c)::value;
+        constexpr int KBASE = SLOT * STAGE, VBASE = KVSAME ? KBASE : KBASE + TILE;
+        const int k0 = t * KT;
+        stage(t + 2, SLOT == 0 ? 2 : SLOT - 1);
+        bool with_max = t == 0;                                    // wave-uniform
+        uint32_t pw[2][8];
+        bf16x4_t vlo[2][2][DT], vhi[2][2][DT];
+        float psum;
+        for (;;) {
+            f32x16_t sacc[2];
+            bf16x8_t kfr[2][KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) kfr[kt][ks] = *reinterpret_cast<const bf16x8_t*>(smem + KBASE + kt * 32 * ROWB + k_off[ks]);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[kt][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[kt][ks], qf[ks], sacc[kt], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            attn_static_for<0, 2>([&](auto s2c) {
+                constexpr int s2 = decltype(s2c)::value;
+#pragma unroll
+                for (int d = 0; d < DT; ++d) {
+                    vlo[0][s2][d] = attn_tr16i<VBASE + (16 * s2) * ROWB>(v_off[d][0]);
+                    vhi[0][s2][d] = attn_tr16i<VBASE + (16 * s2) * ROWB>(v_off[d][1]);
+                }
+            });
+            if ((k0 + KT > a.Sk) || (a.causal && k0 + KT - 1 > q0)) {
+                int lim = a.Sk - k0;
+                if (a.causal) lim = min(lim, qi - k0 + 1);
+                lim -= 4 * h;
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sacc[kt][r] = (kt * 32 + (r & 3) + 8 * (r >> 2)) < lim ? sacc[kt][r] : -INFINITY;
+            }
+            if (with_max) {
+                float tmax;
+                {
+                    float m3[11];
+#pragma unroll
+                    for (int g = 0; g < 10; ++g) {
+                        const int e = 3 * g;
+                        m3[g] = fmaxf(fmaxf(sacc[e >> 4][e & 15], sacc[(e + 1) >> 4][(e + 1) & 15]), sacc[(e + 2) >> 4][(e + 2) & 15]);
+                    }
+                    m3[10] = fmaxf(sacc[1][14], sacc[1][15]);
+                    const float a0 = fmaxf(fmaxf(m3[0], m3[1]), m3[2]), a1 = fmaxf(fmaxf(m3[3], m3[4]), m3[5]);
+                    const float a2 = fmaxf(fmaxf(m3[6], m3[7]), m3[8]), a3 = fmaxf(m3[9], m3[10]);
+                    tmax = fmaxf(fmaxf(fmaxf(a0, a1), a2), a3);
+                }
+                tmax = attn_xmax32(tmax);
+                const float m_new = fmaxf(m_run, tmax);
+                const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
+                l_run *= alpha;
+#pragma unroll
+                for (int d = 0; d < DT; ++d)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+                m_run = m_new;
+            }
+            const float mc = m_run * c2;
+            float ps0, ps1, ps2, ps3;
+            attn_static_for<0, 2>([&](auto ktc) {
+                constexpr int kt = decltype(ktc)::value;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[kt][4 * e + 0], c2, -mc));
+                    const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[kt][4 * e + 1], c2, -mc));
+                    const float p2 = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[kt][4 * e + 2], c2, -mc));
+                    const float p3 = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[kt][4 * e + 3], c2, -mc));
+                    if (kt == 0 && e == 0) { ps0 = p0; ps1 = p1; ps2 = p2; ps3 = p3; }
+                    else { ps0 += p0; ps1 += p1; ps2 += p2; ps3 += p3; }
+                    pw[kt][2 * e] = pack_bf16x2(p0, p1);
+                    pw[kt][2 * e + 1] = pack_bf16x2(p2, p3);
+                }
+            });
+            psum = (ps0 + ps1) + (ps2 + ps3);
+            // (!(x <= 2^8): true for inf and NaN as well)
+            if (with_max || __builtin_amdgcn_ballot_w64(!(psum <= 256.f)) == 0) break;
+            with_max = true;
+        }
+        l_run += attn_xsum32(psum);
+        // second half's V^T fragments: requested in front of the first half's products, they land under them
+        __builtin_amdgcn_sched_barrier(0);
+        attn_static_for<0, 2>([&](auto s2c) {
+            constexpr int s2 = decltype(s2c)::value;
+#pragma unroll
+            for (int d = 0; d < DT; ++d) {
+                vlo[1][s2][d] = attn_tr16i<VBASE + (32 + 16 * s2) * ROWB>(v_off[d][0]);
+                vhi[1][s2][d] = attn_tr16i<VBASE + (32 + 16 * s2) * ROWB>(v_off[d][1]);
+            }
+        });
+        attn_static_for<0, 2>([&](auto ktc) {
+            constexpr int kt = decltype(ktc)::value;
+            if constexpr (kt == 0) asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(4 * DT) : "memory");     // the first half's fragments (older requests) have landed
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                u32x4_t pv4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pv4[e] = pw[kt][4 * s2 + e];
+                const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pv4);
+#pragma unroll
+                for (int d = 0; d < DT; ++d) {
+                    asm volatile("" : "+v"(vlo[kt][s2][d]), "+v"(vhi[kt][s2][d]));
+                    const bf16x8_t vf = __builtin_shufflevector(vlo[kt][s2][d], vhi[kt][s2][d], 0, 1, 2, 3, 4, 5, 6, 7);
+                    oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[d], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LPT) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    auto tile_any = [&](auto slot_c, int t) {
+        if constexpr (DEFER == 2) tile_body_s(slot_c, t); else tile_body(slot_c, t);
+    };
     for (int t = 0; t < ntile; t += 3) {
-        tile_body(std::integral_constant<int, 0>{}, t);
-        if (t + 1 < ntile) tile_body(std::integral_constant<int, 1>{}, t + 1);
-        if (t + 2 < ntile) tile_body(std::integral_constant<int, 2>{}, t + 2);
+        tile_any(std::integral_constant<int, 0>{}, t);
+        if (t + 1 < ntile) tile_any(std::integral_constant<int, 1>{}, t + 1);
+        if (t + 2 < ntile) tile_any(std::integral_constant<int, 2>{}, t + 2);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
@@ -861,8 +997,9 @@ __global__ void __attribute__((amdgpu_waves_per_eu(3, 3))) __launch_bounds__(64 
 // GENIE_ATTN_LEAN / genie_attention_lean_mode: bit 0 forward, bit 1 backward dQ, bit 2 backward dK / dV on the lean kernels (0 sends
 // everything through attention.hip's general kernels -- A/B timing and the tests that compare the two families); bit 3: unused (was:
 // no s_setprio around the MFMA clusters -- measured neutral, profiles/r04_attention_lean_ab.log); bit 6: forward blocks of four waves at every
-// length (default: eight from 2048 queries on); bit 4: deferred running maximum in the forward (see attn_fwd4_kernel)
-#define LEAN_DEFAULT 23      // lean forward + dQ + dK-dV, deferred running maximum
+// length (default: eight from 2048 queries on); bit 4: deferred running maximum in the forward (see attn_fwd4_kernel); bit 7 (with bit 4):
+// the sum-triggered form of it (no per-tile maximum at all in the steady state)
+#define LEAN_DEFAULT 151     // lean forward + dQ + dK-dV, deferred running maximum in its sum-triggered form (bits 0, 1, 2, 4, 7)
 static int g_lean_mode = -1;
 static int lean_mode() {
     if (g_lean_mode < 0) { const char* e = getenv("GENIE_ATTN_LEAN"); g_lean_mode = e ? atoi(e) : LEAN_DEFAULT; }
@@ -870,7 +1007,7 @@ static int lean_mode() {
 }
 extern "C" int genie_attention_lean_mode(int mask) {
     const int old = lean_mode();
-    if (mask >= 0) g_lean_mode = mask & 127;
+    if (mask >= 0) g_lean_mode = mask & 255;
     return old;
 }
 // byte offsets inside a sequence travel as 32-bit buffer offsets / record counts
@@ -911,13 +1048,16 @@ int genie_attn_lean_fwd(const AttnArgs& a_in, hipStream_t s) {
     int lds = 3 * (a.kv_same ? tile : 2 * tile);
     if (lds < nw * 32 * 64 * 4) lds = nw * 32 * 64 * 4;               // the epilogue stages NW x 32 fp32 rows in the ring's memory
     const dim3 grid = lean_grid(a.nseq, a.nhead, qtiles, &a.xcd_swizzle);
-    const bool defer = (lean_mode() & 16) != 0;
+    // running-maximum rule: bit 4 deferred (round 4), bit 7 on top of it sum-triggered (round 6, the default); neither: exact
+    const int defer = (lean_mode() & 16) ? ((lean_mode() & 128) ? 2 : 1) : 0;
 #define LEAN_FWD(NWv)                                                                                    \
     do {                                                                                                 \
-        if (a.kv_same && defer) attn_fwd4_kernel<64, NWv, true, true><<<grid, 64 * NWv, lds, s>>>(a);    \
-        else if (a.kv_same) attn_fwd4_kernel<64, NWv, true, false><<<grid, 64 * NWv, lds, s>>>(a);       \
-        else if (defer) attn_fwd4_kernel<64, NWv, false, true><<<grid, 64 * NWv, lds, s>>>(a);           \
-        else attn_fwd4_kernel<64, NWv, false, false><<<grid, 64 * NWv, lds, s>>>(a);                     \
+        if (a.kv_same && defer == 2) attn_fwd4_kernel<64, NWv, true, 2><<<grid, 64 * NWv, lds, s>>>(a);  \
+        else if (a.kv_same && defer) attn_fwd4_kernel<64, NWv, true, 1><<<grid, 64 * NWv, lds, s>>>(a);  \
+        else if (a.kv_same) attn_fwd4_kernel<64, NWv, true, 0><<<grid, 64 * NWv, lds, s>>>(a);           \
+        else if (defer == 2) attn_fwd4_kernel<64, NWv, false, 2><<<grid, 64 * NWv, lds, s>>>(a);         \
+        else if (defer) attn_fwd4_kernel<64, NWv, false, 1><<<grid, 64 * NWv, lds, s>>>(a);              \
+        else attn_fwd4_kernel<64, NWv, false, 0><<<grid, 64 * NWv, lds, s>>>(a);                         \
     } while (0)
     if (nw == 8) LEAN_FWD(8); else LEAN_FWD(4);
 #undef LEAN_FWD
@@ -968,7 +1108,7 @@ extern "C" int genie_attention_lean_occupancy(int which) {
     int n = -1;
     const int tile = 64 * 64 * 2;
     hipError_t e;
-    if (which == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_fwd4_kernel<64, 4, true, true>, 256, 4 * 32 * 64 * 4);
+    if (which == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_fwd4_kernel<64, 4, true, 2>, 256, 4 * 32 * 64 * 4);
     else if (which == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_bwd_dq3_kernel<64, 4, true>, 256, 3 * tile);
     else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_bwd_dkv3_kernel<64, 4, true>, 256, 3 * (2 * tile + 512));
     if (e != hipSuccess) { genie_set_error("hipOccupancyMaxActiveBlocksPerMultiprocessor: %s", hipGetErrorString(e)); return -1; }

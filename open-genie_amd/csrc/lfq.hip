@@ -538,11 +538,31 @@ __global__ void __launch_bounds__(256) masked_ce_fwd_kernel(const bf16_t* __rest
         if (threadIdx.x == 0) {
             const float lse = M + __logf(S);
             row_lse[r] = lse;
-            const long long t = target[r];
-            // F.cross_entropy raises on a target outside [0, V); a kernel cannot, so the loss is poisoned instead of reading out of bounds
-            atomicAdd(loss_sum, (t >= 0 && t < V) ? lse - bf16_to_f32(row[t]) : __builtin_nanf(""));
         }
     }
+}
+
+// sum over the masked rows of lse - logit[target], in ONE fixed order (thread t takes rows t, t + 1024, ...; fixed tree over the threads; a single
+// writer): the loss is bit-reproducible run to run -- per-row atomics on the one loss word were neither that nor cheap (L2 serialises
+// same-address atomics).  One block; 15 bytes per row.
+__global__ void __launch_bounds__(1024) masked_ce_loss_kernel(const bf16_t* __restrict__ logits, long long pitch, long long nrow, int V,
+                                                              const long long* __restrict__ target, const unsigned char* __restrict__ mask,
+                                                              const float* __restrict__ row_lse, float* __restrict__ loss_sum) {
+    __shared__ float red[1024];
+    float acc = 0.f;
+    for (long long r = threadIdx.x; r < nrow; r += 1024) {
+        if (mask && !mask[r]) continue;
+        const long long t = target[r];
+        // F.cross_entropy raises on a target outside [0, V); a kernel cannot, so the loss is poisoned instead of reading out of bounds
+        acc += (t >= 0 && t < V) ? row_lse[r] - bf16_to_f32(logits[r * pitch + t]) : __builtin_nanf("");
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *loss_sum += red[0];
 }
 
 __global__ void __launch_bounds__(256) masked_ce_bwd_kernel(const bf16_t* __restrict__ logits, long long pitch, long long nrow, int V,
@@ -578,6 +598,7 @@ extern "C" int genie_masked_ce_fwd(const void* logits_bf16, int64_t pitch, int64
     if (nrow == 0) return GENIE_OK;
     const unsigned grid = (unsigned)(nrow < 4096 ? nrow : 4096);
     masked_ce_fwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((const bf16_t*)logits_bf16, pitch, nrow, V, (const long long*)target, mask, row_lse, loss_sum);
+    masked_ce_loss_kernel<<<1, 1024, 0, (hipStream_t)stream>>>((const bf16_t*)logits_bf16, pitch, nrow, V, (const long long*)target, mask, row_lse, loss_sum);
     GENIE_CHECK_LAUNCH();
     return GENIE_OK;
 }

@@ -628,7 +628,7 @@ class _LinearCEFn(torch.autograd.Function):
     h: (M, D) bf16; weight: (V, D) fp32 parameter; wpack: its bf16 forward pack (V, D); bias: (V,) fp32 or None."""
 
     @staticmethod
-    def forward(ctx, h: Tensor, weight: Tensor, bias: Optional[Tensor], wpack: Tensor, target: Tensor, valid: Optional[Tensor]):
+    def forward(ctx, h: Tensor, weight: Tensor, bias: Optional[Tensor], wpack: Tensor, target: Tensor, valid: Optional[Tensor], grad_mode: bool = True):
         lib = _hip.load_library()
         m, d = h.shape
         v = weight.shape[0]
@@ -636,8 +636,9 @@ class _LinearCEFn(torch.autograd.Function):
         assert wp.dtype == torch.bfloat16 and wp.is_contiguous() and wp.shape[1] == d
         tgt = target.reshape(m).to(torch.int64).contiguous()
         vk = None if valid is None else valid.reshape(m).to(torch.uint8).contiguous()
-        # (needs_input_grad mirrors requires_grad, not the grad mode: under no_grad the lse-only sweep is enough)
-        need = torch.is_grad_enabled() and any(ctx.needs_input_grad[:3])
+        # (needs_input_grad mirrors requires_grad, not the grad mode -- and inside forward() the grad mode is always off: the caller's mode
+        # comes in as an argument; under no_grad the lse-only sweep is enough)
+        need = grad_mode and any(ctx.needs_input_grad[:3])
         dev = h.device
         ws_n = lib.genie_linear_ce_ws_floats(m, d, v, int(need))
         ws = workspace(ws_n, dev, 'lce')
@@ -699,13 +700,13 @@ class _LinearCEFn(torch.autograd.Function):
         if prof is not None and gw is not None:
             # algorithmic: d loss / d W = one product of the reference (2 M V D); executed: the scores are recomputed (4 M V D)
             prof.end('linear_ce[mfma]', f'linear_ce bwd dW rows={m} D={d} V={v}', 2.0 * m * v * d, t0, flops_exec=4.0 * m * v * d)
-        return dhb, dw, db, None, None, None
+        return dhb, dw, db, None, None, None, None
 
 
 def linear_cross_entropy(h: Tensor, weight: Tensor, bias: Optional[Tensor], wpack: Tensor, target: Tensor, valid: Optional[Tensor] = None) -> Tensor:
     """mean_{rows with valid} CE(h W^T + b, target) without materialising the (M, V) logits (see ``_LinearCEFn``)."""
     _hip.require_gpu(h, 'linear_cross_entropy')
-    return _LinearCEFn.apply(h, weight, bias, wpack, target, valid)
+    return _LinearCEFn.apply(h, weight, bias, wpack, target, valid, torch.is_grad_enabled())
 
 
 # ------------------------------------------------------------------------------------------------

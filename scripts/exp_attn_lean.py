@@ -3,7 +3,8 @@
 
   mode 0 = attention.hip's general kernels (3 / 2 waves per SIMD at d_head 64)
   mode 7 = attention_lean.hip (4 / 3 waves per SIMD); 1 / 2 / 4 = forward / dQ / dK-dV alone; + 8 = no s_setprio around the MFMA
-  clusters; + 16 = deferred running maximum in the forward; + 32 = plain (sequence * tiles, head) grid instead of the XCD-aware one
+  clusters; + 16 = deferred running maximum in the forward; + 32 = plain (sequence * tiles, head) grid instead of the XCD-aware one;
+  + 128 (with 16) = the sum-triggered form of the deferred maximum (round 6 default: 151)
 
 for the spatial ST-attention shapes of scripts/microbench.py (MFMA-bound: S >= 1024; traffic-bound: S = 256 / 64).  Writes
 gpurun_out/attn_lean_ab.json; every line is also printed."""
@@ -22,14 +23,12 @@ def main():
     lib = _hip.load_library()
     iters = int(os.environ.get('AB_ITERS', 30))
     only = os.environ.get('AB_ONLY', 'spatial S=4096,spatial S=1024,spatial S=256,spatial S=64').split(',')
-    modes = [int(m) for m in os.environ.get('AB_MODES', '0,7,23').split(',')]
+    modes = [int(m) for m in os.environ.get('AB_MODES', '0,23,151').split(',')]
     reps = int(os.environ.get('AB_REPS', 2))
     base_report = mb.report
     rows = []
     for rep in range(reps):
         for mode in modes:
-            if rep >= 1 and mode not in (0, 7, 23):
-                continue
             lib.genie_attention_lean_mode(mode)
 
             def report(section, name, ms, **kw):
@@ -38,7 +37,7 @@ def main():
                     rows.append(mb.RESULTS[-1])
             mb.report = report
             mb.bench_attn(iters, only=only)
-    lib.genie_attention_lean_mode(23)
+    lib.genie_attention_lean_mode(151)
     os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
     with open(os.path.join(ROOT, 'gpurun_out', 'attn_lean_ab.json'), 'w') as f:
         json.dump(rows, f, indent=1)

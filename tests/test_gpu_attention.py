@@ -254,10 +254,11 @@ def test_lean_kernels_keep_their_occupancy():
     assert [lib.genie_attention_lean_occupancy(i) for i in range(3)] == [4, 3, 3]
 
 
-@pytest.mark.parametrize('mode', [7, 7 | 16, 7 | 32, 7 | 16 | 32])
+@pytest.mark.parametrize('mode', [7, 7 | 16, 7 | 32, 7 | 16 | 32, 7 | 16 | 128, 7 | 16 | 32 | 128])
 def test_attention_forward_variants_with_late_maxima(mode):
     """The lean forward's switches (genie_attention_lean_mode bit 4: deferred running maximum; bit 5: plain grid) on scores built to move
-    the maximum LATE and by a lot: a few keys far into the sequence are strongly aligned with particular queries (raw score well above
+    the maximum LATE and by a lot (bit 7: the sum-triggered form of the deferred rule -- a tile is redone with its exact maximum only when a
+    lane's row sum exceeds 2^8): a few keys far into the sequence are strongly aligned with particular queries (raw score well above
     everything before them), others only slightly (growth below the deferral threshold) -- the rescale branch fires in the middle of the
     key loop for some rows of a wave and not for others.  Output and log-sum-exp against fp32 softmax attention, every variant
     (cdna_hip_programming.md T13: a passing check on bounded random scores says nothing about this branch)."""
@@ -273,6 +274,9 @@ def test_attention_forward_variants_with_late_maxima(mode):
     v = torch.randn(nseq, S, c)
     for (qi, ki, gain) in ((5, 700, 6.0), (37, 901, 3.0), (300, 130, 8.0), (1000, 1023, 5.0), (64, 64, 1.5), (511, 333, 1.2)):
         k[:, ki] = q[:, qi] * gain                           # one key per chosen query, far above (or just above) that row's other scores
+    # a whole key tile MODERATELY above one row's running maximum (each score ~5 binades over it, none past the 2^8 of the deferred rule): the
+    # sum-triggered rule (mode bit 7) must fire on the row SUM -- 32 weights of ~2^5 per lane -- where no single weight would have moved the maximum
+    k[:, 640:704] = q[:, 200:201] * 0.8 + 0.05 * torch.randn(nseq, 64, c)
     q, k, v = bf16_round(q), bf16_round(k), bf16_round(v)
     qh = q.reshape(nseq, S, nhead, dh).transpose(1, 2)
     kh = k.reshape(nseq, S, nhead, dh).transpose(1, 2)

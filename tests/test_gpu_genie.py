@@ -131,7 +131,8 @@ def test_genie_configs4_size_parity():
         weight gradient; `proj_out` on the HIP decoder output: reconstruction, MSE, weight / bias gradients;
       * the dynamics term end to end (integer inputs are shared exactly): loss and EVERY parameter gradient against oracle autograd on the
         HIP run's token grid, action ids and the same host-drawn mask.
-    Tolerances are those of the configs[2] / configs[3] tests: 3e-2 relative RMS on activations, 6e-2 on gradients, 1e-2 on the losses."""
+    Tolerances: 1e-2 relative RMS on the stage-fed activations and gradients (measured 0.2-0.3 %), 3e-2 on the end-to-end dynamics gradients
+    (measured <= 0.9 %), 1e-2 on the losses, 4e-2 on the end-to-end latent."""
     import time
     import torch.nn.functional as F
     from genie import LATENT_ACT_DEC, LATENT_ACT_ENC, MAGVIT2_DEC_DESC, MAGVIT2_ENC_DESC, Genie, VideoTokenizer
@@ -196,14 +197,22 @@ def test_genie_configs4_size_parity():
         z = e_ref.movedim(1, -1)                                                         # (1, 8, 16, 16, 18) pre-sign values (no projection at d = input_dim)
         (_, idx_ref), _ = O.lfq_forward(e_ref, sd_tok, 'quant.', 18, 1, training=False, transpose=True)
         idx_ref = idx_ref.reshape(1, 8, 16, 16)
-        margin = 6e-2 * z.pow(2).mean().sqrt()
+        # a token id is 18 sign bits of a latent that went through 27 bf16 layers: a bit may differ from the fp32 oracle's only where the oracle's
+        # pre-sign value is within the end-to-end noise of zero.  Noise = the measured RMS deviation of the latent; 5 sigma of it is the margin.
+        z_hip = e_hip[:1].movedim(1, -1)
+        noise = (z_hip - z).pow(2).mean().sqrt()
+        margin = 5 * noise
+        flipped = (z_hip > 0) != (z > 0)
         safe = (z.abs() >= margin).all(-1)
         res['latent_rel_rms'] = _rr(e_hip[:1], e_ref)
         res['token_safe_fraction'] = safe.float().mean().item()
         res['token_match_rate'] = (tokens[:1] == idx_ref).float().mean().item()
+        res['bits_flipped_fraction'] = flipped.float().mean().item()
+        res['flipped_max_over_noise'] = (z[flipped].abs().max() / noise).item() if flipped.any() else 0.
         assert res['latent_rel_rms'] < 4e-2, res
-        assert safe.float().mean() > 0.2, res
-        assert torch.equal(tokens[:1][safe], idx_ref[safe]), res
+        assert (z[flipped].abs() < margin).all(), res                                    # every differing bit sits inside the noise of zero
+        assert res['bits_flipped_fraction'] < 0.03 and safe.float().mean() > 0.02, res
+        assert torch.equal(tokens[:1][safe], idx_ref[safe]), res                         # ids equal wherever the whole code is decided by a margin
     res['tokens_s'] = round(time.time() - t_start, 1)
 
     # ---- first full-resolution ST block of the LAM encoder -----------------------------------------------------------------------------
@@ -304,10 +313,12 @@ def test_genie_configs4_size_parity():
     res['total_s'] = round(time.time() - t_start, 1)
     report('genie_configs4_size_parity', **res)
     print('configs[4] parity:', res)
+    # measured on the first run: sub-layer outputs and input gradients 0.16-0.28 %, dynamics gradients <= 0.9 % (profiles/r06_parity_report.jsonl)
     for k in ('space_out', 'temp_out', 'ffn_out', 'cond_temp_out', 'recon'):
-        assert res[k] < 3e-2, (k, res)
-    for k in ('space_dx', 'temp_dx', 'cond_temp_dx', 'proj_out_dw', 'proj_out_db', 'proj_out_dx', 'dyn_grad_worst'):
-        assert res[k] < 6e-2, (k, res)
+        assert res[k] < 1e-2, (k, res)
+    for k in ('space_dx', 'temp_dx', 'cond_temp_dx', 'proj_out_dw', 'proj_out_db', 'proj_out_dx'):
+        assert res[k] < 1e-2, (k, res)
+    assert res['dyn_grad_worst'] < 3e-2, res
     assert n_cmp >= 50, n_cmp
     assert abs(loss.item() - (aux['act_loss'] + aux['dyn_loss']).item()) < 1e-4
 
