@@ -838,6 +838,267 @@ __global__ void __launch_bounds__(256) conv_narrow_wgrad_kernel(const NarrowWgra
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Weight gradient, second cut (round 6).  What the counters said about the kernel above (profiles/r05_pmc_narrow_wgrad.txt): matrix pipe 19 %,
+// 8.6 scalar + 9.4 vector instructions per MFMA, 1.9 of 3 waves per SIMD resident, 0.68 bank-conflict cycles per LDS instruction -- a chain of
+// three barriers per 16-KB chunk (LDS store | im2col build | transposing reads + MFMAs) whose links are index arithmetic.  Re-cut:
+//   * NO im2col tile.  ds_read_b64_tr_b16 takes a per-lane address: the lane that owns (k-row = pixel, columns = the 4 channels of tap
+//     (dt, dh, dw)) reads those 8 bytes straight from the zero-bordered IMAGE tile of SMALL at pixel + (dt, dh, dw) -- its offset is a
+//     loop-invariant lane constant plus a compile-time k-step term.  The ones column (bias gradient) and the pad columns read a constant slot.
+//     Gone: 28 KB of LDS traffic, 1792 items of div / mod arithmetic and one barrier per chunk, 16 KB of LDS per workgroup.
+//   * two stages {BIG tile, image} in LDS: chunk c + 1 is written while chunk c is multiplied -- ONE barrier per chunk -- and chunk c + 2
+//     is in flight from HBM in registers meanwhile.
+//   * chunk -> (n, t, h, w) by carries, the image items' (frame, row, column) decoded once per thread.
+// Same arguments, tile layout and epilogue as the kernel above (which stays behind GENIE_NARROW_WGRAD_CUT=1).
+// ------------------------------------------------------------------------------------------------------------------------------
+template <int CW, int RPC, int TEAMS>      // TEAMS teams of four waves share a workgroup: each walks every TEAMS-th chunk of the block's range through its own
+__global__ void __launch_bounds__(256 * TEAMS) conv_narrow_wgrad2_kernel(const NarrowWgradArgs a) {      // two LDS stages; ONE tile of atomics per workgroup at the end
+    constexpr int IR = RPC + 2, IC = CW + 2, IMG = 3 * IR * IC;            // image pixels (8 B each: the first 4 channels)
+    constexpr int IMG_LOADS = (IMG + 255) / 256;
+    constexpr int IMGB = ((IMG * 8 + 15) & ~15) + 16;                      // + the constant slot {1, 0, 0, 0 | 0, 0, 0, 0}
+    constexpr int STG = 64 * 256 + IMGB;
+    extern __shared__ __attribute__((aligned(16))) char smem_all[];        // TEAMS x 2 stages (>= 64 KB for the epilogue's exchange when TEAMS > 1)
+    const int team = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);
+    char* const smem = smem_all + team * (2 * STG);
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int W = a.W, H = a.H, T = a.T;
+    const int halves = W / CW, hb = H / RPC;
+    int c0 = blockIdx.x * a.chunks_per_block, c1 = c0 + a.chunks_per_block;
+    if (c1 > a.nchunks) c1 = a.nchunks;
+    if (c0 >= c1) return;
+    const int niter = (c1 - c0 + TEAMS - 1) / TEAMS;                       // every team runs the same number of barrier rounds
+    c0 += team;                                                           // this team's chunks: c0, c0 + TEAMS, ...
+
+    if (tid < 4) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) reinterpret_cast<uint32_t*>(smem + s * STG + 64 * 256 + IMGB - 16)[tid] = (tid == 0 && a.ones) ? 0x00003F80u : 0u;
+    }
+    // chunk position, advanced by carries: chunks run along w (halves), then h (RPC rows each), then t, n
+    int pn, pt, ph, pw;
+    {
+        int c = c0;
+        pw = c % halves; c /= halves;
+        ph = c % hb; c /= hb;
+        pt = c % T; pn = c / T;
+    }
+    // this thread's image items: (frame f, row r, column cc) of item i * 256 + tid, fixed for the launch
+    int it_f[IMG_LOADS], it_r[IMG_LOADS], it_c[IMG_LOADS];
+#pragma unroll
+    for (int i = 0; i < IMG_LOADS; ++i) {
+        const int li = i * 256 + tid;
+        it_f[i] = li / (IR * IC); it_r[i] = (li / IC) % IR; it_c[i] = li % IC;
+    }
+    const int self_f = (a.G == nullptr && !a.stem && a.dbias) ? -a.t_lo : -1;      // head conv, direct mode: the bias gradient is the plain sum of SMALL
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+    u32x4_t breg[4];
+    u32x2_t ireg[IMG_LOADS];
+    long long big_off = (long long)c0 * (64 * 128);                       // a chunk is 64 consecutive pixels of BIG: 16 KB
+    auto load_chunk = [&]() {                                             // the chunk at (pn, pt, ph, pw) / big_off
+#pragma unroll
+        for (int i = 0; i < 4; ++i)                                       // thread -> (px = i * 16 + tid / 16, 16-B piece tid % 16): 256 B per 16 lanes
+            breg[i] = *reinterpret_cast<const u32x4_t*>(a.big + big_off + (i * 16 + (tid >> 4)) * 128 + (tid & 15) * 8);
+        const int h0 = ph * RPC, w0 = pw * CW;
+#pragma unroll
+        for (int i = 0; i < IMG_LOADS; ++i) {
+            u32x2_t v = u32x2_t{0u, 0u};
+            const int tt = pt + a.t_lo + it_f[i], hh = h0 - 1 + it_r[i], ww = w0 - 1 + it_c[i];
+            if (i * 256 + tid < IMG && (unsigned)tt < (unsigned)T && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W)
+                v = *reinterpret_cast<const u32x2_t*>(a.small_ + ((((long long)pn * T + tt) * H + hh) * W + ww) * a.sp);
+            ireg[i] = v;
+        }
+    };
+    auto advance = [&]() {
+        big_off += 64 * 128 * TEAMS;
+#pragma unroll
+        for (int i = 0; i < TEAMS; ++i)
+            if (++pw == halves) { pw = 0; if (++ph == hb) { ph = 0; if (++pt == T) { pt = 0; ++pn; } } }
+    };
+    auto store_chunk = [&](int s) {
+        char* const A_ = smem + s * STG;
+        char* const I_ = A_ + 64 * 256;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int px = i * 16 + (tid >> 4), ch = tid & 15;
+            *reinterpret_cast<u32x4_t*>(A_ + px * 256 + ((ch ^ ((px & 3) << 2)) << 4)) = breg[i];
+        }
+#pragma unroll
+        for (int i = 0; i < IMG_LOADS; ++i) {
+            if (i * 256 + tid < IMG) {
+                *reinterpret_cast<u32x2_t*>(I_ + (i * 256 + tid) * 8) = ireg[i];
+                if (it_f[i] == self_f && it_r[i] >= 1 && it_r[i] <= RPC && it_c[i] >= 1 && it_c[i] <= CW) {
+                    bsum[0] += __uint_as_float(ireg[i][0] << 16); bsum[1] += __uint_as_float(ireg[i][0] & 0xffff0000u);
+                    bsum[2] += __uint_as_float(ireg[i][1] << 16); bsum[3] += __uint_as_float(ireg[i][1] & 0xffff0000u);
+                }
+            }
+        }
+    };
+    // transposing-read addresses: lane = 16 g + 4 r + q reads k-row 8 (g >> 1) + r (+ 16 k-step, + 4 second read), 4 columns 16 (g & 1) + 4 q .. + 3 of a
+    // 32-wide tile.  A: BIG channels from the swizzled tile.  B: column group = tap 8 (2 wn + j) + 4 (g & 1) + q -- from the image at
+    // pixel + tap offset (8 B per pixel), or from the constant slot (tap 27: ones; taps 28..31: zeros; no k-step term there)
+    const int g16 = lane >> 4, rr = (lane >> 2) & 3, qq = lane & 3;
+    const int krow = 8 * (g16 >> 1) + rr;
+    int a_off[2], b_off[2], b_mul[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int ca = wm * 64 + i * 32 + 16 * (g16 & 1) + 4 * qq;
+        a_off[i] = krow * 256 + (((ca >> 3) ^ (rr << 2)) << 4) + (ca & 7) * 2;
+        const int tap = 8 * (2 * wn + i) + 4 * (g16 & 1) + qq;
+        if (tap < 27) {
+            const int dt = tap / 9, dh = (tap / 3) % 3, dw = tap % 3;
+            b_off[i] = 64 * 256 + ((dt * IR + dh) * IC + dw + krow) * 8;       // (krow < 16 stays inside one image row: 16 | CW)
+            b_mul[i] = 8;
+        } else {
+            b_off[i] = 64 * 256 + IMGB - 16 + (tap == 27 ? 0 : 8);
+            b_mul[i] = 0;
+        }
+    }
+    auto tr16 = [&](const char* p) -> bf16x4_t {
+        return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4_t*)(p));
+    };
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (c0 < c1) {
+        load_chunk();
+        store_chunk(0);
+        advance();
+        if (c0 + TEAMS < c1) load_chunk();
+    }
+    __syncthreads();
+    for (int k = 0; k < niter; ++k) {
+        const int c = c0 + k * TEAMS, s = k & 1;
+        if (c + TEAMS < c1) {
+            store_chunk(s ^ 1);                                           // the team's next chunk (registers) -> the other stage; its last reader passed the barrier below
+            advance();
+            if (c + 2 * TEAMS < c1) load_chunk();                         // the one after: in flight under this chunk's MFMAs and the next store
+        }
+        const char* const S_ = smem + s * STG;
+        if (c < c1)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            // pixel of k-row krow in k-step ks: 16 ks + krow (+ 4) -> image (row (16 ks) / CW, column (16 ks) % CW + krow)
+            constexpr int dummy = 0; (void)dummy;
+            const int kpix = ((16 * ks) / CW) * IC + (16 * ks) % CW;
+            bf16x8_t af[2], bfr[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const bf16x4_t lo = tr16(S_ + ks * 16 * 256 + a_off[i]), hi = tr16(S_ + (ks * 16 + 4) * 256 + a_off[i]);
+                af[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                const bf16x4_t l2 = tr16(S_ + b_off[i] + kpix * b_mul[i]), h2 = tr16(S_ + b_off[i] + (kpix + 4) * b_mul[i]);
+                bfr[i] = __builtin_shufflevector(l2, h2, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();                                                  // stage s is free again; stage s ^ 1 is complete
+    }
+    if (self_f >= 0) {
+        // ONE atomic instruction per team (lanes 0 .. cs - 1, one cache line): per-wave atomics to these three addresses serialise in L2
+        float* const red = reinterpret_cast<float*>(smem);                // (the team's stages are done: the loop ended on a barrier)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float t = wave_sum(bsum[c]);
+            if (lane == 0) red[wave * 4 + c] = t;
+        }
+        __syncthreads();
+        if (tid < a.cs) atomicAdd(a.dbias + tid, (red[tid] + red[4 + tid]) + (red[8 + tid] + red[12 + tid]));
+        __syncthreads();
+    }
+    // the teams' tiles meet in team 0 (through LDS, one team at a time: 64 KB each), which alone runs the epilogue
+    if constexpr (TEAMS > 1) {
+        float* const xch = reinterpret_cast<float*>(smem_all);
+#pragma unroll
+        for (int tm = 1; tm < TEAMS; ++tm) {
+            if (team == tm) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) xch[(((i * 2 + j) * 16 + r) * 4 + wave) * 64 + lane] = acc[i][j][r];
+            }
+            __syncthreads();
+            if (team == 0) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[i][j][r] += xch[(((i * 2 + j) * 16 + r) * 4 + wave) * 64 + lane];
+            }
+            __syncthreads();
+        }
+        if (team != 0) return;                                            // (s_barrier counts the surviving waves only)
+    }
+    // D row = BIG channel (registers), col = im2col column (lane & 31)
+    const int khalf = lane >> 5;
+    if (a.G) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r16 = 0; r16 < 16; ++r16) {
+                const int ch = wm * 64 + i * 32 + (r16 & 3) + 8 * (r16 >> 2) + 4 * khalf;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int col = wn * 64 + j * 32 + (lane & 31);
+                    if (col < 112) atomicAdd(a.G + ch * 128 + col, acc[i][j][r16]);
+                }
+            }
+    } else {
+        // direct mode: the tile goes through LDS (the stages are done) in the ORDER OF THE PARAMETER, 64 BIG channels at a time, and leaves as
+        // contiguous atomics -- scattered 4-byte atomics in the parameter's order straight from the MFMA layout cost 3x the whole kernel
+        float* const stage = reinterpret_cast<float*>(smem);              // stem: [64 ch][cs][27] (+ [64] bias sums); head: [cs][64 ch][27]
+        const int cs = a.cs, per = 64 * cs * 27;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            if (half) __syncthreads();                                    // the previous half's atomics have read the stage
+            if (wm == half) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r16 = 0; r16 < 16; ++r16) {
+                        const int chl = i * 32 + (r16 & 3) + 8 * (r16 >> 2) + 4 * khalf;        // channel inside the half
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const int col = wn * 64 + j * 32 + (lane & 31);
+                            const int tap = col >> 2, cc = col & 3;
+                            if (col < 108) {
+                                if (cc < cs) {
+                                    const int e = a.stem ? (a.wcl ? (chl * 27 + tap) * cs + cc : (chl * cs + cc) * 27 + tap)
+                                                         : (a.wcl ? (cc * 27 + 26 - tap) * 64 + chl : (cc * 64 + chl) * 27 + 26 - tap);
+                                    stage[e] = acc[i][j][r16];
+                                }
+                            } else if (col == 108) {
+                                stage[per + chl] = acc[i][j][r16];
+                            }
+                        }
+                    }
+            }
+            __syncthreads();
+            if (a.stem) {
+                float* const dst = a.dW + (long long)half * per;
+                for (int e = tid; e < per; e += 256) atomicAdd(dst + e, stage[e]);
+                if (a.dbias && tid < 64) atomicAdd(a.dbias + half * 64 + tid, stage[per + tid]);
+            } else {
+                for (int e = tid; e < per; e += 256) {
+                    int d;
+                    if (a.wcl) d = (e >> 6) * 128 + half * 64 + (e & 63);                       // (co, tap) rows of 128 input channels
+                    else { const int cc = e / (64 * 27); d = (cc * 128 + half * 64) * 27 + (e - cc * (64 * 27)); }
+                    atomicAdd(a.dW + d, stage[e]);
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int genie_conv_narrow_in(const void* src_cl, int src_pitch, const void* wpack, void* dst_cl, int dst_pitch, int N, int T, int H, int W,
@@ -944,8 +1205,34 @@ static int narrow_wgrad_launch(NarrowWgradArgs& a, const char* who, void* stream
     a.chunks_per_block = (int)((nch + blocks - 1) / blocks);
     blocks = (nch + a.chunks_per_block - 1) / a.chunks_per_block;
     hipStream_t s = (hipStream_t)stream;
-    if (W == 32) conv_narrow_wgrad_kernel<32, 2><<<(unsigned)blocks, 256, 0, s>>>(a);
-    else conv_narrow_wgrad_kernel<64, 1><<<(unsigned)blocks, 256, 0, s>>>(a);
+    static const int cut = [] { const char* e = getenv("GENIE_NARROW_WGRAD_CUT"); return e ? atoi(e) : 3; }();
+    if (cut == 2 || cut == 3) {
+        // cut 3 (default): 256 workgroups of THREE four-wave teams -- the same twelve waves per CU as three workgroups of one team, a third of the
+        // 55-KB atomic tiles at the end (768 tiles = 8 M fp32 atomics were ~20 us of a 240-us launch, and of a 60-us one at 8 clips); cut 2: one team
+        const int teams = cut == 3 ? 3 : 1;
+        if (teams == 3) {
+            long long b3 = 256;
+            if (b3 * 3 * 4 > nch) b3 = (nch + 11) / 12;                   // at least four chunks per team
+            a.chunks_per_block = (int)((nch + b3 - 1) / b3);
+            blocks = (nch + a.chunks_per_block - 1) / a.chunks_per_block;
+        }
+        const int lds32 = teams * 2 * (64 * 256 + ((3 * 4 * 34 * 8 + 15) & ~15) + 16), lds64 = teams * 2 * (64 * 256 + ((3 * 3 * 66 * 8 + 15) & ~15) + 16);
+        static bool configured = false;
+        if (!configured) {
+            GENIE_CHECK_ARG(hipFuncSetAttribute((const void*)conv_narrow_wgrad2_kernel<32, 2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
+                            hipFuncSetAttribute((const void*)conv_narrow_wgrad2_kernel<64, 1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess,
+                            "hipFuncSetAttribute failed");
+            configured = true;
+        }
+        const int lds = W == 32 ? lds32 : lds64;
+        if (W == 32 && teams == 3) conv_narrow_wgrad2_kernel<32, 2, 3><<<(unsigned)blocks, 768, lds, s>>>(a);
+        else if (W == 32) conv_narrow_wgrad2_kernel<32, 2, 1><<<(unsigned)blocks, 256, lds > 64 * 112 * 4 + 64 ? lds : 64 * 112 * 4 + 64, s>>>(a);
+        else if (teams == 3) conv_narrow_wgrad2_kernel<64, 1, 3><<<(unsigned)blocks, 768, lds, s>>>(a);
+        else conv_narrow_wgrad2_kernel<64, 1, 1><<<(unsigned)blocks, 256, lds > 64 * 112 * 4 + 64 ? lds : 64 * 112 * 4 + 64, s>>>(a);
+    } else {
+        if (W == 32) conv_narrow_wgrad_kernel<32, 2><<<(unsigned)blocks, 256, 0, s>>>(a);
+        else conv_narrow_wgrad_kernel<64, 1><<<(unsigned)blocks, 256, 0, s>>>(a);
+    }
     GENIE_CHECK_LAUNCH();
     return GENIE_OK;
 }

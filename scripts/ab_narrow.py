@@ -25,7 +25,7 @@ stem = CausalConv3d(3, 128, 3).cuda()
 head = CausalConv3d(128, 3, 3).cuda()
 for B in (8, 64):
     npx = B * 16 * 64 * 64
-    nbytes = npx * (8 + 128) * 2
+    nbytes = npx * (3 + 128) * 2 + 128 * 3 * 27 * 2      # 17.19 MB per clip ((3 + 128) channels + the weights), not the 8-channel pitch
     vid = to_cl(torch.randn(B, 3, 16, 64, 64, device='cuda'))
     feat = rand_cl(B, 128, 16, 64, 64)
     gy = rand_cl(B, 128, 16, 64, 64)
