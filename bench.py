@@ -506,7 +506,7 @@ def main():
             for key, fn, b in (('configs[2] LatentAction', bm.bench_lam, args.lam_batch), ('configs[3] DynamicsModel', bm.bench_dyn, args.dyn_batch),
                                 ('configs[4] Genie 32x128x128', bm.bench_genie4, args.genie_batch)):
                 r = bm.run_quiet(fn, b)
-                oc[key] = {'model': r['model'], 'batch': b, 'ms_per_step': r['ms_per_step'], 'units_per_s': r['units_per_s'], 'peak_mem_GB': r['peak_mem_GB'],
+                oc[key] = {'model': r['model'], 'batch': b, 'ms_per_step': r['ms_per_step'], 'ms_per_step_all': r.get('ms_per_step_all'), 'units_per_s': r['units_per_s'], 'peak_mem_GB': r['peak_mem_GB'],
                            'roofline': r.get('roofline'), 'top_kernels': dict(list(r.get('kernels', {}).items())[:4])}
             out['other_configs'] = oc
         except Exception as ex:                            # a side measurement must never cost the headline line

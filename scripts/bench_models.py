@@ -37,12 +37,17 @@ def run(name, model, step_fn, units, steps=4, warm=2, cpu=None, quiet=False):
     for _ in range(warm):
         step_fn().backward(); arena.adamw_step()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
+    # every step timed on its own (one host synchronisation per step: these steps are 40-800 ms): `ms_per_step` is the MEDIAN, so that one
+    # allocator / first-touch hiccup inside a three-step window does not become the number; the mean rides along
+    per = []
     for _ in range(steps):
+        t0 = time.perf_counter()
         step_fn().backward(); arena.adamw_step()
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / steps * 1e3
-    out = {'model': name, 'ms_per_step': round(ms, 2), 'units_per_s': round(units / ms * 1e3, 1), 'params': sum(p.numel() for p in model.parameters()),
+        torch.cuda.synchronize()
+        per.append((time.perf_counter() - t0) * 1e3)
+    ms = sorted(per)[len(per) // 2]
+    out = {'model': name, 'ms_per_step': round(ms, 2), 'ms_per_step_mean': round(sum(per) / len(per), 2), 'ms_per_step_all': [round(v, 2) for v in per],
+           'units_per_s': round(units / ms * 1e3, 1), 'params': sum(p.numel() for p in model.parameters()),
            'peak_mem_GB': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
     # second pass with HIP events around every conv / GEMM launch (costs a few % of the step: kept out of the timing above)
     prof = gconv.PROFILER = gconv.LaunchProfiler(only_triple=False)
