@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GENIE_ABI_VERSION 11
+#define GENIE_ABI_VERSION 12
 
 #define GENIE_F32 0
 #define GENIE_BF16 1
@@ -324,6 +324,13 @@ int genie_linear_ce_bwd(const void* h_bf16, int64_t h_pitch, int64_t M, int D, c
  * (elementwise.hip; ABI 11).   replaces: `video / 255.` + rearrange 't h w c -> c t h w' of Platformer2D.load_video_slice (genie/module/data.py:218-231)
  * done on the host, followed by the model-boundary layout conversion.  Same numbers as that path (fp32 quotient, one rounding to bf16). */
 int genie_u8_frames_to_cl(const void* src_u8, int64_t npix, int C, void* dst_cl, int cpitch, void* stream);
+
+/* Embedding lookup and its sparse backward (elementwise.hip; ABI 12).   replaces: nn.Embedding tok_emb / act_emb of DynamicsModel
+ * (genie/dynamics.py:31-38, 52-55) and autograd's index_add_ scatter behind it.  fwd: out[n][:] = weight[idx[n]][:] (fp32 [V][D], D % 4 == 0; an index
+ * outside [0, V) poisons its row with NaN -- nn.Embedding raises).  bwd: grad[idx[n]][:] += dy[n][:] (dy fp32 or bf16, dense [N][D]; grad fp32 [V][D],
+ * accumulated with fp32 atomics, one per distinct index per 64-row chunk and column; out-of-range rows are skipped). */
+int genie_embedding_fwd(const int64_t* idx, const float* weight, float* out, int64_t N, int D, int64_t V, void* stream);
+int genie_embedding_bwd(const int64_t* idx, const void* dy, int dy_dtype, float* grad, int64_t N, int D, int64_t V, void* stream);
 
 /* Guard-page device allocations for the memory-safety harness (guard.hip; tests/guard.py).  *ptr: `bytes` bytes of device memory whose last byte
  * (up to 15 bytes of alignment slack) is the last byte of a mapping with an UNMAPPED page on either side -- an out-of-bounds access of a

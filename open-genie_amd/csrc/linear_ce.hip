@@ -621,16 +621,34 @@ __global__ void __launch_bounds__(256) lce_onehot_kernel(const bf16_t* __restric
 
 struct LcePlan { int n_atiles, nsplit, tps, ntiles, Apad; };
 
-// rows of the stationary matrix in 128-row tiles; the streamed matrix in 32-row tiles, split over blocks so that about three rounds of
-// 256 blocks exist (one block per CU is resident) and every split keeps at least 8 tiles
+// rows of the stationary matrix in 128-row tiles; the streamed matrix in 32-row tiles, split over blocks.  One block per CU is resident (one wave per
+// SIMD), blocks cost the same, so a launch runs in ROUNDS of (number of CUs) blocks and a last round of four blocks costs as much as a full one:
+// round 5 always asked for ~768 blocks -- 24576 gathered rows are 192 row tiles x 4 splits = 768 = three rounds exactly, but the 24 6xx rows a
+// Bernoulli(0.75) mask actually leaves are 193 x 4 = 772 blocks = FOUR rounds (the 14.2 ms in the training step against 10.97 ms in the stand-alone
+// bench).  Now the split count minimises rounds / splits (the time in units of one un-split sweep) plus a small charge per split for
+// its partial (max, sum, O) tile: 193 row tiles -> 5 splits = 965 blocks = four rounds of one fifth each (0.80 against 1.00).
+static int lce_cu_count() {
+    static int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1) v = 256;
+        return v;
+    }();
+    return n;
+}
 LcePlan lce_plan(long long n_station, long long n_stream) {
     LcePlan p;
     p.n_atiles = (int)((n_station + 127) / 128);
     p.ntiles = (int)((n_stream + 31) / 32);
-    int want = (768 + p.n_atiles - 1) / p.n_atiles;
-    const int cap = p.ntiles / 8 > 0 ? p.ntiles / 8 : 1;
-    if (want > cap) want = cap;
-    if (want < 1) want = 1;
+    const int cus = lce_cu_count();
+    int cap = p.ntiles / 8 > 0 ? p.ntiles / 8 : 1;                 // every split keeps at least 8 tiles
+    if (cap > 16) cap = 16;
+    int want = 1;
+    double best = 1e30;
+    for (int ns = 1; ns <= cap; ++ns) {
+        const long long blocks = (long long)p.n_atiles * ns;
+        const double cost = (double)((blocks + cus - 1) / cus) / ns + 0.004 * ns;
+        if (cost < best - 1e-9) { best = cost; want = ns; }
+    }
     p.tps = (p.ntiles + want - 1) / want;
     p.nsplit = (p.ntiles + p.tps - 1) / p.tps;
     p.Apad = p.n_atiles * 128;

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('GENIE_HIP_LIB', os.path.join(os.path.dirname(_HERE), 'lib', 'libgenie_hip.so'))
 
 GENIE_F32, GENIE_BF16 = 0, 1
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 class GenieTap(C.Structure):
@@ -107,6 +107,8 @@ SIGNATURES = {
     'genie_linear_ce_fwd': (C.c_int, [_P, _L, _L, _I, _P, _L, _L, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P]),
     'genie_linear_ce_bwd': (C.c_int, [_P, _L, _L, _I, _P, _L, _L, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P]),
     'genie_u8_frames_to_cl': (C.c_int, [_P, _L, _I, _P, _I, _P]),
+    'genie_embedding_fwd': (C.c_int, [_P, _P, _P, _L, _I, _L, _P]),
+    'genie_embedding_bwd': (C.c_int, [_P, _P, _I, _P, _L, _I, _L, _P]),
     'genie_guard_alloc': (C.c_int, [_L, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     'genie_guard_free': (C.c_int, [_P]),
     'genie_maskgit_sample': (C.c_int, [_P, _I, _L, _L, _L, _L, _L, _P, _F, _P, _P, _P]),

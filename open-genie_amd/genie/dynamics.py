@@ -44,7 +44,8 @@ class DynamicsModel(nn.Module):
         return [self.tok_emb, self.act_emb, self.dec_layers, self.head]
 
     def _trunk(self, tokens: Tensor, act_id: Tensor) -> Tensor:
-        x = GF.embedding(tokens, self.tok_emb.weight) + self.act_emb(act_id)                 # (B, T, H, W, D); sparse embedding backward
+        # (B, T, H, W, D); both lookups and their sparse backward are genie_embedding_fwd / _bwd (act_emb[1] is the 'b t d -> b t 1 1 d' rearrange)
+        x = GF.embedding(tokens, self.tok_emb.weight) + self.act_emb[1](GF.embedding(act_id, self.act_emb[0].weight))
         for dec in self.dec_layers:
             x = dec(x)
         return x

@@ -939,3 +939,28 @@ def test_residual_block_groupnorm_fused_into_conv_epilogues(G, cin, cout, size, 
     for a, b, (name, _) in zip(p1, p0, blocks.named_parameters()):
         err = (a - b).norm().item() / (b.norm().item() + 1e-12)
         assert err < 5e-3, (name, err)
+
+
+@pytest.mark.parametrize('n,d,v,dt', [(32768, 512, 1 << 18, torch.float32), (1000, 512, 8, torch.float32), (777, 64, 1000, torch.bfloat16), (5, 8, 3, torch.float32)])
+def test_embedding_lookup_and_sparse_backward(G, n, d, v, dt):
+    """genie_embedding_fwd / _bwd (nn.Embedding of DynamicsModel, dynamics.py:31-38) against F.embedding and a dense index_add_ on the CPU: the
+    MaskGIT fill pattern (three quarters of the rows are token 0), ragged row counts, bf16 upstream gradients, accumulation into a non-zero
+    buffer."""
+    from genie import functional as GF
+    torch.manual_seed(31)
+    w = torch.randn(v, d)
+    idx = torch.randint(0, v, (n,))
+    idx[torch.rand(n) < 0.75] = 0
+    wd = w.cuda().requires_grad_(True)
+    out = GF.embedding(idx.cuda().view(1, n), wd)
+    assert tuple(out.shape) == (1, n, d) and torch.equal(out.cpu()[0], F.embedding(idx, w))
+    dy = torch.randn(1, n, d).to(dt)
+    out.backward(dy.cuda().to(out.dtype) if dt == torch.float32 else dy.cuda().float())
+    ref = torch.zeros(v, d).index_add_(0, idx, dy[0].float())
+    torch.testing.assert_close(wd.grad.cpu(), ref, rtol=1e-5, atol=1e-5 * ref.abs().max().item())
+    # the C entry point with a bf16 dy and a pre-filled gradient buffer
+    g = torch.full((v, d), 0.25, device='cuda')
+    dyb = dy[0].to(torch.bfloat16).cuda().contiguous()
+    G.hip.check(G.hip.load_library().genie_embedding_bwd(idx.cuda().data_ptr(), dyb.data_ptr(), G.hip.GENIE_BF16, g.data_ptr(), n, d, v, G.hip.stream_ptr()), 'emb')
+    ref_b = torch.full((v, d), 0.25).index_add_(0, idx, dyb.float().cpu())
+    torch.testing.assert_close(g.cpu(), ref_b, rtol=1e-5, atol=1e-5 * ref_b.abs().max().item())
