@@ -444,7 +444,9 @@ int genie_attention_bwd(const void* q, const void* k, const void* v, const void*
  * largest weight is then rounded to bf16 like every other one instead of being exactly 1); bit 5: plain grid instead of the XCD-aware one;
  * bit 6: forward blocks of four waves at every length (default: eight waves from 2048 queries on; bit-identical results); bit 7 (with bit 4):
  * sum-triggered form of the deferred maximum -- a tile is exponentiated against the running maximum as it is and redone with its exact
- * maximum only when a lane's row sum exceeds 2^8 (same bound on P; no per-tile maximum in the steady state).
+ * maximum only when a lane's row sum exceeds 2^8 (same bound on P; no per-tile maximum in the steady state); bit 8: self-attention through one
+ * tensor (q == k == v), non-causal, 64 < S <= 1024 runs with the whole K / V sequence resident in LDS, one workgroup per (sequence, head) -- parity-tested,
+ * measured 5-7 % slower than the ring kernel, off by default.
  * A negative mask only queries.  Returns the previous mask (default 151 = bits 0, 1, 2, 4, 7, or the GENIE_ATTN_LEAN environment variable).
  * Process-wide; meant for A/B timing and for tests that cover both kernel families and both maximum rules. (ABI 10) */
 int genie_attention_lean_mode(int mask);

@@ -493,6 +493,268 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(64 
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
+// Forward with the WHOLE key / value sequence resident in LDS (round 6): self-attention (q == k == v, the reference's default,
+// attention.py:219-223), non-causal, 64 < S <= 1024 -- spatial attention of the tokenizers and of the half-resolution LatentAction blocks.
+// attn_fwd4_kernel streams K / V through a ring for every block of 128 queries: at S = 1024 that is eight blocks per (sequence, head), each
+// DMA-ing the same 128 KB, each paying a prologue, an epilogue and a barrier + counted wait per key tile -- 4.4 tile-times of fixed cost against
+// 16 tiles (profiles/r05_attention_vs_length.txt).  Here ONE workgroup of up to 16 waves owns a (sequence, head): the sequence is DMA'd once
+// (128 KB at S = 1024; the CU's whole register file and 128 of its 160 KB of LDS), the waves then walk their 32-query tiles on their own --
+// no barrier, no vmcnt, no DMA in the key loop; Q fragments come from the same LDS image (q == k); O leaves through registers: a
+// v_permlane32_swap per value gives each lane 8 consecutive channels of its row, so the residual is read and the results are stored as
+// 16-byte chunks, 32 contiguous bytes per row and instruction, without an LDS staging tile that would not fit.
+// Arithmetic: that of attn_fwd4_kernel<.., DEFER = 2> (sum-triggered running maximum).
+// MEASURED (profiles/r06_attention_resident_ab.log): parity-green (tests/test_gpu_attention.py::test_attention_sequence_resident_forward) and
+// SLOWER than the ring kernel -- 762 vs 816 TFLOP/s at S = 1024 / C = 256, 739 vs 764 at C = 512, 456 vs 464 at S = 256: with 128 KB of LDS a CU holds
+// ONE workgroup, so its 128-KB load (8-10 us of a ~95-us workgroup) is covered by nothing, and the ring kernel's per-tile barrier + counted wait --
+// what this form removes -- turn out not to be what S = 1024 pays for (four ring workgroups per CU already overlap each other's prologues).
+// Kept behind mode bit 8, OFF by default.
+// ------------------------------------------------------------------------------------------------------------------------------
+template <int DH>
+__global__ void __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(1024) attn_fwdr_kernel(const AttnArgs a) {
+    constexpr int KT = 64, ROWB = DH * 2, CPR = DH / 8, TILE = KT * ROWB, KS = DH / 16, DT = DH / 32;
+    static_assert(DH == 64, "register-direct epilogue is written for two 32-channel accumulator tiles");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nw = (int)(blockDim.x >> 6);
+    const int seq = blockIdx.x / a.nhead, head = blockIdx.x % a.nhead;
+    const int h = lane >> 5;
+    const int ntile = (a.Sk + KT - 1) / KT;
+
+    {   // the whole sequence: 1-KiB pieces (8 key rows each), wave w takes pieces w, w + nw, ...; rows past the end read zeros (range check)
+        const bf16_t* kseq = a.k + seq_base(a.km, seq) + head * DH;
+        const int seq_bytes = (int)((a.Sk - 1) * a.km.pos_stride * 2) + DH * 2;
+        const int nslab = ntile * (TILE / 1024);
+        const int r8 = lane / CPR, ch = lane % CPR;
+        for (int slab = wave; slab < nslab; slab += nw) {
+            const int row = slab * (64 / CPR) + r8;
+            const uint32_t voff = (uint32_t)((long long)row * a.km.pos_stride * 2) + (uint32_t)(attn_swz<CPR>(row, ch) * 16);
+            attn_dma16(kseq, seq_bytes, smem + slab * 1024, voff);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+    const float c2 = a.scale * 1.4426950408889634f;
+    auto ldk = [&](uint32_t addr) -> bf16x8_t {              // ds_read_b128 (the caller waits)
+        bf16x8_t v;
+        asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+        return v;
+    };
+
+    for (int qt = wave; qt * 32 < a.Sq; qt += nw) {
+        const int q0 = qt * 32, qi = q0 + (lane & 31);
+        // lane offsets of the fragment reads for key tile 0 (rebuilt per query tile -- a dozen instructions -- instead of kept: 8 registers);
+        // the key loop advances them by four tiles per group, the tile inside a group is an instruction immediate
+        uint32_t kb[KS], vb[DT][2];
+        {
+            int ln = lane;
+            asm volatile("" : "+v"(ln));                    // laundered: hipcc would hoist these lane constants out of the query loop and keep BOTH copies
+            const int row = ln & 31, hh = ln >> 5;
+            const uint32_t smem_off = attn_lds_offset(smem);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) kb[ks] = smem_off + (uint32_t)(row * ROWB + (attn_swz<CPR>(row, ks * 2 + hh) << 4));
+            const int g16 = ln >> 4, rr = (ln >> 2) & 3, qq = ln & 3;
+            const int r0 = 4 * (g16 >> 1) + rr, r1 = r0 + 8;
+#pragma unroll
+            for (int d = 0; d < DT; ++d) {
+                const int col = d * 32 + 16 * (g16 & 1) + 4 * qq;
+                vb[d][0] = smem_off + (uint32_t)(r0 * ROWB + (attn_swz<CPR>(r0, col >> 3) << 4) + (col & 7) * 2);
+                vb[d][1] = smem_off + (uint32_t)(r1 * ROWB + (attn_swz<CPR>(r1, col >> 3) << 4) + (col & 7) * 2);
+            }
+        }
+        bf16x8_t qf[KS];
+        {
+            const uint32_t qb = (uint32_t)((q0 >> 6) * TILE + (q0 & 32) * ROWB);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) qf[ks] = ldk(kb[ks] + qb);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));
+        }
+        f32x16_t oacc[DT];
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
+        float m_run = -1e30f, l_run = 0.f;
+
+        auto tile_body_r = [&](auto imm_c, int t) {
+            constexpr int IMM = decltype(imm_c)::value * TILE;
+            const int k0 = t * KT;
+            bool with_max = t == 0;
+            uint32_t pw[2][8];
+            bf16x4_t vlo[2][2][DT], vhi[2][2][DT];
+            float psum;
+            for (;;) {
+                // S^T = K Q^T.  The K fragments come in two batches of four (k-steps 0-1, then 2-3), the second requested behind the first batch's
+                // products: 16 registers of fragments in flight instead of 32 -- with all eight the kernel spilled two Q fragments to scratch, and a
+                // scratch reload is a vmcnt(0) in the middle of the MFMA cluster.  The second batch's LDS latency is covered by the other three
+                // waves of the SIMD.
+                f32x16_t sacc[2];
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sacc[kt][r] = 0.f;
+                attn_static_for<0, 2>([&](auto bc) {
+                    constexpr int b2 = decltype(bc)::value;
+                    bf16x8_t kf[2][2];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int kt = 0; kt < 2; ++kt)
+                            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kf[kt][j]) : "v"(kb[2 * b2 + j]), "i"(IMM + kt * 32 * ROWB));
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int kt = 0; kt < 2; ++kt) asm volatile("" : "+v"(kf[kt][j]));
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int kt = 0; kt < 2; ++kt) sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt][j], qf[2 * b2 + j], sacc[kt], 0, 0, 0);
+                    __builtin_amdgcn_s_setprio(0);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                attn_static_for<0, 2>([&](auto s2c) {
+                    constexpr int s2 = decltype(s2c)::value;
+#pragma unroll
+                    for (int d = 0; d < DT; ++d) {
+                        vlo[0][s2][d] = attn_tr16i<IMM + (16 * s2) * ROWB>(vb[d][0]);
+                        vhi[0][s2][d] = attn_tr16i<IMM + (16 * s2) * ROWB>(vb[d][1]);
+                    }
+                });
+                if (k0 + KT > a.Sk) {
+                    const int lim = a.Sk - k0 - 4 * h;
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) sacc[kt][r] = (kt * 32 + (r & 3) + 8 * (r >> 2)) < lim ? sacc[kt][r] : -INFINITY;
+                }
+                if (with_max) {
+                    float tmax;
+                    {
+                        float m3[11];
+#pragma unroll
+                        for (int g = 0; g < 10; ++g) {
+                            const int e = 3 * g;
+                            m3[g] = fmaxf(fmaxf(sacc[e >> 4][e & 15], sacc[(e + 1) >> 4][(e + 1) & 15]), sacc[(e + 2) >> 4][(e + 2) & 15]);
+                        }
+                        m3[10] = fmaxf(sacc[1][14], sacc[1][15]);
+                        const float a0 = fmaxf(fmaxf(m3[0], m3[1]), m3[2]), a1 = fmaxf(fmaxf(m3[3], m3[4]), m3[5]);
+                        const float a2 = fmaxf(fmaxf(m3[6], m3[7]), m3[8]), a3 = fmaxf(m3[9], m3[10]);
+                        tmax = fmaxf(fmaxf(fmaxf(a0, a1), a2), a3);
+                    }
+                    tmax = attn_xmax32(tmax);
+                    const float m_new = fmaxf(m_run, tmax);
+                    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
+                    l_run *= alpha;
+#pragma unroll
+                    for (int d = 0; d < DT; ++d)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+                    m_run = m_new;
+                }
+                const float mc = m_run * c2;
+                float ps0, ps1, ps2, ps3;
+                attn_static_for<0, 2>([&](auto ktc) {
+                    constexpr int kt = decltype(ktc)::value;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[kt][4 * e + 0], c2, -mc));
+                        const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[kt][4 * e + 1], c2, -mc));
+                        const float p2 = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[kt][4 * e + 2], c2, -mc));
+                        const float p3 = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[kt][4 * e + 3], c2, -mc));
+                        if (kt == 0 && e == 0) { ps0 = p0; ps1 = p1; ps2 = p2; ps3 = p3; }
+                        else { ps0 += p0; ps1 += p1; ps2 += p2; ps3 += p3; }
+                        pw[kt][2 * e] = pack_bf16x2(p0, p1);
+                        pw[kt][2 * e + 1] = pack_bf16x2(p2, p3);
+                    }
+                });
+                psum = (ps0 + ps1) + (ps2 + ps3);
+                if (with_max || __builtin_amdgcn_ballot_w64(!(psum <= 256.f)) == 0) break;
+                with_max = true;
+            }
+            l_run += attn_xsum32(psum);
+            __builtin_amdgcn_sched_barrier(0);
+            attn_static_for<0, 2>([&](auto s2c) {
+                constexpr int s2 = decltype(s2c)::value;
+#pragma unroll
+                for (int d = 0; d < DT; ++d) {
+                    vlo[1][s2][d] = attn_tr16i<IMM + (32 + 16 * s2) * ROWB>(vb[d][0]);
+                    vhi[1][s2][d] = attn_tr16i<IMM + (32 + 16 * s2) * ROWB>(vb[d][1]);
+                }
+            });
+            attn_static_for<0, 2>([&](auto ktc) {
+                constexpr int kt = decltype(ktc)::value;
+                if constexpr (kt == 0) asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(4 * DT) : "memory");
+                else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    u32x4_t pv4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pv4[e] = pw[kt][4 * s2 + e];
+                    const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pv4);
+#pragma unroll
+                    for (int d = 0; d < DT; ++d) {
+                        asm volatile("" : "+v"(vlo[kt][s2][d]), "+v"(vhi[kt][s2][d]));
+                        const bf16x8_t vf = __builtin_shufflevector(vlo[kt][s2][d], vhi[kt][s2][d], 0, 1, 2, 3, 4, 5, 6, 7);
+                        oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[d], 0, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        };
+        // key tiles in groups of four: the group's base goes into the lane offsets once, the tile inside the group is an instruction immediate
+        for (int t0 = 0; t0 < ntile; t0 += 4) {
+            tile_body_r(std::integral_constant<int, 0>{}, t0);
+            if (t0 + 1 < ntile) tile_body_r(std::integral_constant<int, 1>{}, t0 + 1);
+            if (t0 + 2 < ntile) tile_body_r(std::integral_constant<int, 2>{}, t0 + 2);
+            if (t0 + 3 < ntile) tile_body_r(std::integral_constant<int, 3>{}, t0 + 3);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) kb[ks] += 4 * TILE;
+#pragma unroll
+            for (int d = 0; d < DT; ++d) { vb[d][0] += 4 * TILE; vb[d][1] += 4 * TILE; }
+        }
+        // epilogue, through registers: accumulator (d, 4 g + e) of lane (query, h) is channel 32 d + 8 g + 4 h + e.  For a pair of groups (g, g + 1)
+        // one v_permlane32_swap per value hands lane h = 0 the whole group g (its own four channels and the partner's) and lane h = 1 the
+        // whole group g + 1: eight consecutive channels = one 16-byte chunk of the row
+        const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+        const long long obase_s = seq_base(a.om, seq) + head * DH;
+        if (a.lse && h == 0 && qi < a.Sq) a.lse[((obase_s - head * DH + (long long)qi * a.om.pos_stride) / a.C) * a.nhead + head] = m_run * a.scale + __logf(l_run);
+        const long long orow = obase_s + (long long)qi * a.om.pos_stride;
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) {
+                float x[4], y[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { x[e] = oacc[d][8 * gp + e] * inv; y[e] = oacc[d][8 * gp + 4 + e] * inv; }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) attn_swap32(x[e], y[e]);
+                // lanes < 32: (x, y) = group 2 gp, channels 0-3 | 4-7; lanes >= 32: group 2 gp + 1
+                float f[8] = {x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
+                if (qi < a.Sq) {
+                    const long long o = orow + d * 32 + (2 * gp + h) * 8;
+                    if (a.oattn) *reinterpret_cast<u32x4_t*>(a.oattn + o) = pack8(f);
+                    if (a.resid) {
+                        float r[8];
+                        unpack8(*reinterpret_cast<const u32x4_t*>(a.resid + o), r);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) f[e] += r[e];
+                    }
+                    *reinterpret_cast<u32x4_t*>(a.out + o) = pack8(f);
+                }
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
 // backward, dQ: per query tile, loop over key tiles (lane = query).  Per 32-key half: S^T and dP^T (8 MFMAs on two independent
 // accumulators), p = exp2(c s - lse), dS = p (dP - D) packed to bf16, dQ^T += K^T dS^T (4 MFMAs).  Keys past the end need no mask
 // here: their K rows are zeros (descriptor range check), so whatever p they get multiplies a zero row; only the causal diagonal does.
@@ -998,8 +1260,10 @@ __global__ void __attribute__((amdgpu_waves_per_eu(3, 3))) __launch_bounds__(64 
 // everything through attention.hip's general kernels -- A/B timing and the tests that compare the two families); bit 3: unused (was:
 // no s_setprio around the MFMA clusters -- measured neutral, profiles/r04_attention_lean_ab.log); bit 6: forward blocks of four waves at every
 // length (default: eight from 2048 queries on); bit 4: deferred running maximum in the forward (see attn_fwd4_kernel); bit 7 (with bit 4):
-// the sum-triggered form of it (no per-tile maximum at all in the steady state)
-#define LEAN_DEFAULT 151     // lean forward + dQ + dK-dV, deferred running maximum in its sum-triggered form (bits 0, 1, 2, 4, 7)
+// the sum-triggered form of it (no per-tile maximum at all in the steady state); bit 8: self-attention sequences of 65..1024 positions run with the
+// whole K / V sequence resident in LDS (attn_fwdr_kernel)
+#define LEAN_DEFAULT 151     // lean forward + dQ + dK-dV, deferred running maximum in its sum-triggered form (bits 0, 1, 2, 4, 7); bit 8 (sequence-resident
+                             // forward) is OFF: measured 5-7 % slower than the ring kernel, see attn_fwdr_kernel
 static int g_lean_mode = -1;
 static int lean_mode() {
     if (g_lean_mode < 0) { const char* e = getenv("GENIE_ATTN_LEAN"); g_lean_mode = e ? atoi(e) : LEAN_DEFAULT; }
@@ -1007,7 +1271,7 @@ static int lean_mode() {
 }
 extern "C" int genie_attention_lean_mode(int mask) {
     const int old = lean_mode();
-    if (mask >= 0) g_lean_mode = mask & 255;
+    if (mask >= 0) g_lean_mode = mask & 511;
     return old;
 }
 // byte offsets inside a sequence travel as 32-bit buffer offsets / record counts
@@ -1036,12 +1300,35 @@ static dim3 lean_grid(int nseq, int nhead, int tiles, int* swizzle) {
     return dim3((unsigned)(((n + 7) / 8) * 8), 1, 1);
 }
 
+// sequence-resident forward (attn_fwdr_kernel): self-attention through ONE tensor, non-causal, 64 < S <= 1024; mode bit 8 (default on)
+static bool lean_resident_ok(const AttnArgs& a) {
+    return (lean_mode() & 256) && a.kv_same && a.q == a.k && !a.causal && a.Sq == a.Sk && a.Sk > 64 && a.Sk <= 1024 &&
+           a.qm.pos_stride == a.km.pos_stride && a.qm.stride_outer == a.km.stride_outer && a.qm.stride_inner == a.km.stride_inner && a.qm.n_inner == a.km.n_inner;
+}
+
 int genie_attn_lean_fwd(const AttnArgs& a_in, hipStream_t s) {
     AttnArgs a = a_in;
+    if (lean_resident_ok(a)) {
+        const int ntile = (a.Sk + 63) / 64;
+        const int lds = ntile * 64 * 64 * 2;
+        int nw = (a.Sq + 31) / 32;
+        if (nw > 16) nw = 16;
+        GENIE_CHECK_ARG((long long)a.nseq * a.nhead < (1ll << 31), "genie_attention_fwd: grid too large");
+        static bool configured = false;
+        if (!configured) {
+            GENIE_CHECK_ARG(hipFuncSetAttribute((const void*)attn_fwdr_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess,
+                            "hipFuncSetAttribute failed");
+            configured = true;
+        }
+        attn_fwdr_kernel<64><<<(unsigned)(a.nseq * a.nhead), 64 * nw, lds, s>>>(a);
+        GENIE_CHECK_LAUNCH();
+        return GENIE_OK;
+    }
     // blocks of four waves (128 queries); from 2048 queries on, eight (256 queries share a K / V tile: half the L2 -> LDS bytes per query; two
     // blocks of eight waves per CU are the same four waves per SIMD).  Same arithmetic, bit-identical results; measured 970 vs 951 TFLOP/s
     // at S = 4096, equal at 1024, 494 vs 520 at 256 (profiles/r04_attention_lean_ab.log).  Bit 6 of the mode keeps four everywhere (A/B).
-    const int nw = (!(lean_mode() & 64) && a.Sq >= 2048) ? 8 : 4;
+    static const int nw8_min = [] { const char* e = getenv("GENIE_ATTN_NW8_MIN"); return e ? atoi(e) : 2048; }();      // (A/B knob)
+    const int nw = (!(lean_mode() & 64) && a.Sq >= nw8_min) ? 8 : 4;
     const int qtiles = (a.Sq + 32 * nw - 1) / (32 * nw);
     GENIE_CHECK_ARG((long long)a.nseq * qtiles * a.nhead < (1ll << 31) - 8 && a.nhead <= 65535, "genie_attention_fwd: grid too large");
     const int tile = 64 * 64 * 2;

@@ -4,7 +4,7 @@
   mode 0 = attention.hip's general kernels (3 / 2 waves per SIMD at d_head 64)
   mode 7 = attention_lean.hip (4 / 3 waves per SIMD); 1 / 2 / 4 = forward / dQ / dK-dV alone; + 8 = no s_setprio around the MFMA
   clusters; + 16 = deferred running maximum in the forward; + 32 = plain (sequence * tiles, head) grid instead of the XCD-aware one;
-  + 128 (with 16) = the sum-triggered form of the deferred maximum (round 6 default: 151)
+  + 128 (with 16) = the sum-triggered form of the deferred maximum ; + 256 = sequence-resident forward for S <= 1024 (parity-green, measured slower: off; round 6 default: 151)
 
 for the spatial ST-attention shapes of scripts/microbench.py (MFMA-bound: S >= 1024; traffic-bound: S = 256 / 64).  Writes
 gpurun_out/attn_lean_ab.json; every line is also printed."""
@@ -23,7 +23,7 @@ def main():
     lib = _hip.load_library()
     iters = int(os.environ.get('AB_ITERS', 30))
     only = os.environ.get('AB_ONLY', 'spatial S=4096,spatial S=1024,spatial S=256,spatial S=64').split(',')
-    modes = [int(m) for m in os.environ.get('AB_MODES', '0,23,151').split(',')]
+    modes = [int(m) for m in os.environ.get('AB_MODES', '151,407').split(',')]
     reps = int(os.environ.get('AB_REPS', 2))
     base_report = mb.report
     rows = []

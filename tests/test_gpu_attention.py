@@ -298,6 +298,53 @@ def test_attention_forward_variants_with_late_maxima(mode):
     torch.testing.assert_close(lse.cpu().reshape(nseq, S, nhead), lse_ref, rtol=2e-3, atol=2e-3)
 
 
+@pytest.mark.parametrize('S', [1024, 333, 96, 640])
+@pytest.mark.parametrize('resid', [False, True])
+def test_attention_sequence_resident_forward(S, resid):
+    """attn_fwdr_kernel (lean mode bit 8): self-attention through ONE tensor (q == k == v, the reference's default), 64 < S <= 1024, the whole
+    K / V sequence resident in LDS, Q fragments read from the same image, O leaving through registers -- against fp32 softmax attention AND against
+    the ring kernel (bit 8 off) on the same input: full and ragged lengths (partial last key tile, partial last query tile, fewer than 16
+    waves), rows whose maximum arrives late (the sum-triggered redo), with and without the residual epilogue, o_attn and log-sum-exp outputs."""
+    from genie import _hip
+    lib = _hip.load_library()
+    P = _hip.ptr
+    torch.manual_seed(91 + S)
+    nseq, nhead, dh = 3, 2, 64
+    c = nhead * dh
+    scale = dh ** -0.5 * 2.0
+    u = torch.randn(nseq, S, c) * 0.7
+    if S > 80:
+        u[:, S - 7] = u[:, 5] * 2.5                          # a late key strongly aligned with query 5 (and with itself)
+        u[:, 70:90] = u[:, 40:41] * 0.9 + 0.05 * torch.randn(nseq, 20, c)      # a run of keys moderately above row 40's maximum
+    u = bf16_round(u)
+    r = bf16_round(torch.randn(nseq, S, c))
+    uh = u.reshape(nseq, S, nhead, dh).transpose(1, 2)
+    sc = (uh @ uh.transpose(-1, -2)) * scale
+    o_ref = (sc.softmax(-1) @ uh).transpose(1, 2).reshape(nseq, S, c)
+    lse_ref = sc.logsumexp(-1).transpose(1, 2).contiguous()
+    ud, rd = u.cuda().to(torch.bfloat16), r.cuda().to(torch.bfloat16)
+    m = _hip.i64((1, S * c, 0, c))
+    res = {}
+    base = lib.genie_attention_lean_mode(-1)
+    for tag, mode in (('resident', base | 256), ('ring', base & ~256)):
+        old = lib.genie_attention_lean_mode(mode)
+        try:
+            out, oattn, lse = torch.full_like(ud, 7.0), torch.full_like(ud, 7.0), torch.full((nseq * S * nhead,), 7.0, device='cuda')
+            _hip.check(lib.genie_attention_fwd(P(ud), P(ud), P(ud), P(rd) if resid else None, P(out), P(oattn), P(lse), nseq, nhead, dh, S, S, m, m, m, scale, 0, c,
+                                               _hip.stream_ptr()), 'fwd')
+            torch.cuda.synchronize()
+            res[tag] = (out.float().cpu(), oattn.float().cpu(), lse.cpu().reshape(nseq, S, nhead))
+        finally:
+            lib.genie_attention_lean_mode(old)
+    for tag, (out, oattn, lse) in res.items():
+        assert_close_bf16(oattn, o_ref, f'{tag} o_attn S={S}', rms_frac=8e-3)
+        assert_close_bf16(out, o_ref + (r if resid else 0), f'{tag} out S={S}', rms_frac=8e-3)
+        torch.testing.assert_close(lse, lse_ref, rtol=2e-3, atol=2e-3)
+    # same arithmetic, same tile order: the two kernels agree to a bf16 ulp (the K fragments are consumed in another order: fp32 sums may differ in the last bit)
+    assert (res['resident'][1] - res['ring'][1]).abs().max().item() <= 2 ** -7 * o_ref.abs().max().item() + 1e-6
+    assert (res['resident'][2] - res['ring'][2]).abs().max().item() <= 1e-4
+
+
 @pytest.mark.parametrize('nseq,nhead,dh,sq,sk,causal,cross', CORE_CASES)
 def test_attention_core_kernels(nseq, nhead, dh, sq, sk, causal, cross):
     """genie_attention_fwd / _bwd through the C ABI on longer and ragged sequences (several key tiles, partial last tile,
