@@ -269,3 +269,30 @@ def test_bench_launcher_branch(monkeypatch):
     monkeypatch.setenv('WORLD_SIZE', '4')
     with pytest.raises(SystemExit):
         bench.main()
+
+
+def test_linear_ce_plan_fills_whole_rounds():
+    """The fused head + CE runs one workgroup per CU, i.e. in rounds of (number of CUs) workgroups: the split count must not leave a nearly empty
+    last round.  Round 5's plan always asked for ~768 workgroups: 192 row tiles x 4 = three rounds, but the 193 row tiles a Bernoulli mask actually
+    leaves x 4 = 772 = FOUR (14.2 ms in the step vs 10.97 ms stand-alone).  genie_linear_ce_ws_floats is host arithmetic (256 CUs are
+    assumed where no device answers), so the plan is visible here: splits = workspace / (padded rows x (2 + D))."""
+    from genie import _hip
+    lib = _hip.load_library()
+    d, v, cus = 512, 1 << 18, 256
+
+    def splits(m):
+        tiles = (m + 127) // 128
+        ws = lib.genie_linear_ce_ws_floats(m, d, v, 1)
+        assert ws % (tiles * 128 * (2 + d)) == 0
+        return tiles, ws // (tiles * 128 * (2 + d))
+
+    for m in (24576, 24616, 24000, 25000, 20000, 12345, 8192, 3072, 1024, 128):
+        tiles, ns = splits(m)
+        assert 1 <= ns <= 16
+        rounds = -(-tiles * ns // cus)
+        cost = rounds / ns                      # time in units of one un-split sweep
+        ideal = tiles / cus
+        # within a quarter of a round-unit of the ideal, and never the 4 / 3 of round 5
+        assert cost <= max(ideal * 1.12, ideal + 0.13), (m, tiles, ns, rounds, cost, ideal)
+    assert splits(24576) == (192, 4)            # the stand-alone bench's shape keeps its three full rounds
+    assert lib.genie_linear_ce_ws_floats(24616, d, v, 0) * (2 + d) == lib.genie_linear_ce_ws_floats(24616, d, v, 1) * 2      # lse-only sweep: no O partials
