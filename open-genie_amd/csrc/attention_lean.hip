@@ -89,8 +89,12 @@ __device__ __forceinline__ void attn_static_for(F&& f) {
 template <int DH, int NW, bool KVSAME, int DEFER>
 __global__ void __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(64 * NW) attn_fwd4_kernel(const AttnArgs a) {
     constexpr int KT = 64, ROWB = DH * 2, CPR = DH / 8, TILE = KT * ROWB, KS = DH / 16, DT = DH / 32;
-    constexpr int SLABS = TILE / 1024, LPW = SLABS / NW, LPT = KVSAME ? LPW : 2 * LPW;
-    constexpr int STAGE = KVSAME ? TILE : 2 * TILE;
+    // SUP: 64-key tiles per ring stage.  2 for the sum-triggered self-attention form (round 6): a stage is two tiles = 128 keys, so the barrier, the counted
+    // wait and the DMA issue block come once per 32 MFMAs instead of once per 16 (LDS: 3 x 16 KB per workgroup); 1 elsewhere
+    constexpr int SUP = (DEFER == 2 && KVSAME && NW == 8) ? 2 : 1;      // (DEFER == 3: the sum-triggered rule with one tile per stage, for A/B)
+    // (four-wave workgroups would stage twice the pieces per wave: two more offset registers, which spill at this budget)
+    constexpr int SLABS = TILE / 1024, LPW = SLABS / NW, LPT = SUP * (KVSAME ? LPW : 2 * LPW);
+    constexpr int STAGE = SUP * (KVSAME ? TILE : 2 * TILE);
     static_assert(SLABS % NW == 0, "every wave stages the same number of pieces (counted vmcnt)");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -138,24 +142,25 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(64 
     // (host side guarantees (Sk + 192) * pos_stride * 2 < 2^31, so the byte counts below fit an int)
     const int tile_bytes = (int)(KT * a.km.pos_stride * 2);
     const int seq_bytes = (int)((a.Sk - 1) * a.km.pos_stride * 2) + DH * 2;                // first byte behind the last key's head slice
-    uint32_t st_voff[LPW];
+    uint32_t st_voff[SUP * LPW];
 #pragma unroll
-    for (int i = 0; i < LPW; ++i) {
-        const int idx = (wave + i * NW) * 64 + lane;
+    for (int i = 0; i < SUP * LPW; ++i) {
+        const int idx = (wave + i * NW) * 64 + lane;          // (rows 64 .. 127 of a two-tile stage: the second tile, same swizzle -- its keys use row bits 0 .. 3)
         const int row = idx / CPR;
         st_voff[i] = (uint32_t)((long long)row * a.km.pos_stride * 2) + (uint32_t)(attn_swz<CPR>(row, idx % CPR) * 16);
     }
-    auto stage = [&](int t, int buf) {
+    const int nstage = (ntile + SUP - 1) / SUP;
+    auto stage = [&](int t, int buf) {                       // t: stage index (SUP tiles of 64 keys)
         char* kt_ = smem + buf * STAGE;
-        int left = seq_bytes - t * tile_bytes;
-        left = (t < ntile && left > 0) ? left : 0;
-        const bf16_t* kt_base = kseq + (long long)t * (tile_bytes / 2);
-        const bf16_t* vt_base = vseq + (long long)t * (tile_bytes / 2);
+        int left = seq_bytes - t * (SUP * tile_bytes);
+        left = (t < nstage && left > 0) ? left : 0;
+        const bf16_t* kt_base = kseq + (long long)t * (SUP * tile_bytes / 2);
+        const bf16_t* vt_base = vseq + (long long)t * (SUP * tile_bytes / 2);
 #pragma unroll
-        for (int i = 0; i < LPW; ++i) {
+        for (int i = 0; i < SUP * LPW; ++i) {
             const int slab = wave + i * NW;
             attn_dma16(kt_base, left, kt_ + slab * 1024, st_voff[i]);
-            if (!KVSAME) attn_dma16(vt_base, left, kt_ + TILE + slab * 1024, st_voff[i]);
+            if (!KVSAME) attn_dma16(vt_base, left, kt_ + SUP * TILE + slab * 1024, st_voff[i]);
         }
     };
 
@@ -321,11 +326,15 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(64 
     // lane's sum exceeds it (or is inf / NaN: the first tile, m = -1e30) is the tile redone with its exact maximum: scores recomputed (the K
     // tile is still in its ring slot), maximum, rescale of O and l, exponentials again.  No P V product is issued before the test, so a redo
     // finds O untouched.  Steady state: no maximum tree, no compare chain -- 113 VALU instructions per tile instead of 150.
-    auto tile_body_s = [&](auto slot_c, int t) {
+    auto tile_body_s = [&](auto slot_c, int st) {
         constexpr int SLOT = decltype(slot_c)::value;
-        constexpr int KBASE = SLOT * STAGE, VBASE = KVSAME ? KBASE : KBASE + TILE;
+        stage(st + 2, SLOT == 0 ? 2 : SLOT - 1);
+        attn_static_for<0, SUP>([&](auto half_c) {
+        constexpr int HALF = decltype(half_c)::value;
+        constexpr int KBASE = SLOT * STAGE + HALF * TILE, VBASE = KVSAME ? KBASE : SLOT * STAGE + SUP * TILE + HALF * TILE;
+        const int t = st * SUP + HALF;
+        if (HALF > 0 && t >= ntile) return;                        // odd tile count: the stage's second tile does not exist (wave-uniform)
         const int k0 = t * KT;
-        stage(t + 2, SLOT == 0 ? 2 : SLOT - 1);
         bool with_max = t == 0;                                    // wave-uniform
         uint32_t pw[2][8];
         bf16x4_t vlo[2][2][DT], vhi[2][2][DT];
@@ -443,17 +452,18 @@ __global__ void __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(64 
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
         });
+        });                                                        // tiles of the stage
         asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LPT) : "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     };
     auto tile_any = [&](auto slot_c, int t) {
-        if constexpr (DEFER == 2) tile_body_s(slot_c, t); else tile_body(slot_c, t);
+        if constexpr (DEFER >= 2) tile_body_s(slot_c, t); else tile_body(slot_c, t);
     };
-    for (int t = 0; t < ntile; t += 3) {
+    for (int t = 0; t < nstage; t += 3) {                          // t: stage index (= tile index where a stage is one tile)
         tile_any(std::integral_constant<int, 0>{}, t);
-        if (t + 1 < ntile) tile_any(std::integral_constant<int, 1>{}, t + 1);
-        if (t + 2 < ntile) tile_any(std::integral_constant<int, 2>{}, t + 2);
+        if (t + 1 < nstage) tile_any(std::integral_constant<int, 1>{}, t + 1);
+        if (t + 2 < nstage) tile_any(std::integral_constant<int, 2>{}, t + 2);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
@@ -1271,7 +1281,7 @@ static int lean_mode() {
 }
 extern "C" int genie_attention_lean_mode(int mask) {
     const int old = lean_mode();
-    if (mask >= 0) g_lean_mode = mask & 511;
+    if (mask >= 0) g_lean_mode = mask & 1023;
     return old;
 }
 // byte offsets inside a sequence travel as 32-bit buffer offsets / record counts
@@ -1332,17 +1342,19 @@ int genie_attn_lean_fwd(const AttnArgs& a_in, hipStream_t s) {
     const int qtiles = (a.Sq + 32 * nw - 1) / (32 * nw);
     GENIE_CHECK_ARG((long long)a.nseq * qtiles * a.nhead < (1ll << 31) - 8 && a.nhead <= 65535, "genie_attention_fwd: grid too large");
     const int tile = 64 * 64 * 2;
-    int lds = 3 * (a.kv_same ? tile : 2 * tile);
+    // running-maximum rule: bit 4 deferred (round 4), bit 7 on top of it sum-triggered (round 6, the default); neither: exact
+    const int defer = (lean_mode() & 16) ? ((lean_mode() & 128) ? ((lean_mode() & 512) ? 3 : 2) : 1) : 0;      // (bit 9: sum-triggered, one tile per stage)
+    const int sup = (defer == 2 && a.kv_same && nw == 8) ? 2 : 1;     // 64-key tiles per ring stage (attn_fwd4_kernel: SUP)
+    int lds = 3 * sup * (a.kv_same ? tile : 2 * tile);
     if (lds < nw * 32 * 64 * 4) lds = nw * 32 * 64 * 4;               // the epilogue stages NW x 32 fp32 rows in the ring's memory
     const dim3 grid = lean_grid(a.nseq, a.nhead, qtiles, &a.xcd_swizzle);
-    // running-maximum rule: bit 4 deferred (round 4), bit 7 on top of it sum-triggered (round 6, the default); neither: exact
-    const int defer = (lean_mode() & 16) ? ((lean_mode() & 128) ? 2 : 1) : 0;
 #define LEAN_FWD(NWv)                                                                                    \
     do {                                                                                                 \
-        if (a.kv_same && defer == 2) attn_fwd4_kernel<64, NWv, true, 2><<<grid, 64 * NWv, lds, s>>>(a);  \
+        if (a.kv_same && defer == 3) attn_fwd4_kernel<64, NWv, true, 3><<<grid, 64 * NWv, lds, s>>>(a);  \
+        else if (a.kv_same && defer == 2) attn_fwd4_kernel<64, NWv, true, 2><<<grid, 64 * NWv, lds, s>>>(a);  \
         else if (a.kv_same && defer) attn_fwd4_kernel<64, NWv, true, 1><<<grid, 64 * NWv, lds, s>>>(a);  \
         else if (a.kv_same) attn_fwd4_kernel<64, NWv, true, 0><<<grid, 64 * NWv, lds, s>>>(a);           \
-        else if (defer == 2) attn_fwd4_kernel<64, NWv, false, 2><<<grid, 64 * NWv, lds, s>>>(a);         \
+        else if (defer >= 2) attn_fwd4_kernel<64, NWv, false, 2><<<grid, 64 * NWv, lds, s>>>(a);         \
         else if (defer) attn_fwd4_kernel<64, NWv, false, 1><<<grid, 64 * NWv, lds, s>>>(a);              \
         else attn_fwd4_kernel<64, NWv, false, 0><<<grid, 64 * NWv, lds, s>>>(a);                         \
     } while (0)
