@@ -332,6 +332,21 @@ int genie_u8_frames_to_cl(const void* src_u8, int64_t npix, int C, void* dst_cl,
 int genie_embedding_fwd(const int64_t* idx, const float* weight, float* out, int64_t N, int D, int64_t V, void* stream);
 int genie_embedding_bwd(const int64_t* idx, const void* dy, int dy_dtype, float* grad, int64_t N, int D, int64_t V, void* stream);
 
+/* Skinny linears in fp32 arithmetic (linear_small.hip; ABI 12): y = x W^T + bias with min(in K, out N) <= 32.   replaces: F.linear of
+ * AdaptiveGroupNorm.std / .avg (genie/module/norm.py:55-69), LookupFreeQuantization.proj_inp / proj_out (quantization.py:52-58), Adapter.to_k / to_v on a
+ * conditioning vector (attention.py:128-129), LatentAction.to_act (action.py:83-90).  x: [M][x_pitch >= K] fp32 / bf16; W: fp32, W[n][k] at n * w_sn +
+ * k * w_sk (the backward-data pass is the same call with dy as x and the strides exchanged); bias: fp32 [N] or NULL; y: [M][y_pitch >= N] fp32 / bf16.
+ * K > 32 walks the reduction axis in register-resident weight slices; more than one slice (K > 1024 / 512 / 256 for N <= 10 / 16 / 32) needs
+ * genie_linear_small_ws_floats(M, K, N) floats of scratch (partials summed in a fixed order).  wgrad: dW[n * w_sn + k * w_sk] += sum_m dy[m][n] x[m][k],
+ * dbias[n] += sum_m dy[m][n] (NULL: skipped), rows split over workgroups, partials in ws (genie_linear_small_wgrad_ws_floats) summed in a fixed order:
+ * no atomics, bit-reproducible. */
+int64_t genie_linear_small_ws_floats(int64_t M, int K, int N);
+int genie_linear_small_fwd(const void* x, int x_dtype, int64_t x_pitch, int64_t M, int K, const float* W, int64_t w_sn, int64_t w_sk,
+                           const float* bias, void* y, int y_dtype, int64_t y_pitch, int N, float* ws, int64_t ws_floats, void* stream);
+int64_t genie_linear_small_wgrad_ws_floats(int64_t M, int N, int K);
+int genie_linear_small_wgrad(const void* dy, int dy_dtype, int64_t dy_pitch, const void* x, int x_dtype, int64_t x_pitch, int64_t M, int N, int K,
+                             float* dW, int64_t w_sn, int64_t w_sk, float* dbias, float* ws, int64_t ws_floats, void* stream);
+
 /* Guard-page device allocations for the memory-safety harness (guard.hip; tests/guard.py).  *ptr: `bytes` bytes of device memory whose last byte
  * (up to 15 bytes of alignment slack) is the last byte of a mapping with an UNMAPPED page on either side -- an out-of-bounds access of a
  * kernel in either direction is a GPU page fault on every run, not only when the caching allocator happens to leave a hole there.

@@ -108,6 +108,10 @@ SIGNATURES = {
     'genie_linear_ce_bwd': (C.c_int, [_P, _L, _L, _I, _P, _L, _L, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P]),
     'genie_u8_frames_to_cl': (C.c_int, [_P, _L, _I, _P, _I, _P]),
     'genie_embedding_fwd': (C.c_int, [_P, _P, _P, _L, _I, _L, _P]),
+    'genie_linear_small_ws_floats': (C.c_int64, [_L, _I, _I]),
+    'genie_linear_small_fwd': (C.c_int, [_P, _I, _L, _L, _I, _P, _L, _L, _P, _P, _I, _L, _I, _P, _L, _P]),
+    'genie_linear_small_wgrad_ws_floats': (C.c_int64, [_L, _I, _I]),
+    'genie_linear_small_wgrad': (C.c_int, [_P, _I, _L, _P, _I, _L, _L, _I, _I, _P, _L, _L, _P, _P, _L, _P]),
     'genie_embedding_bwd': (C.c_int, [_P, _P, _I, _P, _L, _I, _L, _P]),
     'genie_guard_alloc': (C.c_int, [_L, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     'genie_guard_free': (C.c_int, [_P]),

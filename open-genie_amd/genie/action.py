@@ -72,7 +72,9 @@ class LatentAction(nn.Module):
             raise RuntimeError(f'to_act expects {wt.shape[1]} features per frame, the encoder produced {c}x{h}x{w}')
         w_perm = wt.reshape(-1, c, h, w).permute(0, 2, 3, 1).reshape(wt.shape[0], -1)
         frames = x.permute(0, 2, 3, 4, 1).reshape(b * t, h * w * c)            # zero-copy view of the CL buffer
-        return (frames @ w_perm.to(frames.dtype).t()).float().reshape(b, t, -1)
+        # (B T, h w c) x (d, h w c)^T in fp32 arithmetic (csrc/linear_small.hip: the 2^18 .. 2^20-long reduction in register-resident weight
+        # slices, partials summed in a fixed order); rounds 1-5: one bf16 library GEMM
+        return GF.linear(frames, w_perm.contiguous(), None, out_dtype=torch.float32).reshape(b, t, -1)
 
     def encode(self, video: Tensor, mask: Tensor | None = None, transpose: bool = False):
         video = self.proj_in(video)

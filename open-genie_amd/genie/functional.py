@@ -710,6 +710,92 @@ def linear_cross_entropy(h: Tensor, weight: Tensor, bias: Optional[Tensor], wpac
 
 
 # ------------------------------------------------------------------------------------------------
+# Skinny linears (min(in, out) <= 32): AdaGN's condition projections, the LFQ projections, cond K / V, LatentAction.to_act
+# ------------------------------------------------------------------------------------------------
+def linear_small_supported(in_features: int, out_features: int) -> bool:
+    return min(int(in_features), int(out_features)) <= 32
+
+
+class _LinearSmallFn(torch.autograd.Function):
+    """y = x W^T + b in fp32 arithmetic (genie_linear_small_fwd; csrc/linear_small.hip) for the weights of the hot path that have a side of
+    <= 32 features.  x: (..., K) fp32 or bf16 rows; weight (N, K) fp32; y: (..., N) in `out_dtype`.  Backward: dx = the same kernel over dy with
+    the weight's strides exchanged; dW / db by genie_linear_small_wgrad (partials summed in a fixed order: no atomics), straight into the
+    parameters' gradient buffers where they are arena / leaf parameters."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, weight: Tensor, bias: Optional[Tensor], out_dtype: torch.dtype):
+        lib = _hip.load_library()
+        n, k = weight.shape
+        lead = x.shape[:-1]
+        rows = x.reshape(-1, k)
+        if rows.dtype not in (torch.float32, torch.bfloat16):
+            rows = rows.float()
+        if rows.stride(-1) != 1 or (rows.shape[0] > 1 and rows.stride(0) < k):
+            rows = rows.contiguous()
+        w = weight.detach()
+        assert w.dtype == torch.float32 and w.dim() == 2
+        m = rows.shape[0]
+        y = torch.empty((m, n), dtype=out_dtype, device=x.device)
+        dt = lambda t: _hip.GENIE_F32 if t.dtype == torch.float32 else _hip.GENIE_BF16
+        ws_n = lib.genie_linear_small_ws_floats(m, k, n)
+        ws = workspace(ws_n, x.device, 'lin') if ws_n else None
+        _hip.check(lib.genie_linear_small_fwd(rows.data_ptr(), dt(rows), rows.stride(0) if m > 1 else k, m, k, w.data_ptr(), w.stride(0), w.stride(1),
+                                              _hip.ptr(None if bias is None else bias.detach()), y.data_ptr(), dt(y), n, n, _hip.ptr(ws), ws_n, _hip.stream_ptr()),
+                   'genie_linear_small_fwd')
+        ctx.save_for_backward(rows)
+        ctx.weight, ctx.bias, ctx.x_shape, ctx.x_dtype = weight, bias, tuple(x.shape), x.dtype
+        return y.reshape(*lead, n)
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        (rows,) = ctx.saved_tensors
+        weight, bias = ctx.weight, ctx.bias
+        lib = _hip.load_library()
+        n, k = weight.shape
+        m = rows.shape[0]
+        g = dy.reshape(-1, n)
+        if g.dtype not in (torch.float32, torch.bfloat16):
+            g = g.float()
+        if g.stride(-1) != 1 or (m > 1 and g.stride(0) < n):
+            g = g.contiguous()
+        dt = lambda t: _hip.GENIE_F32 if t.dtype == torch.float32 else _hip.GENIE_BF16
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            w = weight.detach()
+            dxr = torch.empty((m, k), dtype=torch.float32 if ctx.x_dtype == torch.float32 else torch.bfloat16, device=dy.device)
+            ws_n = lib.genie_linear_small_ws_floats(m, n, k)
+            ws = workspace(ws_n, dy.device, 'lin') if ws_n else None
+            # dx[m][k] = sum_n dy[m][n] W[n][k]: "weight" W'[k][n] = W[n][k], i.e. the strides exchanged
+            _hip.check(lib.genie_linear_small_fwd(g.data_ptr(), dt(g), g.stride(0) if m > 1 else n, m, n, w.data_ptr(), w.stride(1), w.stride(0), None,
+                                                  dxr.data_ptr(), dt(dxr), k, k, _hip.ptr(ws), ws_n, _hip.stream_ptr()), 'genie_linear_small_fwd (dx)')
+            dx = dxr.reshape(ctx.x_shape).to(ctx.x_dtype)
+        need_w, need_b = ctx.needs_input_grad[1], bias is not None and ctx.needs_input_grad[2]
+        if need_w or need_b:
+            direct_w = need_w and weight.is_leaf and _direct(weight)
+            direct_b = need_b and bias.is_leaf and _direct(bias)
+            gw = _grad_buffer(weight) if direct_w else torch.zeros((n, k), dtype=torch.float32, device=dy.device)
+            gb = (_grad_buffer(bias) if direct_b else torch.zeros(n, dtype=torch.float32, device=dy.device)) if need_b else None
+            ws_n = lib.genie_linear_small_wgrad_ws_floats(m, n, k)
+            ws = workspace(ws_n, dy.device, 'linw')
+            _hip.check(lib.genie_linear_small_wgrad(g.data_ptr(), dt(g), g.stride(0) if m > 1 else n, rows.data_ptr(), dt(rows), rows.stride(0) if m > 1 else k,
+                                                    m, n, k, gw.data_ptr(), gw.stride(0), gw.stride(1), _hip.ptr(gb), ws.data_ptr(), ws.numel(), _hip.stream_ptr()),
+                       'genie_linear_small_wgrad')
+            dw = None if (direct_w or not need_w) else gw
+            db = None if (direct_b or not need_b) else gb
+        return dx, dw, db, None
+
+
+def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, out_dtype: Optional[torch.dtype] = None) -> Tensor:
+    """``F.linear`` for the hot path's skinny weights (one side <= 32 features, fp32 parameters) on the HIP kernels of csrc/linear_small.hip;
+    anything else -- square projections of non-default blueprints (``to_q`` / ``to_out`` with d_inp != n_head * d_head) -- stays a library GEMM."""
+    n, k = weight.shape
+    if x.is_cuda and weight.dtype == torch.float32 and linear_small_supported(k, n) and (bias is None or bias.dtype == torch.float32):
+        return _LinearSmallFn.apply(x, weight, bias, out_dtype if out_dtype is not None else (x.dtype if x.dtype in (torch.float32, torch.bfloat16) else torch.float32))
+    y = torch.nn.functional.linear(x.to(weight.dtype), weight, bias)
+    return y if out_dtype is None else y.to(out_dtype)
+
+
+# ------------------------------------------------------------------------------------------------
 # Embedding lookup whose gradient goes straight into the parameter's gradient buffer
 # ------------------------------------------------------------------------------------------------
 class _EmbeddingFn(torch.autograd.Function):

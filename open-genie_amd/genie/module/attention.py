@@ -8,7 +8,8 @@ tensor is Q, K and V (attention.py:219-226); with ``d_inp == n_head * d_head`` t
 What runs where:  rotary + LayerNorm -> ``genie_rotary_layernorm_fwd``;  head split / SDPA / head merge / the
 rearranges around them -> ``genie_attention_fwd`` (address arithmetic, nothing is moved);  FFN = GroupNorm +
 Conv3d(+ residual in the epilogue) -> the conv/norm kernels.  The optional condition projections
-(``to_k`` / ``to_v``, attention.py:128-129) and ``to_out`` are plain library GEMMs.
+(``to_k`` / ``to_v``, attention.py:128-129) run on the skinny-linear kernels (functional.linear); ``to_q`` / ``to_out`` of non-default
+blueprints (d_inp != n_head * d_head) are plain library GEMMs.
 """
 from __future__ import annotations
 
@@ -232,8 +233,9 @@ class Attention(nn.Module):
         kext = vext = None
         if cond is not None:
             kc = cond.to(torch.float32)
-            kext = self.to_qkv.to_k(kc).to(torch.bfloat16).contiguous()
-            vext = self.to_qkv.to_v(kc).to(torch.bfloat16).contiguous()
+            lin = lambda mod, t: GF.linear(t, mod.weight, mod.bias, out_dtype=torch.bfloat16) if isinstance(mod, nn.Linear) else mod(t)
+            kext = lin(self.to_qkv.to_k, kc).to(torch.bfloat16).contiguous()       # Linear(key_dim -> C): csrc/linear_small.hip when key_dim <= 32
+            vext = lin(self.to_qkv.to_v, kc).to(torch.bfloat16).contiguous()
         out = _AttnFn.apply(x, self.norm.weight, self.norm.bias, table, kext, vext, self._mode, self.n_head, self.d_head, float(self.scale),
                             bool(self.causal), add_resid, self.norm.eps)
         if not isinstance(self.to_out[1], nn.Identity):

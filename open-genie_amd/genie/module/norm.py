@@ -66,6 +66,6 @@ class AdaptiveGroupNorm(nn.Module):
 
     def forward(self, inp: Tensor, cond: Tensor) -> Tensor:
         c = cond.float().reshape(cond.shape[0], cond.shape[1], -1).mean(-1)        # norm.py:62
-        std = F.linear(c, self.std.weight, self.std.bias)
-        avg = F.linear(c, self.avg.weight, self.avg.bias) if self.avg is not None else None
+        std = GF.linear(c, self.std.weight, self.std.bias)                         # (B, dim_cond) -> (B, C): csrc/linear_small.hip
+        avg = GF.linear(c, self.avg.weight, self.avg.bias) if self.avg is not None else None
         return GF.group_norm(inp, self.num_groups, self.weight, self.bias, self.eps, ada_scale=std, ada_shift=avg)

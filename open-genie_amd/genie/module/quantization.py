@@ -21,7 +21,7 @@ def entropy(p: Tensor, eps: float = 1e-6) -> Tensor:
 class LookupFreeQuantization(nn.Module):
     """quant = sign(x), idx = MSB-first bit pack, straight-through gradient; in training mode also the
     entropy + commitment loss over all 2^d codes, computed (with its gradient) by ``genie_lfq_loss`` without
-    materialising the N x 2^d probability matrix.  ``proj_inp`` / ``proj_out`` are plain library GEMMs."""
+    materialising the N x 2^d probability matrix.  ``proj_inp`` / ``proj_out`` run on the skinny-linear kernels (functional.linear)."""
 
     def __init__(self, codebook_dim: int, num_codebook: int = 1, input_dim: int | None = None, use_bias: bool = True,
                  frac_sample: float = 1., commit_weight: float = 0.25, entropy_weight: float = 0.1,
@@ -56,7 +56,7 @@ class LookupFreeQuantization(nn.Module):
         x = inp.movedim(1, -1) if transpose else inp
         lead = x.shape[:-1]
         if project:
-            z = self.proj_inp(x.to(self.proj_inp.weight.dtype))
+            z = GF.linear(x, self.proj_inp.weight, self.proj_inp.bias, out_dtype=torch.float32)      # fp32 arithmetic, fp32 z (csrc/linear_small.hip)
             rows = z.reshape(-1, c * d)
         elif transpose and inp.dim() == 5 and is_cl(inp):
             rows = x.reshape(-1, x.shape[-1])              # zero-copy view of the CL latent (pitch = channel pitch)
@@ -68,7 +68,7 @@ class LookupFreeQuantization(nn.Module):
             rows = rows.contiguous()
         quant, idxs, loss4 = GF.lfq_rows(rows, c, d, self.training, float(beta), self.commit_weight, self.entropy_weight,
                                           self.diversity_weight)
-        out = self.proj_out(quant.to(self.proj_out.weight.dtype)) if project else quant
+        out = GF.linear(quant, self.proj_out.weight, self.proj_out.bias, out_dtype=torch.float32) if project else quant
         out = out.reshape(*lead, out.shape[-1])
         if transpose:
             out = out.movedim(-1, 1)

@@ -964,3 +964,51 @@ def test_embedding_lookup_and_sparse_backward(G, n, d, v, dt):
     G.hip.check(G.hip.load_library().genie_embedding_bwd(idx.cuda().data_ptr(), dyb.data_ptr(), G.hip.GENIE_BF16, g.data_ptr(), n, d, v, G.hip.stream_ptr()), 'emb')
     ref_b = torch.full((v, d), 0.25).index_add_(0, idx, dyb.float().cpu())
     torch.testing.assert_close(g.cpu(), ref_b, rtol=1e-5, atol=1e-5 * ref_b.abs().max().item())
+
+
+@pytest.mark.parametrize('m,k,n,xdt,odt,bias', [
+    (64, 18, 512, torch.float32, torch.float32, True),          # AdaGN std / avg
+    (5000, 512, 10, torch.bfloat16, torch.float32, True),       # LFQ proj_inp (R-yaml)
+    (5000, 10, 512, torch.float32, torch.float32, True),        # LFQ proj_out
+    (300, 8, 256, torch.float32, torch.bfloat16, False),        # cond to_k / to_v
+    (64, 262144, 8, torch.bfloat16, torch.float32, False),      # LatentAction.to_act: 256 slices of the reduction axis
+    (3, 40000, 8, torch.bfloat16, torch.float32, False),        # ragged slices, fewer rows than waves
+    (777, 512, 18, torch.float32, torch.float32, False),        # out in (16, 32]: the 4-wide rowdot form (AdaGN's backward-data shape)
+    (1, 5, 3, torch.float32, torch.float32, True),
+])
+def test_linear_small_forward_backward(G, m, k, n, xdt, odt, bias):
+    """functional.linear (genie_linear_small_fwd / _wgrad, csrc/linear_small.hip) against F.linear in fp32 on the CPU: every call site's shape class,
+    forward, backward-data (the same kernel with the weight's strides exchanged), weight / bias gradients accumulated into existing buffers, and
+    run-to-run bit-reproducibility of the weight gradient (fixed-order partial sums, no atomics)."""
+    from genie import functional as GF
+    torch.manual_seed(7 + m + n)
+    x = torch.randn(m, k)
+    if xdt == torch.bfloat16:
+        x = bf16_round(x)
+    w = torch.randn(n, k) / k ** 0.5
+    b = torch.randn(n) if bias else None
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True) if bias else None
+    ref = F.linear(xr, wr, br)
+    dy = bf16_round(torch.randn(m, n))
+    ref.backward(dy)
+    xd = x.cuda().to(xdt).requires_grad_(True)
+    wd = w.cuda().requires_grad_(True)
+    bd = b.cuda().requires_grad_(True) if bias else None
+    assert GF.linear_small_supported(k, n)
+    y = GF.linear(xd, wd, bd, out_dtype=odt)
+    assert y.dtype == odt and tuple(y.shape) == (m, n)
+    tol = 1e-4 if odt == torch.float32 else 2 ** -7
+    scale = ref.detach().abs().max().item() + 1e-6
+    assert (y.float().cpu() - ref.detach()).abs().max().item() <= tol * scale, (y.float().cpu() - ref.detach()).abs().max().item() / scale
+    y.backward(dy.cuda().to(y.dtype))
+    gx_tol = 1e-4 if xdt == torch.float32 else 2 ** -7
+    assert (xd.grad.float().cpu() - xr.grad).abs().max().item() <= gx_tol * (xr.grad.abs().max().item() + 1e-6)
+    assert (wd.grad.cpu() - wr.grad).abs().max().item() <= 1e-4 * (wr.grad.abs().max().item() + 1e-6)
+    if bias:
+        assert (bd.grad.cpu() - br.grad).abs().max().item() <= 1e-4 * (br.grad.abs().max().item() + 1e-6)
+    # bit-reproducible, and accumulating: a second backward doubles the gradient exactly
+    g1 = wd.grad.clone()
+    y2 = GF.linear(xd, wd, bd, out_dtype=odt)
+    y2.backward(dy.cuda().to(y2.dtype))
+    assert torch.equal(wd.grad, g1 + g1)
