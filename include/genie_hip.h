@@ -453,6 +453,17 @@ int genie_attention_bwd(const void* q, const void* k, const void* v, const void*
                         const int64_t* q_map, const int64_t* kv_map, const int64_t* out_map, const int64_t* dkv_map, float scale,
                         int causal, int out_channels, int64_t out_tokens, void* stream);
 
+/* Backward of CONDITIONED short sequences (ABI 12; attention.hip: attn_smallx_bwd_kernel) -- temporal attention of the LatentAction decoder, whose keys /
+ * values are Linear(8 -> C) of the per-clip action codes (reference attention.py:128-129, 222-223; action.py:136-160): Sq = Sk = S <= 32, d_head 32 / 64,
+ * kv_map with inner stride 0 (the n_inner sequences of a clip share the rows).  The forward of this form is taken by genie_attention_fwd on its own.
+ * dq: q_map addressing, bf16.  dk_f32 / dv_f32: fp32 [nseq / n_inner][S][kv_channels], ACCUMULATED with atomics (zero them first): the gradients of the
+ * condition rows summed over every sequence of the clip -- genie_attention_bwd would return them per sequence.  Returns < 0 when the problem is not of this
+ * form (use genie_attention_bwd then).  D_ws as in genie_attention_bwd. */
+int genie_attention_bwd_cond(const void* q, const void* k, const void* v, const void* out, const void* resid, const void* dO, const float* lse,
+                             float* D_ws, void* dq, float* dk_f32, float* dv_f32, int nseq, int nhead, int d_head, int S, const int64_t* q_map,
+                             const int64_t* kv_map, const int64_t* out_map, float scale, int causal, int out_channels, int kv_channels,
+                             int64_t out_tokens, void* stream);
+
 /* d_head 64 runs on register-lean kernels (attention_lean.hip: four / three waves per SIMD) where their preconditions hold.  mask: bit 0
  * forward, bit 1 backward dQ, bit 2 backward dK / dV; bit 3: reserved; bit 4: the forward's running maximum is
  * deferred (O, l rescaled only when a tile's maximum exceeds it by more than 2^8 in the exp2 domain; P <= 2^8 instead of <= 1, the row's

@@ -595,34 +595,55 @@ __device__ __forceinline__ bool small_row_valid(int row, long long seq0, int nse
     return (seq0 + row / TP < nseq) && ((row & (TP - 1)) < S);
 }
 
-template <int DH, int TP>
+// CROSS (round 6): the keys / values are a CONDITION shared by every sequence of a clip -- the quantised action of the LatentAction decoder
+// (action.py:136-160: temporal attention over the pixels of a clip with K, V = Linear(8 -> C) of the (B, T, 8) action codes, attention.py:222-223) --
+// addressed through a kv map whose inner stride is 0.  Row r of the wave's K / V tiles is the condition row of (clip of sequence r / TP, frame r % TP);
+// S^T = K U^T instead of U U^T, everything else as the packed self-attention form.  Rounds 1-5 sent these calls through the general one-wave kernel
+// (1.23 ms per call in the LatentAction step against 0.27 ms for the self-attention layers of the same size).
+template <int DH, int TP, bool CROSS>
 __global__ void __launch_bounds__(256) attn_small_fwd_kernel(const AttnArgs a) {
     constexpr int ROWB = DH * 2, CPR = DH / 8, WTILE = 32 * ROWB, KS = DH / 16, DT = DH / 32, PCS = WTILE / 1024, SPW = 32 / TP;
-    __shared__ __attribute__((aligned(1024))) char smem[4 * 2 * WTILE];      // per wave: 32 rows of bf16 in, 32 rows of fp32 out
+    constexpr int WLDS = (CROSS ? 4 : 2) * WTILE;                            // per wave: 32 rows of bf16 in, 32 rows of fp32 out (+ K rows, V rows)
+    constexpr int VOFF = CROSS ? 3 * WTILE : 0;
+    __shared__ __attribute__((aligned(1024))) char smem[4 * WLDS];
     const int lane = threadIdx.x & 63, h = lane >> 5, lr = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long long wg = (long long)blockIdx.x * 4 + wave;
     const int head = (int)(wg % a.nhead);
     const long long seq0 = (wg / a.nhead) * SPW;
     if (seq0 >= a.nseq) return;
-    char* lds = smem + wave * 2 * WTILE;
+    char* lds = smem + wave * WLDS;
     const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page_a);
 #pragma unroll
     for (int i = 0; i < PCS; ++i) {
         const int idx = i * 64 + lane, row = idx / CPR;
         const bf16_t* src = zero;
-        if (small_row_valid<TP>(row, seq0, a.nseq, a.Sq))
-            src = a.k + seq_base(a.km, (int)(seq0 + row / TP)) + (long long)(row & (TP - 1)) * a.km.pos_stride + head * DH +
-                  attn_swz<CPR>(row, idx % CPR) * 8;
+        const bf16_t* sk = zero;
+        const bf16_t* sv = zero;
+        if (small_row_valid<TP>(row, seq0, a.nseq, a.Sq)) {
+            const int seq = (int)(seq0 + row / TP), pos = row & (TP - 1), c = attn_swz<CPR>(row, idx % CPR) * 8;
+            src = (CROSS ? a.q + seq_base(a.qm, seq) + (long long)pos * a.qm.pos_stride : a.k + seq_base(a.km, seq) + (long long)pos * a.km.pos_stride) + head * DH + c;
+            if (CROSS) {
+                sk = a.k + seq_base(a.km, seq) + (long long)pos * a.km.pos_stride + head * DH + c;
+                sv = a.v + seq_base(a.km, seq) + (long long)pos * a.km.pos_stride + head * DH + c;
+            }
+        }
         __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(lds + i * 1024), 16, 0, 0);
+        if (CROSS) {
+            __builtin_amdgcn_global_load_lds(GLB_PTR(sk), LDS_PTR(lds + 2 * WTILE + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(sv), LDS_PTR(lds + 3 * WTILE + i * 1024), 16, 0, 0);
+        }
     }
     const int g16 = lane >> 4, rr = (lane >> 2) & 3, qq = lane & 3;
     const uint32_t lds_off = attn_lds_offset(lds);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    bf16x8_t uf[KS];
+    bf16x8_t uf[KS], kf[KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) uf[ks] = *reinterpret_cast<const bf16x8_t*>(lds + lr * ROWB + (attn_swz<CPR>(lr, ks * 2 + h) << 4));
+    for (int ks = 0; ks < KS; ++ks) {
+        uf[ks] = *reinterpret_cast<const bf16x8_t*>(lds + lr * ROWB + (attn_swz<CPR>(lr, ks * 2 + h) << 4));
+        kf[ks] = CROSS ? *reinterpret_cast<const bf16x8_t*>(lds + 2 * WTILE + lr * ROWB + (attn_swz<CPR>(lr, ks * 2 + h) << 4)) : uf[ks];
+    }
     bf16x4_t vlo[2][DT], vhi[2][DT];
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
@@ -630,15 +651,15 @@ __global__ void __launch_bounds__(256) attn_small_fwd_kernel(const AttnArgs a) {
 #pragma unroll
         for (int d = 0; d < DT; ++d) {
             const int col = d * 32 + 16 * (g16 & 1) + 4 * qq;
-            vlo[s2][d] = attn_tr16(lds_off + (uint32_t)(r0 * ROWB + (attn_swz<CPR>(r0, col >> 3) << 4) + (col & 7) * 2));
-            vhi[s2][d] = attn_tr16(lds_off + (uint32_t)(r1 * ROWB + (attn_swz<CPR>(r1, col >> 3) << 4) + (col & 7) * 2));
+            vlo[s2][d] = attn_tr16i<VOFF>(lds_off + (uint32_t)(r0 * ROWB + (attn_swz<CPR>(r0, col >> 3) << 4) + (col & 7) * 2));
+            vhi[s2][d] = attn_tr16i<VOFF>(lds_off + (uint32_t)(r1 * ROWB + (attn_swz<CPR>(r1, col >> 3) << 4) + (col & 7) * 2));
         }
     }
     f32x16_t sacc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uf[ks], uf[ks], sacc, 0, 0, 0);
+    for (int ks = 0; ks < KS; ++ks) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], uf[ks], sacc, 0, 0, 0);      // S^T[key][query]
 
     const bool q_ok = small_row_valid<TP>(lr, seq0, a.nseq, a.Sq);
     const int qpos = lr & (TP - 1);
@@ -729,6 +750,15 @@ static SeqMap mk_map(const int64_t* m) {
 static bool same_map(const SeqMap& x, const SeqMap& y) {
     return x.n_inner == y.n_inner && x.stride_outer == y.stride_outer && x.stride_inner == y.stride_inner && x.pos_stride == y.pos_stride;
 }
+static int small_attn_mode();
+// conditioned short sequences (attn_small_fwd_kernel<.., CROSS> / attn_smallx_bwd_kernel): Sq == Sk <= 32, d_head 32 / 64, K / V rows shared by the
+// n_inner sequences of a clip (kv map: inner stride 0), whole packed groups per clip
+template <class Args>
+static bool small_cond_ok(const Args& a, const void* q, const void* k, const void* v, int d_head) {
+    if (q == k || q == v || !small_attn_mode() || a.Sq != a.Sk || a.Sq > 32 || !(d_head == 32 || d_head == 64)) return false;
+    const int tp = a.Sq <= 8 ? 8 : (a.Sq <= 16 ? 16 : 32);
+    return a.km.stride_inner == 0 && a.km.n_inner >= 1 && a.km.n_inner % (32 / tp) == 0 && a.nseq % a.km.n_inner == 0;
+}
 static int small_attn_mode() {          // GENIE_ATTN_SMALL=0 sends short sequences through the general kernels (A/B timing, tests)
     static int mode = -1;
     if (mode < 0) { const char* e = getenv("GENIE_ATTN_SMALL"); mode = e ? atoi(e) : 1; }
@@ -757,12 +787,27 @@ extern "C" int genie_attention_fwd(const void* q, const void* k, const void* v, 
         const unsigned blocks = (unsigned)((waves + 3) / 4);
 #define GENIE_ATTN_SMALL(DHv)                                                                            \
     do {                                                                                                 \
-        if (tp == 8) attn_small_fwd_kernel<DHv, 8><<<blocks, 256, 0, s>>>(a);                            \
-        else if (tp == 16) attn_small_fwd_kernel<DHv, 16><<<blocks, 256, 0, s>>>(a);                     \
-        else attn_small_fwd_kernel<DHv, 32><<<blocks, 256, 0, s>>>(a);                                   \
+        if (tp == 8) attn_small_fwd_kernel<DHv, 8, false><<<blocks, 256, 0, s>>>(a);                     \
+        else if (tp == 16) attn_small_fwd_kernel<DHv, 16, false><<<blocks, 256, 0, s>>>(a);              \
+        else attn_small_fwd_kernel<DHv, 32, false><<<blocks, 256, 0, s>>>(a);                            \
     } while (0)
         if (d_head == 32) GENIE_ATTN_SMALL(32); else if (d_head == 64) GENIE_ATTN_SMALL(64); else GENIE_ATTN_SMALL(128);
 #undef GENIE_ATTN_SMALL
+        GENIE_CHECK_LAUNCH();
+        return GENIE_OK;
+    }
+    if (small_cond_ok(a, q, k, v, d_head)) {               // packed short sequences against a per-clip condition (kv map with inner stride 0)
+        const int tp = Sq <= 8 ? 8 : (Sq <= 16 ? 16 : 32);
+        const long long waves = ((long long)nseq / (32 / tp)) * nhead;
+        const unsigned blocks = (unsigned)((waves + 3) / 4);
+#define GENIE_ATTN_SMALLX(DHv)                                                                           \
+    do {                                                                                                 \
+        if (tp == 8) attn_small_fwd_kernel<DHv, 8, true><<<blocks, 256, 0, s>>>(a);                      \
+        else if (tp == 16) attn_small_fwd_kernel<DHv, 16, true><<<blocks, 256, 0, s>>>(a);               \
+        else attn_small_fwd_kernel<DHv, 32, true><<<blocks, 256, 0, s>>>(a);                             \
+    } while (0)
+        if (d_head == 32) GENIE_ATTN_SMALLX(32); else GENIE_ATTN_SMALLX(64);
+#undef GENIE_ATTN_SMALLX
         GENIE_CHECK_LAUNCH();
         return GENIE_OK;
     }
@@ -1416,6 +1461,192 @@ __global__ void __launch_bounds__(128) attn_small_bwd_kernel(const AttnBwdArgs a
     }
 }
 
+// Backward of the conditioned packed form (attn_small_fwd_kernel<.., CROSS>): dQ per row as above; dK / dV are gradients of the CONDITION rows,
+// i.e. sums over every sequence of a clip.  Rounds 1-5 produced them per sequence (two more tensors of the activation's size) and summed them with
+// torch (a bf16 -> fp32 copy and a reduction each).  Here a wave owns a run of packed groups of ONE (clip, head): the K / V tiles are loaded once,
+// dK^T / dV^T accumulate in registers over the whole run, and leave as fp32 atomics onto the (clip, frame, channel) rows -- one tile per wave.
+// Orientation: "a" = lane is the query (S^T = K U^T, dP^T = V dO^T -> dS^T -> dQ^T += K^T dS^T), "b" = lane is the key (S = U K^T, dP = dO V^T -> dS, P ->
+// dK^T += U^T dS, dV^T += dO^T P); S is not symmetric any more, so both orientations are multiplied out.
+template <int DH, int TP>
+__global__ void __launch_bounds__(128) attn_smallx_bwd_kernel(const AttnBwdArgs a, float* __restrict__ dk32, float* __restrict__ dv32, int wpc, int gpw) {
+    constexpr int ROWB = DH * 2, CPR = DH / 8, WTILE = 32 * ROWB, KS = DH / 16, DT = DH / 32, PCS = WTILE / 1024, SPW = 32 / TP;
+    constexpr int WSTAGE = 4 * WTILE + 256;          // U rows | dO rows | K rows | V rows | lse [32] | D [32]
+    __shared__ __attribute__((aligned(1024))) char smem[2 * WSTAGE];
+    const int lane = threadIdx.x & 63, h = lane >> 5, lr = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long wid = (long long)blockIdx.x * 2 + wave;
+    const int part = (int)(wid % wpc);
+    const long long ch = wid / wpc;
+    const int head = (int)(ch % a.nhead);
+    const int clip = (int)(ch / a.nhead);
+    const int nclip = a.nseq / a.km.n_inner, G = a.km.n_inner / SPW;
+    if (clip >= nclip) return;
+    const int g_lo = part * gpw, g_hi = min(G, g_lo + gpw);
+    if (g_lo >= g_hi) return;
+    char* lds = smem + wave * WSTAGE;
+    const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page_a);
+    const int mypos = lr & (TP - 1);
+    // condition rows of the clip: row r <- frame r % TP (the SPW copies are identical)
+#pragma unroll
+    for (int i = 0; i < PCS; ++i) {
+        const int idx = i * 64 + lane, row = idx / CPR, pos = row & (TP - 1);
+        const bf16_t* sk = zero;
+        const bf16_t* sv = zero;
+        if (pos < a.Sk) {
+            const long long o = seq_base(a.km, clip * a.km.n_inner) + (long long)pos * a.km.pos_stride + head * DH + attn_swz<CPR>(row, idx % CPR) * 8;
+            sk = a.k + o; sv = a.v + o;
+        }
+        __builtin_amdgcn_global_load_lds(GLB_PTR(sk), LDS_PTR(lds + 2 * WTILE + i * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(GLB_PTR(sv), LDS_PTR(lds + 3 * WTILE + i * 1024), 16, 0, 0);
+    }
+    const int g16 = lane >> 4, rr = (lane >> 2) & 3, qq = lane & 3;
+    const uint32_t lds_off = attn_lds_offset(lds);
+    const float c2 = a.scale * 1.4426950408889634f;
+    f32x16_t acckk[DT], accv[DT];                    // dK^T, dV^T of the wave's condition rows, summed over the run
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acckk[d][r] = 0.f; accv[d][r] = 0.f; }
+
+    for (int g = g_lo; g < g_hi; ++g) {
+        const long long seq0 = (long long)clip * a.km.n_inner + (long long)g * SPW;
+#pragma unroll
+        for (int i = 0; i < PCS; ++i) {
+            const int idx = i * 64 + lane, row = idx / CPR;
+            const bf16_t* su = zero;
+            const bf16_t* sd = zero;
+            if ((row & (TP - 1)) < a.Sq) {
+                const int seq = (int)(seq0 + row / TP), pos = row & (TP - 1), c = attn_swz<CPR>(row, idx % CPR) * 8;
+                su = a.q + seq_base(a.qm, seq) + (long long)pos * a.qm.pos_stride + head * DH + c;
+                sd = a.dO + seq_base(a.om, seq) + (long long)pos * a.om.pos_stride + head * DH + c;
+            }
+            __builtin_amdgcn_global_load_lds(GLB_PTR(su), LDS_PTR(lds + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(sd), LDS_PTR(lds + WTILE + i * 1024), 16, 0, 0);
+        }
+        const bool my_ok = mypos < a.Sq;
+        {   // lanes 0..31: lse of row lr, lanes 32..63: D of row lr
+            const float* src = reinterpret_cast<const float*>(zero);
+            if (my_ok) {
+                const long long tok = (seq_base(a.om, (int)(seq0 + lr / TP)) + (long long)mypos * a.om.pos_stride) / a.C;
+                src = (h ? a.D : a.lse) + tok * a.nhead + head;
+            }
+            __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(lds + 4 * WTILE), 4, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+        bf16x8_t uf[KS], df[KS], kf[KS], vf[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int o = lr * ROWB + (attn_swz<CPR>(lr, ks * 2 + h) << 4);
+            uf[ks] = *reinterpret_cast<const bf16x8_t*>(lds + o);
+            df[ks] = *reinterpret_cast<const bf16x8_t*>(lds + WTILE + o);
+            kf[ks] = *reinterpret_cast<const bf16x8_t*>(lds + 2 * WTILE + o);
+            vf[ks] = *reinterpret_cast<const bf16x8_t*>(lds + 3 * WTILE + o);
+        }
+        const float* lse_l = reinterpret_cast<const float*>(lds + 4 * WTILE);
+        const float* D_l = lse_l + 32;
+        const float my_lse2 = lse_l[lr] * 1.4426950408889634f, my_D = D_l[lr];
+        f32x16_t st, pt, sn, pn;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { st[r] = 0.f; pt[r] = 0.f; sn[r] = 0.f; pn[r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], uf[ks], st, 0, 0, 0);          // S^T[key][query]
+            pt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[ks], df[ks], pt, 0, 0, 0);          // dP^T[key][query]
+            sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uf[ks], kf[ks], sn, 0, 0, 0);          // S[query][key]
+            pn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df[ks], vf[ks], pn, 0, 0, 0);          // dP[query][key]
+        }
+        f32x16_t dsa, dsb;               // sn is reused for P (lane = key orientation)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const f32x4_t l4 = *reinterpret_cast<const f32x4_t*>(lse_l + 8 * gq + 4 * h);
+            const f32x4_t d4 = *reinterpret_cast<const f32x4_t*>(D_l + 8 * gq + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 4 * gq + e, row = 8 * gq + 4 * h + e, rpos = row & (TP - 1);
+                const bool pair = my_ok && ((row ^ lr) & ~(TP - 1)) == 0 && rpos < a.Sq;
+                const bool ok_a = pair && (!a.causal || rpos <= mypos);          // key = row, query = this lane
+                const bool ok_b = pair && (!a.causal || mypos <= rpos);          // query = row, key = this lane
+                const float pa = ok_a ? __builtin_amdgcn_exp2f(st[r] * c2 - my_lse2) : 0.f;
+                const float pb = ok_b ? __builtin_amdgcn_exp2f(sn[r] * c2 - l4[e] * 1.4426950408889634f) : 0.f;
+                dsa[r] = pa * (pt[r] - my_D);
+                dsb[r] = pb * (pn[r] - d4[e]);
+                sn[r] = pb;
+            }
+        }
+        f32x16_t accq[DT];
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accq[d][r] = 0.f;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            u32x4_t wa, wb, wp;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                wa[e] = pack_bf16x2(dsa[8 * s2 + 2 * e], dsa[8 * s2 + 2 * e + 1]);
+                wb[e] = pack_bf16x2(dsb[8 * s2 + 2 * e], dsb[8 * s2 + 2 * e + 1]);
+                wp[e] = pack_bf16x2(sn[8 * s2 + 2 * e], sn[8 * s2 + 2 * e + 1]);
+            }
+            const bf16x8_t fa = __builtin_bit_cast(bf16x8_t, wa), fb = __builtin_bit_cast(bf16x8_t, wb), fp = __builtin_bit_cast(bf16x8_t, wp);
+            const int r0 = 16 * s2 + 4 * (g16 >> 1) + rr, r1 = r0 + 8;
+#pragma unroll
+            for (int d = 0; d < DT; ++d) {
+                const int col = d * 32 + 16 * (g16 & 1) + 4 * qq;
+                const uint32_t o0 = lds_off + (uint32_t)(r0 * ROWB + (attn_swz<CPR>(r0, col >> 3) << 4) + (col & 7) * 2);
+                const uint32_t o1 = lds_off + (uint32_t)(r1 * ROWB + (attn_swz<CPR>(r1, col >> 3) << 4) + (col & 7) * 2);
+                bf16x4_t ulo = attn_tr16(o0), uhi = attn_tr16(o1);
+                bf16x4_t dlo = attn_tr16i<WTILE>(o0), dhi = attn_tr16i<WTILE>(o1);
+                bf16x4_t klo = attn_tr16i<2 * WTILE>(o0), khi = attn_tr16i<2 * WTILE>(o1);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                asm volatile("" : "+v"(ulo), "+v"(uhi), "+v"(dlo), "+v"(dhi), "+v"(klo), "+v"(khi));
+                const bf16x8_t uT = __builtin_shufflevector(ulo, uhi, 0, 1, 2, 3, 4, 5, 6, 7);
+                const bf16x8_t dT = __builtin_shufflevector(dlo, dhi, 0, 1, 2, 3, 4, 5, 6, 7);
+                const bf16x8_t kT = __builtin_shufflevector(klo, khi, 0, 1, 2, 3, 4, 5, 6, 7);
+                accq[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kT, fa, accq[d], 0, 0, 0);          // dQ^T += K^T dS^T
+                acckk[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uT, fb, acckk[d], 0, 0, 0);        // dK^T += U^T dS
+                accv[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dT, fp, accv[d], 0, 0, 0);          // dV^T += dO^T P
+            }
+        }
+        // dQ rows go back through the wave's U rows in LDS (all fragment reads of this group are done) and leave as whole 16-B chunks
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                u32x2_t ov;
+                ov[0] = pack_bf16x2(accq[d][4 * gq] * a.scale, accq[d][4 * gq + 1] * a.scale);
+                ov[1] = pack_bf16x2(accq[d][4 * gq + 2] * a.scale, accq[d][4 * gq + 3] * a.scale);
+                *reinterpret_cast<u32x2_t*>(lds + lr * ROWB + (attn_swz<CPR>(lr, d * 4 + gq) << 4) + 8 * h) = ov;
+            }
+#pragma unroll
+        for (int i = 0; i < PCS; ++i) {
+            const int idx = i * 64 + lane, row = idx / CPR;
+            if ((row & (TP - 1)) >= a.Sq) continue;
+            const u32x4_t v = *reinterpret_cast<const u32x4_t*>(lds + idx * 16);
+            *reinterpret_cast<u32x4_t*>(a.dq + seq_base(a.qm, (int)(seq0 + row / TP)) + (long long)(row & (TP - 1)) * a.qm.pos_stride + head * DH +
+                                        attn_swz<CPR>(row, idx % CPR) * 8) = v;
+        }
+        // (the next group's DMA overwrites the U / dO rows: the reads above are complete -- lgkmcnt(0) is implied by the data dependence of the stores)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    // flush: lane = condition row lr -> frame lr % TP; the SPW copies of a frame (lanes lr, lr + TP, ...) are summed first; accumulator (d, r) of lane half h is
+    // channel 32 d + (r & 3) + 8 (r >> 2) + 4 h
+    const bool flush = mypos < a.Sk && (lr / TP) == 0;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float vk = acckk[d][r] * a.scale, vv = accv[d][r];
+#pragma unroll
+            for (int o = TP; o < 32; o <<= 1) { vk += __shfl_xor(vk, o, 64); vv += __shfl_xor(vv, o, 64); }
+            if (flush) {
+                const long long o = ((long long)clip * a.Sk + mypos) * a.Ckv + head * DH + 32 * d + (r & 3) + 8 * (r >> 2) + 4 * h;
+                atomicAdd(dk32 + o, vk);
+                atomicAdd(dv32 + o, vv);
+            }
+        }
+}
+
 // q, k, v, dO: as forward (dO / out / resid share out_map).  Self-attention (q == k == v): du receives dQ + dK + dV.
 // Otherwise dq gets dQ (q-map) and dk / dv (kv-map addressing, caller-provided buffers) get dK / dV.
 extern "C" int genie_attention_bwd(const void* q, const void* k, const void* v, const void* out, const void* resid, const void* dO,
@@ -1492,6 +1723,53 @@ extern "C" int genie_attention_bwd(const void* q, const void* k, const void* v, 
 #undef GENIE_ATTN_BWD_DH
 #undef GENIE_ATTN_DKV
 #undef GENIE_ATTN_DQ
+    GENIE_CHECK_LAUNCH();
+    return GENIE_OK;
+}
+
+
+// Conditioned short sequences (see attn_smallx_bwd_kernel): q-map sequences of Sq = Sk <= 32 positions against K / V rows shared by the n_inner sequences of a
+// clip (kv_map inner stride 0).  dq: q-map addressing (bf16); dk_f32 / dv_f32: fp32 [nseq / n_inner][Sk][kv_channels], ACCUMULATED (the caller zeroes them).
+// Returns GENIE_ERR_ARG when the shape is not this form (the caller then takes genie_attention_bwd).
+extern "C" int genie_attention_bwd_cond(const void* q, const void* k, const void* v, const void* out, const void* resid, const void* dO, const float* lse,
+                                        float* D_ws, void* dq, float* dk_f32, float* dv_f32, int nseq, int nhead, int d_head, int S, const int64_t* q_map,
+                                        const int64_t* kv_map, const int64_t* out_map, float scale, int causal, int out_channels, int kv_channels,
+                                        int64_t out_tokens, void* stream) {
+    GENIE_CHECK_ARG(q && k && v && out && dO && lse && D_ws && dq && dk_f32 && dv_f32 && q_map && kv_map && out_map, "genie_attention_bwd_cond: null pointer");
+    GENIE_CHECK_ARG(scale > 0.f && nseq >= 1 && nhead >= 1 && S >= 1, "genie_attention_bwd_cond: bad scale / empty problem");
+    AttnBwdArgs a;
+    a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.dO = (const bf16_t*)dO; a.lse = lse; a.D = D_ws;
+    a.lse2 = D_ws + out_tokens * nhead; a.negD = D_ws + 2 * out_tokens * nhead;
+    a.dq = (bf16_t*)dq; a.dk = nullptr; a.dv = nullptr; a.dq_in = nullptr;
+    a.qm = mk_map(q_map); a.km = mk_map(kv_map); a.om = mk_map(out_map); a.dkm = a.km;
+    a.nseq = nseq; a.nhead = nhead; a.Sq = S; a.Sk = S; a.C = out_channels; a.Ckv = kv_channels; a.scale = scale; a.causal = causal;
+    a.kv_same = (k == v) ? 1 : 0; a.fuse_self = 0; a.xcd_swizzle = 0; a.out = (const bf16_t*)out; a.resid = (const bf16_t*)resid;
+    GENIE_CHECK_ARG(small_cond_ok(a, q, k, v, d_head), "genie_attention_bwd_cond: not a conditioned short-sequence problem (S = %d <= 32, d_head %d in {32, 64}, kv map inner "
+                    "stride 0, n_inner %d a multiple of the packed group)", S, d_head, a.km.n_inner);
+    GENIE_CHECK_ARG(kv_channels >= nhead * d_head && out_channels >= nhead * d_head, "genie_attention_bwd_cond: channels");
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned pblocks = (unsigned)((out_tokens + 3) / 4);
+    if (d_head == 32) attn_bwd_prep_kernel<32><<<pblocks, 256, 0, s>>>((const bf16_t*)dO, (const bf16_t*)out, (const bf16_t*)resid, D_ws, out_tokens, out_channels, nhead, lse, D_ws + out_tokens * nhead, D_ws + 2 * out_tokens * nhead);
+    else attn_bwd_prep_kernel<64><<<pblocks, 256, 0, s>>>((const bf16_t*)dO, (const bf16_t*)out, (const bf16_t*)resid, D_ws, out_tokens, out_channels, nhead, lse, D_ws + out_tokens * nhead, D_ws + 2 * out_tokens * nhead);
+    GENIE_CHECK_LAUNCH();
+    const int tp = S <= 8 ? 8 : (S <= 16 ? 16 : 32);
+    const int nclip = nseq / a.km.n_inner, G = a.km.n_inner / (32 / tp);
+    // waves per (clip, head): about 8192 waves in all, at least 8 packed groups per wave (each wave ends with one 32 x d_head tile of atomics per gradient)
+    long long wpc = 8192 / ((long long)nclip * nhead);
+    if (wpc < 1) wpc = 1;
+    if (wpc > (G + 7) / 8) wpc = (G + 7) / 8;
+    const int gpw = (int)((G + wpc - 1) / wpc);
+    wpc = (G + gpw - 1) / gpw;
+    const long long waves = (long long)nclip * nhead * wpc;
+    const unsigned blocks = (unsigned)((waves + 1) / 2);
+#define GENIE_ATTN_SMALLX(DHv)                                                                                   \
+    do {                                                                                                         \
+        if (tp == 8) attn_smallx_bwd_kernel<DHv, 8><<<blocks, 128, 0, s>>>(a, dk_f32, dv_f32, (int)wpc, gpw);     \
+        else if (tp == 16) attn_smallx_bwd_kernel<DHv, 16><<<blocks, 128, 0, s>>>(a, dk_f32, dv_f32, (int)wpc, gpw); \
+        else attn_smallx_bwd_kernel<DHv, 32><<<blocks, 128, 0, s>>>(a, dk_f32, dv_f32, (int)wpc, gpw);            \
+    } while (0)
+    if (d_head == 32) GENIE_ATTN_SMALLX(32); else GENIE_ATTN_SMALLX(64);
+#undef GENIE_ATTN_SMALLX
     GENIE_CHECK_LAUNCH();
     return GENIE_OK;
 }

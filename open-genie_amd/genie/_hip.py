@@ -127,6 +127,7 @@ SIGNATURES = {
     'genie_rotary_layernorm_fwd': (C.c_int, [_P, _P, _L, _I, _L, _P, _L, _I, _P, _P, _F, _P, _P]),
     'genie_rotary_layernorm_bwd': (C.c_int, [_P, _P, _P, _P, _L, _I, _L, _P, _L, _I, _P, _P, _P, _P, _P]),
     'genie_attention_fwd': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _PL, _PL, _PL, _F, _I, _I, _P]),
+    'genie_attention_bwd_cond': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _PL, _PL, _PL, _F, _I, _I, _I, _L, _P]),
     'genie_attention_bwd': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _PL, _PL, _PL, _PL, _F, _I, _I, _L, _P]),
     'genie_attention_lean_mode': (C.c_int, [_I]),
     'genie_attention_lean_occupancy': (C.c_int, [_I]),

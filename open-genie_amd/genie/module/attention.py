@@ -103,6 +103,9 @@ def _attn_variant(direction: str, S: int, d_head: int) -> str:
     return f'{fam}_{direction}[{"mfma" if S >= 1024 and d_head >= 32 else "hbm"}]'
 
 
+COND_SMALL = __import__('os').environ.get('GENIE_ATTN_COND_SMALL', '1') != '0'      # A/B: 0 = conditioned short sequences through the general kernels + torch sums
+
+
 class _AttnFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x: Tensor, gamma: Tensor, beta: Tensor, table: Optional[Tensor], kext: Optional[Tensor], vext: Optional[Tensor],
@@ -159,19 +162,34 @@ class _AttnFn(torch.autograd.Function):
         du = empty_like_cl(x)
         D = GF.workspace(3 * ntok * n_head, x.device, 'attn_D')            # D, lse * log2 e, -D (ABI 10)
         P = _hip.ptr
-        dk = dv = None
+        dk = dv = dk32 = dv32 = None
+        inner = t if mode == 'space' else h * w
+        # conditioned SHORT sequences (the LatentAction decoder's temporal attention over the per-clip action codes): the packed kernel sums the
+        # condition rows' gradients over the pixels of a clip itself (genie_attention_bwd_cond) -- rounds 1-5 took them per sequence (two tensors of the
+        # activation's size) and summed them with torch
+        tp = 8 if S <= 8 else (16 if S <= 16 else 32)
+        cond_small = (kext is not None and S == Sk and S <= 32 and d_head in (32, 64) and inner % (32 // tp) == 0 and COND_SMALL)
         if kext is None:
             k, v, dkvmap = u, u, None
         else:
             k, v = kext, vext
-            dk = torch.empty((nseq, Sk, c), dtype=torch.bfloat16, device=x.device)
-            dv = torch.empty_like(dk)
+            if cond_small:
+                dk32 = torch.zeros((b, Sk, c), dtype=torch.float32, device=x.device)
+                dv32 = torch.zeros_like(dk32)
+            else:
+                dk = torch.empty((nseq, Sk, c), dtype=torch.bfloat16, device=x.device)
+                dv = torch.empty_like(dk)
             dkvmap = _hip.i64((1, Sk * c, 0, c))
         prof = _conv.PROFILER if _conv.PROFILER is not None and not _conv.PROFILER.only_triple else None
         t0 = prof.begin() if prof is not None else None
-        _hip.check(lib.genie_attention_bwd(P(u), P(k), P(v), P(out), None, P(dout), P(lse), P(D), P(du), P(dk), P(dv),
-                                           nseq, n_head, d_head, S, Sk, _hip.i64(qmap), _hip.i64(kvmap), _hip.i64(qmap), dkvmap, scale,
-                                           1 if causal else 0, c, ntok, _hip.stream_ptr()), 'genie_attention_bwd')
+        if cond_small:
+            _hip.check(lib.genie_attention_bwd_cond(P(u), P(k), P(v), P(out), None, P(dout), P(lse), P(D), P(du), P(dk32), P(dv32), nseq, n_head, d_head, S,
+                                                    _hip.i64(qmap), _hip.i64(kvmap), _hip.i64(qmap), scale, 1 if causal else 0, c, c, ntok, _hip.stream_ptr()),
+                       'genie_attention_bwd_cond')
+        else:
+            _hip.check(lib.genie_attention_bwd(P(u), P(k), P(v), P(out), None, P(dout), P(lse), P(D), P(du), P(dk), P(dv),
+                                               nseq, n_head, d_head, S, Sk, _hip.i64(qmap), _hip.i64(kvmap), _hip.i64(qmap), dkvmap, scale,
+                                               1 if causal else 0, c, ntok, _hip.stream_ptr()), 'genie_attention_bwd')
         if prof is not None:                              # 2.5 x the forward count (five GEMM units of the maths); traffic: u, out, dout read, du written (+ dq re-read)
             prof.end(_attn_variant('bwd', S, d_head), f'attention bwd {mode} S={S} Sk={Sk} C={c} nseq={nseq}', 10.0 * S * Sk * c * nseq, t0,
                      bytes_=5.0 * ntok * c * 2)
@@ -184,9 +202,11 @@ class _AttnFn(torch.autograd.Function):
                                                   P(GF._f32(gamma)), P(stats), P(dgamma), P(dbeta), _hip.stream_ptr()), 'genie_rotary_layernorm_bwd')
         dkext = dvext = None
         if kext is not None:
-            inner = t if mode == 'space' else h * w
-            dkext = dk.reshape(b, inner, Sk, c).float().sum(1).to(kext.dtype)
-            dvext = dv.reshape(b, inner, Sk, c).float().sum(1).to(vext.dtype)
+            if cond_small:
+                dkext, dvext = dk32.to(kext.dtype), dv32.to(vext.dtype)
+            else:
+                dkext = dk.reshape(b, inner, Sk, c).float().sum(1).to(kext.dtype)
+                dvext = dv.reshape(b, inner, Sk, c).float().sum(1).to(vext.dtype)
         return (dx, None if direct else dgamma, None if direct else dbeta, None, dkext, dvext, None, None, None, None, None, None, None)
 
 

@@ -298,6 +298,69 @@ def test_attention_forward_variants_with_late_maxima(mode):
     torch.testing.assert_close(lse.cpu().reshape(nseq, S, nhead), lse_ref, rtol=2e-3, atol=2e-3)
 
 
+@pytest.mark.parametrize('T,hw,nhead,dh,causal', [(16, 64, 4, 64, True), (5, 12, 2, 32, True), (32, 6, 2, 64, True), (20, 8, 1, 64, False), (8, 16, 2, 64, True)])
+def test_attention_conditioned_short_sequences(T, hw, nhead, dh, causal):
+    """Temporal attention against a per-clip condition (LatentAction decoder, action.py:136-160: K, V = Linear(8 -> C) of the action codes, shared by
+    every pixel of a clip) through the C ABI: genie_attention_fwd takes the packed CROSS form on its own (kv map with inner stride 0),
+    genie_attention_bwd_cond returns dq per token and dK / dV of the CONDITION rows summed over the clip's pixels in fp32 -- against fp32 softmax
+    attention and autograd, and against the general kernels + a host-side sum (GENIE_ATTN_SMALL-independent path: genie_attention_bwd)."""
+    from genie import _hip
+    lib = _hip.load_library()
+    P = _hip.ptr
+    torch.manual_seed(100 + T + hw)
+    B = 3
+    c = nhead * dh
+    scale = nhead * dh ** -0.5
+    u = bf16_round(torch.randn(B, hw, T, c) * 0.6)               # token rows of the video in (b, pixel, t, c) order for the reference
+    kc = bf16_round(torch.randn(B, T, c) * 0.6)
+    vc = bf16_round(torch.randn(B, T, c))
+    do = bf16_round(torch.randn(B, hw, T, c) * 0.5)
+    ur, kr, vr = u.clone().requires_grad_(True), kc.clone().requires_grad_(True), vc.clone().requires_grad_(True)
+    qh = ur.reshape(B, hw, T, nhead, dh).permute(0, 1, 3, 2, 4)                        # b p h t d
+    kh = kr.reshape(B, 1, T, nhead, dh).permute(0, 1, 3, 2, 4)
+    vh = vr.reshape(B, 1, T, nhead, dh).permute(0, 1, 3, 2, 4)
+    sc = (qh @ kh.transpose(-1, -2)) * scale
+    if causal:
+        sc = sc.masked_fill(~torch.ones(T, T, dtype=torch.bool).tril(), float('-inf'))
+    o_ref = (sc.softmax(-1) @ vh).permute(0, 1, 3, 2, 4).reshape(B, hw, T, c)
+    lse_ref = sc.logsumexp(-1)                                                         # b p h t
+    o_ref.backward(do)
+    # device layout: the model's (b, t, h, w, c) token order, sequences = pixels: qmap = (hw, t hw c, c, hw c)
+    to_dev = lambda x: x.permute(0, 2, 1, 3).contiguous().cuda().to(torch.bfloat16)    # (b, t, p, c)
+    ud, dod = to_dev(u), to_dev(do)
+    kd, vd = kc.cuda().to(torch.bfloat16).contiguous(), vc.cuda().to(torch.bfloat16).contiguous()
+    nseq, ntok = B * hw, B * T * hw
+    qmap = _hip.i64((hw, T * hw * c, c, hw * c))
+    kvmap = _hip.i64((hw, T * c, 0, c))
+    out, oattn = torch.full_like(ud, 9.0), torch.full_like(ud, 9.0)
+    lse = torch.full((ntok * nhead,), 9.0, device='cuda')
+    _hip.check(lib.genie_attention_fwd(P(ud), P(kd), P(vd), None, P(out), P(oattn), P(lse), nseq, nhead, dh, T, T, qmap, kvmap, qmap, scale, int(causal), c,
+                                       _hip.stream_ptr()), 'fwd')
+    from_dev = lambda x: x.float().cpu().permute(0, 2, 1, 3)                           # back to (b, p, t, c)
+    assert_close_bf16(from_dev(out), o_ref, 'conditioned fwd', rms_frac=8e-3)
+    lse_h = lse.cpu().reshape(B, T, hw, nhead).permute(0, 2, 3, 1)
+    torch.testing.assert_close(lse_h, lse_ref.detach(), rtol=2e-3, atol=2e-3)
+    D = torch.empty(3 * ntok * nhead, device='cuda')
+    dq = torch.full_like(ud, 9.0)
+    dk32, dv32 = torch.zeros(B, T, c, device='cuda'), torch.zeros(B, T, c, device='cuda')
+    _hip.check(lib.genie_attention_bwd_cond(P(ud), P(kd), P(vd), P(oattn), None, P(dod), P(lse), P(D), P(dq), P(dk32), P(dv32), nseq, nhead, dh, T, qmap, kvmap,
+                                            qmap, scale, int(causal), c, c, ntok, _hip.stream_ptr()), 'bwd_cond')
+    torch.cuda.synchronize()
+    assert rel_rms(from_dev(dq), ur.grad) < 2e-2, rel_rms(from_dev(dq), ur.grad)
+    assert rel_rms(dk32.cpu(), kr.grad) < 2e-2, rel_rms(dk32.cpu(), kr.grad)
+    assert rel_rms(dv32.cpu(), vr.grad) < 2e-2, rel_rms(dv32.cpu(), vr.grad)
+    # the general kernels on the same problem (what rounds 1-5 ran): per-sequence dK / dV summed on the host
+    dq2 = torch.empty_like(ud)
+    dk = torch.empty(nseq, T, c, dtype=torch.bfloat16, device='cuda')
+    dv = torch.empty_like(dk)
+    _hip.check(lib.genie_attention_bwd(P(ud), P(kd), P(vd), P(oattn), None, P(dod), P(lse), P(D), P(dq2), P(dk), P(dv), nseq, nhead, dh, T, T, qmap, kvmap, qmap,
+                                       _hip.i64((1, T * c, 0, c)), scale, int(causal), c, ntok, _hip.stream_ptr()), 'bwd')
+    torch.cuda.synchronize()
+    assert rel_rms(dq, dq2) < 5e-3
+    assert rel_rms(dk32, dk.reshape(B, hw, T, c).float().sum(1)) < 1e-2 and rel_rms(dv32, dv.reshape(B, hw, T, c).float().sum(1)) < 1e-2
+    report('attention_conditioned_short', T=T, hw=hw, d_head=dh, dq=rel_rms(from_dev(dq), ur.grad), dk=rel_rms(dk32.cpu(), kr.grad), dv=rel_rms(dv32.cpu(), vr.grad))
+
+
 @pytest.mark.parametrize('S', [1024, 333, 96, 640])
 @pytest.mark.parametrize('resid', [False, True])
 def test_attention_sequence_resident_forward(S, resid):
