@@ -398,6 +398,10 @@ int genie_conv_narrow_wgrad(const void* big_cl, const void* small_cl, int small_
  * w_channels_last: 0 = dW dense in (co, ci, kt, kh, kw) order, 1 = dense in (co, kt, kh, kw, ci) order (torch.channels_last_3d). */
 int genie_conv_narrow_wgrad_acc(const void* big_cl, const void* small_cl, int small_pitch, float* dW, float* dbias, int N, int T, int H, int W,
                                 int t_lo, int stem, int cs, int w_channels_last, void* stream);
+/* The same for a wide side of a multiple of 128 channels (ABI 12; LatentAction.proj_in 3 -> 256 / proj_out 256 -> 3, genie/action.py:60-70): one call per
+ * 128-channel slab [wide0, wide0 + 128) of the big_pitch-channel tensor; dW / dbias are the whole parameter gradients (wide_total channels on the wide side). */
+int genie_conv_narrow_wgrad_wide(const void* big_cl, int big_pitch, int wide0, int wide_total, const void* small_cl, int small_pitch, float* dW,
+                                 float* dbias, int N, int T, int H, int W, int t_lo, int stem, int cs, int w_channels_last, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Losses and optimiser (elementwise.hip).

@@ -626,6 +626,9 @@ struct NarrowWgradArgs {
     float* dbias;           // stem: [128], head: [cs]; or null
     int stem, cs;           // cs = the narrow side's real channel count (<= 4)
     int wcl;                // 0: dW in (co, ci, tap) memory order; 1: (co, tap, ci) = torch.channels_last_3d, the layout the modules keep
+    // wide side of more than 128 channels (LatentAction's proj_in / proj_out: 256), one launch per 128-channel slab (second-cut kernel only):
+    int big_pitch;          // channels per pixel of BIG (128 for the tokenizer's stem / head)
+    int wide0, wide_total;  // this launch's first channel of the wide side and their total number (dW / dbias addressing)
 };
 
 template <int CW, int RPC>      // chunk = RPC image rows of CW pixels (CW * RPC == 64); W == CW, or W == 128 with CW = 64 (half rows)
@@ -893,11 +896,11 @@ __global__ void __launch_bounds__(256 * TEAMS) conv_narrow_wgrad2_kernel(const N
     float bsum[4] = {0.f, 0.f, 0.f, 0.f};
     u32x4_t breg[4];
     u32x2_t ireg[IMG_LOADS];
-    long long big_off = (long long)c0 * (64 * 128);                       // a chunk is 64 consecutive pixels of BIG: 16 KB
+    long long big_off = (long long)c0 * 64 * a.big_pitch + a.wide0;       // a chunk is 64 consecutive pixels of BIG; this launch reads 128 of their big_pitch channels
     auto load_chunk = [&]() {                                             // the chunk at (pn, pt, ph, pw) / big_off
 #pragma unroll
         for (int i = 0; i < 4; ++i)                                       // thread -> (px = i * 16 + tid / 16, 16-B piece tid % 16): 256 B per 16 lanes
-            breg[i] = *reinterpret_cast<const u32x4_t*>(a.big + big_off + (i * 16 + (tid >> 4)) * 128 + (tid & 15) * 8);
+            breg[i] = *reinterpret_cast<const u32x4_t*>(a.big + big_off + (long long)(i * 16 + (tid >> 4)) * a.big_pitch + (tid & 15) * 8);
         const int h0 = ph * RPC, w0 = pw * CW;
 #pragma unroll
         for (int i = 0; i < IMG_LOADS; ++i) {
@@ -909,7 +912,7 @@ __global__ void __launch_bounds__(256 * TEAMS) conv_narrow_wgrad2_kernel(const N
         }
     };
     auto advance = [&]() {
-        big_off += 64 * 128 * TEAMS;
+        big_off += (long long)64 * a.big_pitch * TEAMS;
 #pragma unroll
         for (int i = 0; i < TEAMS; ++i)
             if (++pw == halves) { pw = 0; if (++ph == hb) { ph = 0; if (++pt == T) { pt = 0; ++pn; } } }
@@ -1084,14 +1087,14 @@ __global__ void __launch_bounds__(256 * TEAMS) conv_narrow_wgrad2_kernel(const N
             }
             __syncthreads();
             if (a.stem) {
-                float* const dst = a.dW + (long long)half * per;
+                float* const dst = a.dW + ((long long)a.wide0 * cs * 27) + (long long)half * per;
                 for (int e = tid; e < per; e += 256) atomicAdd(dst + e, stage[e]);
-                if (a.dbias && tid < 64) atomicAdd(a.dbias + half * 64 + tid, stage[per + tid]);
+                if (a.dbias && tid < 64) atomicAdd(a.dbias + a.wide0 + half * 64 + tid, stage[per + tid]);
             } else {
                 for (int e = tid; e < per; e += 256) {
                     int d;
-                    if (a.wcl) d = (e >> 6) * 128 + half * 64 + (e & 63);                       // (co, tap) rows of 128 input channels
-                    else { const int cc = e / (64 * 27); d = (cc * 128 + half * 64) * 27 + (e - cc * (64 * 27)); }
+                    if (a.wcl) d = (e >> 6) * a.wide_total + a.wide0 + half * 64 + (e & 63);    // (co, tap) rows of wide_total input channels
+                    else { const int cc = e / (64 * 27); d = (cc * a.wide_total + a.wide0 + half * 64) * 27 + (e - cc * (64 * 27)); }
                     atomicAdd(a.dW + d, stage[e]);
                 }
             }
@@ -1187,6 +1190,7 @@ extern "C" int genie_conv_narrow_out(const void* src_cl, const void* wpack, cons
 
 static int narrow_wgrad_launch(NarrowWgradArgs& a, const char* who, void* stream) {
     const int N = a.N, T = a.T, H = a.H, W = a.W;
+    GENIE_CHECK_ARG(a.big_pitch >= 128 && a.big_pitch % 8 == 0 && a.wide0 >= 0 && a.wide0 + 128 <= a.big_pitch && a.wide_total >= a.wide0 + 128, "%s: wide side %d + 128 of %d (pitch %d)", who, a.wide0, a.wide_total, a.big_pitch);
     GENIE_CHECK_ARG(W == 32 || W == 64 || W == 128, "%s: image width %d not in {32, 64, 128}", who, W);
     GENIE_CHECK_ARG(a.sp >= 4 && a.sp % 4 == 0, "%s: pitch %d of the narrow tensor", who, a.sp);
     GENIE_CHECK_ARG(N >= 1 && T >= 1 && H >= 1 && a.t_lo >= -2 && a.t_lo <= 0, "%s: bad geometry / t_lo %d", who, a.t_lo);
@@ -1205,7 +1209,8 @@ static int narrow_wgrad_launch(NarrowWgradArgs& a, const char* who, void* stream
     a.chunks_per_block = (int)((nch + blocks - 1) / blocks);
     blocks = (nch + a.chunks_per_block - 1) / a.chunks_per_block;
     hipStream_t s = (hipStream_t)stream;
-    static const int cut = [] { const char* e = getenv("GENIE_NARROW_WGRAD_CUT"); return e ? atoi(e) : 3; }();
+    static const int cut_env = [] { const char* e = getenv("GENIE_NARROW_WGRAD_CUT"); return e ? atoi(e) : 3; }();
+    const int cut = (a.big_pitch != 128 || a.wide_total != 128) && cut_env == 1 ? 3 : cut_env;      // (the round-5 kernel knows 128-channel rows only)
     if (cut == 2 || cut == 3) {
         // cut 3 (default): 256 workgroups of THREE four-wave teams -- the same twelve waves per CU as three workgroups of one team, a third of the
         // 55-KB atomic tiles at the end (768 tiles = 8 M fp32 atomics were ~20 us of a 240-us launch, and of a 60-us one at 8 clips); cut 2: one team
@@ -1244,6 +1249,7 @@ extern "C" int genie_conv_narrow_wgrad(const void* big_cl, const void* small_cl,
     a.big = (const bf16_t*)big_cl; a.small_ = (const bf16_t*)small_cl; a.G = G;
     a.N = N; a.T = T; a.H = H; a.W = W; a.sp = small_pitch; a.t_lo = t_lo; a.ones = ones;
     a.dW = nullptr; a.dbias = nullptr; a.stem = 0; a.cs = 0; a.wcl = 0;
+    a.big_pitch = 128; a.wide0 = 0; a.wide_total = 128;
     return narrow_wgrad_launch(a, "genie_conv_narrow_wgrad", stream);
 }
 
@@ -1255,5 +1261,21 @@ extern "C" int genie_conv_narrow_wgrad_acc(const void* big_cl, const void* small
     a.big = (const bf16_t*)big_cl; a.small_ = (const bf16_t*)small_cl; a.G = nullptr;
     a.N = N; a.T = T; a.H = H; a.W = W; a.sp = small_pitch; a.t_lo = t_lo; a.ones = (stem && dbias) ? 1 : 0;
     a.dW = dW; a.dbias = dbias; a.stem = stem ? 1 : 0; a.cs = cs; a.wcl = w_channels_last ? 1 : 0;
+    a.big_pitch = 128; a.wide0 = 0; a.wide_total = 128;
     return narrow_wgrad_launch(a, "genie_conv_narrow_wgrad_acc", stream);
+}
+
+// The same for a wide side of a multiple of 128 channels (LatentAction.proj_in 3 -> 256 / proj_out 256 -> 3, action.py:60-70): one launch per 128-channel
+// slab [wide0, wide0 + 128) of the big_pitch-channel tensor; dW / dbias are the WHOLE parameter gradients (wide_total channels on the wide side).
+extern "C" int genie_conv_narrow_wgrad_wide(const void* big_cl, int big_pitch, int wide0, int wide_total, const void* small_cl, int small_pitch, float* dW,
+                                            float* dbias, int N, int T, int H, int W, int t_lo, int stem, int cs, int w_channels_last, void* stream) {
+    GENIE_CHECK_ARG(big_cl && small_cl && dW, "genie_conv_narrow_wgrad_wide: null pointer");
+    GENIE_CHECK_ARG(cs >= 1 && cs <= 4 && cs <= small_pitch, "genie_conv_narrow_wgrad_wide: %d channels on the narrow side (1..4, pitch %d)", cs, small_pitch);
+    NarrowWgradArgs a;
+    a.big = (const bf16_t*)big_cl; a.small_ = (const bf16_t*)small_cl; a.G = nullptr;
+    a.N = N; a.T = T; a.H = H; a.W = W; a.sp = small_pitch; a.t_lo = t_lo; a.ones = (stem && dbias) ? 1 : 0;
+    a.dW = dW; a.dbias = (stem || wide0 == 0) ? dbias : nullptr;        // head: the bias gradient is the sum of the NARROW tensor -- once, with the first slab
+    a.stem = stem ? 1 : 0; a.cs = cs; a.wcl = w_channels_last ? 1 : 0;
+    a.big_pitch = big_pitch; a.wide0 = wide0; a.wide_total = wide_total;
+    return narrow_wgrad_launch(a, "genie_conv_narrow_wgrad_wide", stream);
 }

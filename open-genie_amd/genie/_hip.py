@@ -76,6 +76,7 @@ SIGNATURES = {
     'genie_conv_narrow_out': (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     'genie_conv_narrow_wgrad': (C.c_int, [_P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
     'genie_conv_narrow_wgrad_acc': (C.c_int, [_P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'genie_conv_narrow_wgrad_wide': (C.c_int, [_P, _I, _I, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     'genie_conv_wgrad': (C.c_int, [C.POINTER(GenieWgradDesc), _P]),
     'genie_last_conv_variant': (C.c_int, []),
     'genie_pack_weight': (C.c_int, [_P, _P, _I, _I, _I, _L, _L, _L, _I, _I, _P]),

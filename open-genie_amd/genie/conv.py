@@ -358,14 +358,20 @@ def _narrow_geometry_ok(spec: ConvSpec) -> bool:
             and spec.pad_front[1:] == (1, 1) and spec.pad_back[1:] == (1, 1) and spec.pad_front[0] + spec.pad_back[0] == 2)
 
 
+def _narrow_wide(c: int) -> bool:
+    """The wide side of a narrow conv: 128 channels (the tokenizer's stem / head) or a small multiple of them (LatentAction's proj_in / proj_out: 256),
+    taken one 128-channel slab per launch."""
+    return c in (128, 256, 384, 512)
+
+
 def narrow_fwd_ok(spec: ConvSpec, x: Tensor) -> bool:
-    """Forward of a (<= 4) -> 128 channel conv on the narrow-input kernel?"""
-    return NARROW_CONV and spec.cin <= 4 and spec.cout == 128 and _narrow_geometry_ok(spec) and x.shape[4] in _NARROW_W and pitch_of(x) % 4 == 0
+    """Forward of a (<= 4) -> 128 k channel conv on the narrow-input kernel?"""
+    return NARROW_CONV and spec.cin <= 4 and _narrow_wide(spec.cout) and _narrow_geometry_ok(spec) and x.shape[4] in _NARROW_W and pitch_of(x) % 4 == 0
 
 
 def narrow_dgrad_ok(spec: ConvSpec, dy: Tensor) -> bool:
-    """Backward-data of a 128 -> (<= 4) channel conv (= a (<= 4) -> 128 conv of dy with flipped taps) on the narrow-input kernel?"""
-    return NARROW_CONV and spec.cin == 128 and spec.cout <= 4 and _narrow_geometry_ok(spec) and dy.shape[4] in _NARROW_W and pitch_of(dy) % 4 == 0
+    """Backward-data of a 128 k -> (<= 4) channel conv (= a (<= 4) -> 128 k conv of dy with flipped taps) on the narrow-input kernel?"""
+    return NARROW_CONV and _narrow_wide(spec.cin) and spec.cout <= 4 and _narrow_geometry_ok(spec) and dy.shape[4] in _NARROW_W and pitch_of(dy) % 4 == 0
 
 
 def _narrow_pack(w_rows: Tensor, bias: Optional[Tensor]) -> Tensor:
@@ -397,9 +403,9 @@ def narrow_wgrad_ok(spec: ConvSpec, x: Tensor, dy: Tensor) -> bool:
     """Weight gradient of the stem ((<= 4) -> 128) or head (128 -> (<= 4)) conv on the one-pass narrow kernel?"""
     if not (NARROW_CONV and NARROW_WGRAD and not DETERMINISTIC and _narrow_geometry_ok(spec) and x.shape[4] in _NARROW_W and (x.shape[4] != 32 or x.shape[3] % 2 == 0)):
         return False
-    if spec.cin <= 4 and spec.cout == 128:
-        return pitch_of(dy) == 128 and pitch_of(x) % 4 == 0
-    return spec.cin == 128 and spec.cout <= 4 and pitch_of(x) == 128 and pitch_of(dy) % 4 == 0
+    if spec.cin <= 4 and _narrow_wide(spec.cout):
+        return pitch_of(dy) == spec.cout and pitch_of(x) % 4 == 0
+    return _narrow_wide(spec.cin) and spec.cout <= 4 and pitch_of(x) == spec.cin and pitch_of(dy) % 4 == 0
 
 
 def conv_narrow_wgrad(x: Tensor, dy: Tensor, spec: ConvSpec, dweight: Tensor, dbias: Optional[Tensor], label: str = '') -> None:
@@ -423,10 +429,17 @@ def conv_narrow_wgrad(x: Tensor, dy: Tensor, spec: ConvSpec, dweight: Tensor, db
         return
     t0 = PROFILER.begin() if PROFILER is not None and not PROFILER.only_triple else None
     # straight into dW / db (the kernel's epilogue knows both parameter layouts): no G tile to zero, no scatter, no torch reduction for the head's bias
-    _hip.check(_hip.load_library().genie_conv_narrow_wgrad_acc(big.data_ptr(), small.data_ptr(), pitch_of(small), dweight.data_ptr(), _hip.ptr(dbias),
-                                                               n, t, h, w, int(t_lo), int(stem), int(cs), wcl, _hip.stream_ptr()), 'genie_conv_narrow_wgrad_acc')
+    wide = spec.cout if stem else spec.cin
+    if wide == 128:
+        _hip.check(_hip.load_library().genie_conv_narrow_wgrad_acc(big.data_ptr(), small.data_ptr(), pitch_of(small), dweight.data_ptr(), _hip.ptr(dbias),
+                                                                   n, t, h, w, int(t_lo), int(stem), int(cs), wcl, _hip.stream_ptr()), 'genie_conv_narrow_wgrad_acc')
+    else:                                                # one launch per 128-channel slab of the wide tensor, all of them into the same dW / db
+        for w0 in range(0, wide, 128):
+            _hip.check(_hip.load_library().genie_conv_narrow_wgrad_wide(big.data_ptr(), pitch_of(big), w0, wide, small.data_ptr(), pitch_of(small), dweight.data_ptr(),
+                                                                        _hip.ptr(dbias), n, t, h, w, int(t_lo), int(stem), int(cs), wcl, _hip.stream_ptr()),
+                       'genie_conv_narrow_wgrad_wide')
     if t0 is not None:
-        PROFILER.end('conv_narrow_wgrad_kernel', label, 2.0 * n * t * h * w * 128 * min(spec.cin, spec.cout) * 27, t0)
+        PROFILER.end('conv_narrow_wgrad_kernel', label, 2.0 * n * t * h * w * wide * min(spec.cin, spec.cout) * 27, t0)
 
 
 def narrow_out_ok(spec: ConvSpec, x: Tensor) -> bool:
@@ -458,14 +471,17 @@ def conv_narrow_out(x: Tensor, pack: Tensor, bias: Optional[Tensor], cout: int, 
 
 
 def conv_narrow_in(x: Tensor, pack: Tensor, t_lo: int, label: str = '') -> Tensor:
-    """x: CL (N, c <= 4, T, H, W); returns CL (N, 128, T, H, W) = sum over the 27 taps (dt in t_lo .. t_lo + 2, dh, dw in -1 .. 1)."""
+    """x: CL (N, c <= 4, T, H, W); pack: (128 k, 112) rows of `_narrow_pack`; returns CL (N, 128 k, T, H, W) = sum over the 27 taps (dt in t_lo .. t_lo + 2,
+    dh, dw in -1 .. 1) -- one launch per 128 output channels (the kernel keeps 128 weight rows in registers and writes them at the output's pitch)."""
     n, c, t, h, w = x.shape
-    out = empty_cl(n, 128, t, h, w, x.device)
+    cout = pack.shape[0]
+    out = empty_cl(n, cout, t, h, w, x.device)
     t0 = PROFILER.begin() if PROFILER is not None and not PROFILER.only_triple else None
-    _hip.check(_hip.load_library().genie_conv_narrow_in(x.data_ptr(), pitch_of(x), pack.data_ptr(), out.data_ptr(), pitch_of(out), n, t, h, w, int(t_lo),
-                                                        _hip.stream_ptr()), 'genie_conv_narrow_in')
+    for c0 in range(0, cout, 128):
+        _hip.check(_hip.load_library().genie_conv_narrow_in(x.data_ptr(), pitch_of(x), pack[c0:c0 + 128].data_ptr(), out.data_ptr() + 2 * c0, pitch_of(out), n, t, h, w,
+                                                            int(t_lo), _hip.stream_ptr()), 'genie_conv_narrow_in')
     if t0 is not None:
-        PROFILER.end('conv_narrow_in_kernel', label, 2.0 * n * t * h * w * 128 * c * 27, t0)
+        PROFILER.end('conv_narrow_in_kernel', label, 2.0 * n * t * h * w * cout * c * 27, t0)
     return out
 
 

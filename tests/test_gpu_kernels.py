@@ -493,7 +493,8 @@ def test_conv_wgrad_pointwise_kernel(G, cin, cout, size, monkeypatch):
 
 @pytest.mark.parametrize('cin,cout,causal,size', [(3, 128, True, (2, 5, 10, 64)), (4, 128, False, (1, 3, 8, 32)), (1, 128, True, (1, 2, 4, 128)),
                                                   (128, 3, True, (2, 4, 9, 64)), (128, 2, False, (1, 3, 6, 32)), (128, 1, True, (1, 2, 5, 128)),
-                                                  (3, 128, True, (4, 16, 64, 64)), (128, 3, True, (4, 16, 64, 64))])
+                                                  (3, 128, True, (4, 16, 64, 64)), (128, 3, True, (4, 16, 64, 64)),
+                                                  (3, 256, True, (2, 5, 10, 64)), (256, 3, True, (2, 4, 9, 64)), (4, 256, False, (1, 3, 8, 32)), (384, 2, True, (1, 3, 6, 64))])
 def test_conv_narrow_wgrad_kernel(G, cin, cout, causal, size):
     """conv_narrow.hip, weight gradients of the stem ((<= 4) -> 128) and head (128 -> (<= 4)) convolutions in ONE pass over the
     128-channel tensor (im2col tile of the narrow tensor built in LDS, transposing reads on both MFMA operands), against autograd of
@@ -1012,3 +1013,61 @@ def test_linear_small_forward_backward(G, m, k, n, xdt, odt, bias):
     y2 = GF.linear(xd, wd, bd, out_dtype=odt)
     y2.backward(dy.cuda().to(y2.dtype))
     assert torch.equal(wd.grad, g1 + g1)
+
+
+@pytest.mark.parametrize('wide,narrow,causal,size', [(256, 3, True, (2, 5, 10, 64)), (256, 4, False, (1, 3, 8, 32)), (384, 1, True, (1, 2, 4, 128))])
+def test_conv_narrow_wide_side(G, wide, narrow, causal, size):
+    """The narrow-conv kernels with a wide side of 256 / 384 channels (LatentAction.proj_in 3 -> 256 and the backward passes of proj_out 256 -> 3,
+    action.py:60-70): one launch per 128-channel slab -- forward of narrow -> wide, backward-data of wide -> narrow, both weight gradients, through
+    the module-level path against the oracle; the library must report the narrow kernels."""
+    from genie import functional as GF
+    from oracle import genie_oracle as O
+    torch.manual_seed(23 + wide + narrow)
+    n, t, h, w = size
+    kernel = (3, 3, 3)
+    ref_conv = (lambda x, wt, b: O.causal_conv3d(x, wt, b)) if causal else (lambda x, wt, b: F.conv3d(x, wt, b, padding=1))
+    mk_spec = (lambda ci, co: G.conv.causal_spec(ci, co, kernel)) if causal else (lambda ci, co: G.conv.same_spec(ci, co, kernel))
+    # ---- narrow -> wide: forward + weight gradient ----
+    x = bf16_round(torch.randn(n, narrow, t, h, w))
+    wt = bf16_round(torch.randn(wide, narrow, *kernel) / (narrow * 27) ** 0.5)
+    b = torch.randn(wide)
+    wr, br = wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = ref_conv(x, wr, br)
+    dy = bf16_round(torch.randn_like(ref))
+    ref.backward(dy)
+    spec = mk_spec(narrow, wide)
+    xc = G.cl.to_cl(x.cuda())
+    assert G.conv.narrow_fwd_ok(spec, xc)
+    wd, bd = wt.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    G.conv.PROFILER = prof = G.conv.LaunchProfiler()
+    try:
+        out = GF.conv3d(xc, wd, bd, GF.ConvOp(spec))
+        out.backward(G.cl.to_cl(dy.cuda()))
+    finally:
+        G.conv.PROFILER = None
+    assert 'conv_narrow_in_kernel' in prof.summary() and 'conv_narrow_wgrad_kernel' in prof.summary(), list(prof.summary())
+    assert_close_bf16(out, ref.detach(), 'wide stem fwd')
+    torch.testing.assert_close(wd.grad.cpu(), wr.grad, rtol=1e-3, atol=1e-3 * wr.grad.abs().max().item())
+    torch.testing.assert_close(bd.grad.cpu(), br.grad, rtol=1e-3, atol=1e-3 * br.grad.abs().max().item())
+    # ---- wide -> narrow: backward-data + weight gradient (the forward of this direction stays on the generic kernel for wide > 128) ----
+    x2 = bf16_round(torch.randn(n, wide, t, h, w))
+    w2 = bf16_round(torch.randn(narrow, wide, *kernel) / (wide * 27) ** 0.5)
+    b2 = torch.randn(narrow)
+    x2r, w2r, b2r = x2.clone().requires_grad_(True), w2.clone().requires_grad_(True), b2.clone().requires_grad_(True)
+    ref2 = ref_conv(x2r, w2r, b2r)
+    dy2 = bf16_round(torch.randn_like(ref2))
+    ref2.backward(dy2)
+    spec2 = mk_spec(wide, narrow)
+    x2c = G.cl.to_cl(x2.cuda()).requires_grad_(True)
+    w2d, b2d = w2.cuda().requires_grad_(True), b2.cuda().requires_grad_(True)
+    G.conv.PROFILER = prof = G.conv.LaunchProfiler()
+    try:
+        out2 = GF.conv3d(x2c, w2d, b2d, GF.ConvOp(spec2))
+        out2.backward(G.cl.to_cl(dy2.cuda()))
+    finally:
+        G.conv.PROFILER = None
+    assert 'conv_narrow_in_kernel' in prof.summary() and 'conv_narrow_wgrad_kernel' in prof.summary(), list(prof.summary())
+    assert_close_bf16(out2, ref2.detach(), 'wide head fwd (generic kernel)')
+    assert_close_bf16(x2c.grad, x2r.grad, 'wide head backward-data')
+    torch.testing.assert_close(w2d.grad.cpu(), w2r.grad, rtol=1e-3, atol=1e-3 * w2r.grad.abs().max().item())
+    torch.testing.assert_close(b2d.grad.cpu(), b2r.grad, rtol=1e-3, atol=1e-3 * b2r.grad.abs().max().item())
