@@ -162,6 +162,7 @@ FORCE_SPLIT_K = 0                   # experiments only: split-K factor handed to
 # element in a fixed order, so they are bit-reproducible run to run (the default split-K partial sums meet in fp32 atomics whose
 # order the hardware picks: reproducible to ~1e-6 relative, tests/test_gpu_properties.py::test_gradient_determinism).  Slower (the
 # low-resolution layers lose their parallelism); the stem / head weight gradients go through the generic kernel in this mode.
+# Bias gradients in this mode: a fixed-order column sum (_bias_grad_fixed_order) instead of the kernels' epilogue atomics.
 DETERMINISTIC = os.environ.get('GENIE_DETERMINISTIC', '0') not in ('0', '')
 
 
@@ -723,6 +724,21 @@ def unshuffle_dy(dy: Tensor, spec: ConvSpec) -> Tensor:
     return _unshuffle(dy, spec, 'pqrc')
 
 
+def _bias_grad_fixed_order(dy: Tensor, spec: ConvSpec, dy_unshuffled: bool) -> Tensor:
+    """fp32 [cout] column sums of `dy` in the natural order of the bias, reduced in a fixed tree (torch's sum uses no atomics).  For an
+    upsample conv the bias sits before the depth-to-space-time rearrange: channel ``c * PQR + f`` of the bias collects final channel c at
+    sub-pixel f; an unshuffled `dy` holds the same sums in '(p q r c)' order."""
+    if spec.shuffle is None:
+        return dy[:, :spec.cout].sum((0, 2, 3, 4), dtype=torch.float32)
+    P, Q, R = spec.shuffle
+    f = P * Q * R
+    if dy_unshuffled:
+        return dy[:, :spec.cout].sum((0, 2, 3, 4), dtype=torch.float32).view(f, spec.cfinal).t().reshape(-1)
+    n, _, tp, hq, wr = dy.shape
+    v = dy[:, :spec.cfinal].reshape(n, spec.cfinal, tp // P, P, hq // Q, Q, wr // R, R)
+    return v.sum((0, 2, 4, 6), dtype=torch.float32).reshape(-1)
+
+
 def conv_wgrad(x: Tensor, dy: Tensor, spec: ConvSpec, dweight: Tensor, dbias: Optional[Tensor], dy_unshuffled: bool = False) -> None:
     """Accumulate dW (fp32, any strides, shape (cout, cin, kt, kh, kw)) and dbias (fp32 [cout]).  `dy_unshuffled`: `dy` is
     ``unshuffle_dy(dy, spec)`` of an upsample conv (only where ``wgrad_unshuffled_ok``)."""
@@ -735,6 +751,12 @@ def conv_wgrad(x: Tensor, dy: Tensor, spec: ConvSpec, dweight: Tensor, dbias: Op
     P, Q, R = spec.shuffle if spec.shuffle is not None and not dy_unshuffled else (1, 1, 1)
     assert tuple(dy.shape[2:]) == (to * P, ho * Q, wo * R)
     assert dweight.dtype == torch.float32 and tuple(dweight.shape) == (spec.cout, spec.cin, *spec.kernel)
+    if DETERMINISTIC and dbias is not None:
+        # The kernels' epilogues add per-wave column sums of dy into dbias with atomics; several waves of a workgroup (and every workgroup
+        # of a column) meet on one address, so the ORDER of those adds -- and the last ulp of the sum -- changes from run to run even with
+        # one K split.  Deterministic mode sums the bias gradient in a fixed tree instead and hands the kernel no bias pointer.
+        dbias.add_(_bias_grad_fixed_order(dy, spec, dy_unshuffled))
+        dbias = None
     if narrow_wgrad_ok(spec, x, dy):
         return conv_narrow_wgrad(x, dy, spec, dweight, dbias, f'wgrad {spec.cin}->{spec.cout} k3 @{(t, h, w)}')
     s = dweight.stride()

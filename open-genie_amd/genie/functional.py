@@ -712,8 +712,11 @@ def linear_cross_entropy(h: Tensor, weight: Tensor, bias: Optional[Tensor], wpac
 # ------------------------------------------------------------------------------------------------
 # Skinny linears (min(in, out) <= 32): AdaGN's condition projections, the LFQ projections, cond K / V, LatentAction.to_act
 # ------------------------------------------------------------------------------------------------
+LINEAR_SMALL = __import__('os').environ.get('GENIE_LINEAR_SMALL', '1') != '0'      # A/B: 0 = every linear through F.linear (rounds 1-5)
+
+
 def linear_small_supported(in_features: int, out_features: int) -> bool:
-    return min(int(in_features), int(out_features)) <= 32
+    return LINEAR_SMALL and min(int(in_features), int(out_features)) <= 32
 
 
 class _LinearSmallFn(torch.autograd.Function):

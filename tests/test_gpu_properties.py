@@ -174,7 +174,8 @@ def test_gradient_determinism(G):
     """Same step, same state, twice.  Default mode: split-K partial sums of the weight-gradient kernels meet in fp32
     atomics (conv_wgrad3.hip / conv_wgrad.hip / conv_narrow.hip), so a gradient is reproducible only up to the order of those adds --
     bounded here at 1e-5 relative RMS per parameter (measured ~1e-7; reported).  GENIE_DETERMINISTIC / conv.set_deterministic(True):
-    one owner per output tile, fixed order -- the conv weight gradients are bit-identical run to run.  Forward values, input gradients,
+    one owner per output tile, fixed order, and the bias gradients summed in a fixed tree instead of the kernels' epilogue atomics -- the conv
+    weight and bias gradients are bit-identical run to run.  Forward values, input gradients,
     GroupNorm statistics and LFQ indices are bit-identical in both modes (no atomics on those paths)."""
     from genie import VideoTokenizer
     from genie.trainer import ParamArena
@@ -210,6 +211,7 @@ def test_gradient_determinism(G):
         try:
             l1, g1 = step()
             l2, g2 = step()
+            _, g3 = step()
         finally:
             G.conv.set_deterministic(old)
         assert l1 == l2, (det, l1, l2)                          # the forward pass has no atomics: the loss is bit-identical
@@ -219,8 +221,10 @@ def test_gradient_determinism(G):
         out['deterministic' if det else 'default'] = (spread[worst], worst, sum(1 for v in spread.values() if v == 0), len(spread), top)
         assert spread[worst] < 1e-5, (det, top)
         if det:
-            moving = [n for n, v in spread.items() if v != 0 and n.endswith('weight') and g1[n].dim() == 5]
-            assert not moving, moving                           # every conv weight gradient bit-identical
+            conv_w = [n for n in g1 if n.endswith('weight') and g1[n].dim() == 5]
+            conv_p = conv_w + [n[:-6] + 'bias' for n in conv_w if n[:-6] + 'bias' in g1]
+            moving = [n for n in conv_p if not (torch.equal(g1[n], g2[n]) and torch.equal(g1[n], g3[n]))]
+            assert not moving, moving                           # every conv weight AND bias gradient bit-identical (bias: fixed-order sum)
     report('gradient_determinism', default_worst_rel=out['default'][0], default_worst_param=out['default'][1], default_bit_identical=out['default'][2],
            deterministic_worst_rel=out['deterministic'][0], deterministic_bit_identical=out['deterministic'][2], params=out['default'][3],
            default_top5=out['default'][4], deterministic_top5=out['deterministic'][4])
