@@ -1,3 +1,6 @@
+"""Probe: three eager runs of the small tokenizer step of tests/test_gpu_graph.py (default stream twice, a side stream once) in deterministic
+mode; prints the loss sequences and which gradients differ run to run.  Round 6 used it to find the conv bias gradients (epilogue atomics)
+as the seed of the graph-replay test's fresh-box failure; with the fixed-order bias sum it prints no differing gradient."""
 import sys, os, torch
 sys.path[:0]=['/root/repo','/root/repo/open-genie_amd','/root/repo/tests']
 from genie import conv as gconv, functional as GF
