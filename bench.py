@@ -237,7 +237,10 @@ def side_kernels(batch: int = 64):
             'st_attention': {'peak_tflops': BF16_MFMA_PEAK_TFLOPS, 'flop_count': 'dense 4 S^2 C per sequence forward, 2.5x that backward',
                              'causal_skipping': 'none credited and none present: both shapes are SPATIAL attention (non-causal, every key tile is executed), so the dense count '
                                                 'IS the executed count; causal attention here is temporal, T <= 32, on the packed traffic-bound kernels (priced in GB/s, not TFLOP/s)',
-                             'best_fwd_mfma_frac': best, 'best_bwd_mfma_frac': best_bwd, 'kernel_family': fam, 'kernels': att},
+                             'best_fwd_mfma_frac': best, 'best_bwd_mfma_frac': best_bwd, 'kernel_family': fam,
+                             'batch': "no suffix: 1 clip (S = 4096) / 2 clips (S = 1024), the grids of rounds 1-5 (2-4 rounds of workgroups: mostly ramp and tail); "
+                                      "'(4 clips)': the batch BASELINE configs[0] quotes -- the steady state a training step runs in",
+                             'kernels': att},
             'hbm_kernels': {'peak_gbps': 8000.0, 'bytes': 'what the passes of the call move (stated per entry); *_min: the minimal traffic of the operation', 'kernels': hbm}}
 
 

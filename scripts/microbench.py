@@ -87,6 +87,10 @@ def bench_attn(iters, only=None):
         ('repr_tok spatial S=256 C=512', 8, 16, 16, 16, 8, 64, 'space'),
         ('yaml_tok spatial S=1024 C=512', 2, 16, 32, 32, 8, 64, 'space'),
         ('lam spatial S=4096 C=256', 1, 16, 64, 64, 4, 64, 'space'),
+        # the same two shapes at the batch BASELINE configs[0] quotes (4 clips): 2 / 4 rounds of workgroups become 4 / 16 -- what a training step
+        # launches; the 1- and 2-clip lines above stay for continuity with rounds 1-5 (their grids are mostly ramp and tail)
+        ('yaml_tok spatial S=1024 C=512 (4 clips)', 4, 16, 32, 32, 8, 64, 'space'),
+        ('lam spatial S=4096 C=256 (4 clips)', 4, 16, 64, 64, 4, 64, 'space'),
         ('lam spatial S=1024 C=256', 4, 16, 32, 32, 4, 64, 'space'),
         ('dynamics spatial S=64 C=512', 32, 16, 8, 8, 8, 64, 'space'),
         ('repr_tok temporal T=16 C=512', 8, 16, 16, 16, 8, 64, 'time'),
