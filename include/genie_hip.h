@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GENIE_ABI_VERSION 12
+#define GENIE_ABI_VERSION 13
 
 #define GENIE_F32 0
 #define GENIE_BF16 1
@@ -467,6 +467,24 @@ int genie_attention_bwd_cond(const void* q, const void* k, const void* v, const 
                              float* D_ws, void* dq, float* dk_f32, float* dv_f32, int nseq, int nhead, int d_head, int S, const int64_t* q_map,
                              const int64_t* kv_map, const int64_t* out_map, float scale, int causal, int out_channels, int kv_channels,
                              int64_t out_tokens, void* stream);
+
+/* Attention dropout (ABI 13).  Reference attention.py:225-230 hands `dropout_p=self.dropout` to F.scaled_dot_product_attention (in training AND in
+ * eval: the functional form has no training switch): out = (softmax(S) o M / (1 - p)) V, M Bernoulli(1 - p) per (sequence, head, query, key).
+ * Here M is a pure function of (seed, sequence, head, query, key) (csrc/attn_args.h: two rounds of a multiply-xorshift mixer over q * Sk + k, keyed per
+ * (sequence, head) from the seed), evaluated in registers by the forward and by both backward kernels: no mask is stored, the backward call passes the
+ * forward's (dropout_p, seed).  Arguments and contracts otherwise as genie_attention_fwd / genie_attention_bwd; lse is the softmax's, o_attn the DROPPED
+ * output (so that D = rowsum(dO o o_attn)).  d_head 32 / 64 / 128 on the general MFMA kernels (the packed, conditioned and lean families take no mask:
+ * dropout costs the fast paths, as it does in every flash implementation's bookkeeping); d_head < 32 -> GENIE_ERR_ARG.  dropout_p = 0 is the plain call.
+ * torch's Philox stream cannot be reproduced (and differs between its own backends): parity with the reference is through the mask --
+ * genie_attention_dropout_mask writes the decisions out, keep[((seq * nhead + head) * Sq + q) * Sk + k], for the oracle to apply. */
+int genie_attention_fwd_dropout(const void* q, const void* k, const void* v, const void* resid, void* out, void* o_attn, float* lse, int nseq, int nhead,
+                                int d_head, int Sq, int Sk, const int64_t* q_map, const int64_t* kv_map, const int64_t* out_map, float scale,
+                                int causal, int out_channels, float dropout_p, uint64_t seed, void* stream);
+int genie_attention_bwd_dropout(const void* q, const void* k, const void* v, const void* out, const void* resid, const void* dO,
+                                const float* lse, float* D_ws, void* dq, void* dk, void* dv, int nseq, int nhead, int d_head, int Sq, int Sk,
+                                const int64_t* q_map, const int64_t* kv_map, const int64_t* out_map, const int64_t* dkv_map, float scale,
+                                int causal, int out_channels, int64_t out_tokens, float dropout_p, uint64_t seed, void* stream);
+int genie_attention_dropout_mask(uint8_t* keep, int nseq, int nhead, int Sq, int Sk, float dropout_p, uint64_t seed, void* stream);
 
 /* d_head 64 runs on register-lean kernels (attention_lean.hip: four / three waves per SIMD) where their preconditions hold.  mask: bit 0
  * forward, bit 1 backward dQ, bit 2 backward dK / dV; bit 3: reserved; bit 4: the forward's running maximum is

@@ -363,6 +363,7 @@ __global__ void __launch_bounds__(64 * NW) attn_fwd_kernel(const AttnArgs a) {
         for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
     float m_run = -1e30f, l_run = 0.f;           // running max of the RAW scores, running sum of exp2(c * (s - m))
     const float c2 = a.scale * 1.4426950408889634f;
+    const unsigned drop_key = attn_drop_seqkey(a.drop_key, seq, a.nhead, head);
 
     const long long kbase = seq_base(a.km, seq) + head * DH;
     const int blk_q_max = qtile * (32 * NW) + 32 * NW - 1;   // causal: no key beyond the block's last query contributes
@@ -513,6 +514,13 @@ __global__ void __launch_bounds__(64 * NW) attn_fwd_kernel(const AttnArgs a) {
             }
         psum += __shfl_xor(psum, 32, 64);
         l_run += psum;
+        if (a.drop_thr) {                                  // dropout acts on softmax(S): the row sum above is of the undropped weights
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (!attn_drop_keep(drop_key, a.drop_thr, qi, k0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, a.Sk)) sacc[kt][r] = 0.f;
+        }
 
         // ---- O^T += V^T P^T ----
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -551,7 +559,7 @@ __global__ void __launch_bounds__(64 * NW) attn_fwd_kernel(const AttnArgs a) {
     __syncthreads();                                 // every wave is done with the ring: its memory now stages the output rows
     {
         float* fl = reinterpret_cast<float*>(smem) + wave * 32 * DH;
-        const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+        const float inv = l_run > 0.f ? a.drop_scale / l_run : 0.f;     // (drop_scale = 1 without dropout)
         const int lr = lane & 31;
 #pragma unroll
         for (int d = 0; d < DT; ++d)
@@ -765,9 +773,24 @@ static int small_attn_mode() {          // GENIE_ATTN_SMALL=0 sends short sequen
     return mode;
 }
 
-extern "C" int genie_attention_fwd(const void* q, const void* k, const void* v, const void* resid, void* out, void* o_attn, float* lse, int nseq, int nhead,
-                                   int d_head, int Sq, int Sk, const int64_t* q_map, const int64_t* kv_map, const int64_t* out_map, float scale,
-                                   int causal, int out_channels, void* stream) {
+// Host side of attention dropout: probability -> 32-bit threshold, 64-bit seed -> 32-bit call key
+struct AttnDrop { unsigned thr, key; float scale; };
+static AttnDrop attn_drop_of(float p, uint64_t seed) {
+    AttnDrop d{0u, 0u, 1.f};
+    if (p > 0.f) {
+        const double t = (double)p * 4294967296.0;
+        d.thr = t >= 4294967295.0 ? 4294967295u : (t < 1.0 ? 1u : (unsigned)t);
+        uint64_t z = seed + 0x9E3779B97F4A7C15ull;                      // splitmix64 finaliser: every seed bit reaches the key
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+        d.key = (unsigned)z ^ (unsigned)(z >> 32);
+        d.scale = 1.f / (1.f - p);
+    }
+    return d;
+}
+
+static int attention_fwd_impl(const void* q, const void* k, const void* v, const void* resid, void* out, void* o_attn, float* lse, int nseq, int nhead,
+                              int d_head, int Sq, int Sk, const int64_t* q_map, const int64_t* kv_map, const int64_t* out_map, float scale,
+                              int causal, int out_channels, float dropout_p, uint64_t seed, void* stream) {
     GENIE_CHECK_ARG(q && k && v && out && q_map && kv_map && out_map, "genie_attention_fwd: null pointer");
     GENIE_CHECK_ARG(d_head == 8 || d_head == 16 || d_head == 32 || d_head == 64 || d_head == 128, "genie_attention_fwd: d_head %d not in {8, 16, 32, 64, 128}", d_head);
     GENIE_CHECK_ARG(nseq >= 1 && nhead >= 1 && Sq >= 1 && Sk >= 1, "genie_attention_fwd: empty problem");
@@ -780,8 +803,16 @@ extern "C" int genie_attention_fwd(const void* q, const void* k, const void* v, 
     GENIE_CHECK_ARG(out_channels >= nhead * d_head, "genie_attention_fwd: out_channels %d < nhead * d_head", out_channels);
     GENIE_CHECK_ARG(scale > 0.f, "genie_attention_fwd: scale must be positive (got %g)", (double)scale);
     hipStream_t s = (hipStream_t)stream;
+    const bool drop = dropout_p > 0.f;
+    if (drop) {                                             // the general kernels only (the packed, conditioned and lean families take no mask)
+        GENIE_CHECK_ARG(dropout_p < 1.f, "genie_attention_fwd_dropout: dropout_p %g not in [0, 1)", (double)dropout_p);
+        GENIE_CHECK_ARG(d_head >= 32, "genie_attention_fwd_dropout: d_head %d < 32 has no dropout path", d_head);
+        GENIE_CHECK_ARG((long long)Sq * Sk < (1ll << 32), "genie_attention_fwd_dropout: Sq * Sk must fit 32 bits");
+        const AttnDrop d = attn_drop_of(dropout_p, seed);
+        a.drop_thr = d.thr; a.drop_key = d.key; a.drop_scale = d.scale;
+    }
     if (d_head < 32) return genie_attn_narrow_fwd(a, d_head, s);                                     // fp32 VALU kernels (attention_narrow.hip)
-    if (q == k && k == v && Sq == Sk && Sq <= 32 && same_map(a.qm, a.km) && small_attn_mode()) {   // packed short sequences (temporal attention)
+    if (!drop && q == k && k == v && Sq == Sk && Sq <= 32 && same_map(a.qm, a.km) && small_attn_mode()) {   // packed short sequences (temporal attention)
         const int tp = Sq <= 8 ? 8 : (Sq <= 16 ? 16 : 32);
         const long long waves = ((long long)nseq + 32 / tp - 1) / (32 / tp) * nhead;
         const unsigned blocks = (unsigned)((waves + 3) / 4);
@@ -796,7 +827,7 @@ extern "C" int genie_attention_fwd(const void* q, const void* k, const void* v, 
         GENIE_CHECK_LAUNCH();
         return GENIE_OK;
     }
-    if (small_cond_ok(a, q, k, v, d_head)) {               // packed short sequences against a per-clip condition (kv map with inner stride 0)
+    if (!drop && small_cond_ok(a, q, k, v, d_head)) {      // packed short sequences against a per-clip condition (kv map with inner stride 0)
         const int tp = Sq <= 8 ? 8 : (Sq <= 16 ? 16 : 32);
         const long long waves = ((long long)nseq / (32 / tp)) * nhead;
         const unsigned blocks = (unsigned)((waves + 3) / 4);
@@ -811,7 +842,7 @@ extern "C" int genie_attention_fwd(const void* q, const void* k, const void* v, 
         GENIE_CHECK_LAUNCH();
         return GENIE_OK;
     }
-    if (genie_attn_lean_fwd_ok(a, d_head)) return genie_attn_lean_fwd(a, s);        // d_head 64, four waves per SIMD (attention_lean.hip)
+    if (!drop && genie_attn_lean_fwd_ok(a, d_head)) return genie_attn_lean_fwd(a, s);        // d_head 64, four waves per SIMD (attention_lean.hip)
     int nw = (Sq + 31) / 32;
     nw = nw >= 3 ? 4 : nw;                                        // 1, 2 or 4 waves (every wave stages the same number of pieces)
     const int qtiles = (Sq + 32 * nw - 1) / (32 * nw);
@@ -835,6 +866,44 @@ extern "C" int genie_attention_fwd(const void* q, const void* k, const void* v, 
     else GENIE_ATTN_FWD_NW(128);
 #undef GENIE_ATTN_FWD_NW
 #undef GENIE_ATTN_FWD
+    GENIE_CHECK_LAUNCH();
+    return GENIE_OK;
+}
+
+extern "C" int genie_attention_fwd(const void* q, const void* k, const void* v, const void* resid, void* out, void* o_attn, float* lse, int nseq, int nhead,
+                                   int d_head, int Sq, int Sk, const int64_t* q_map, const int64_t* kv_map, const int64_t* out_map, float scale,
+                                   int causal, int out_channels, void* stream) {
+    return attention_fwd_impl(q, k, v, resid, out, o_attn, lse, nseq, nhead, d_head, Sq, Sk, q_map, kv_map, out_map, scale, causal, out_channels, 0.f, 0, stream);
+}
+
+// genie_attention_fwd with dropout on the attention weights (reference attention.py:225-230: `dropout_p=self.dropout`): out = (softmax(S) o M / (1 - p)) V
+// with M a pure function of (seed, sequence, head, query, key) -- attn_args.h.  lse is the softmax's (no dropout in it); o_attn is the dropped output.
+extern "C" int genie_attention_fwd_dropout(const void* q, const void* k, const void* v, const void* resid, void* out, void* o_attn, float* lse, int nseq,
+                                           int nhead, int d_head, int Sq, int Sk, const int64_t* q_map, const int64_t* kv_map, const int64_t* out_map,
+                                           float scale, int causal, int out_channels, float dropout_p, uint64_t seed, void* stream) {
+    GENIE_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "genie_attention_fwd_dropout: dropout_p %g not in [0, 1)", (double)dropout_p);
+    return attention_fwd_impl(q, k, v, resid, out, o_attn, lse, nseq, nhead, d_head, Sq, Sk, q_map, kv_map, out_map, scale, causal, out_channels, dropout_p, seed, stream);
+}
+
+// The keep decisions of the two dropout entry points, written out: keep[((seq * nhead + head) * Sq + q) * Sk + k] = 1 | 0.  For tests and debugging (the
+// kernels never store a mask).
+__global__ void __launch_bounds__(256) attn_dropout_mask_kernel(uint8_t* __restrict__ keep, int nseq, int nhead, int Sq, int Sk, unsigned thr, unsigned key) {
+    const long long n = (long long)nseq * nhead * Sq * Sk;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int k = (int)(i % Sk), q = (int)((i / Sk) % Sq);
+        const long long sh = i / ((long long)Sq * Sk);
+        keep[i] = attn_drop_keep(attn_drop_seqkey(key, (int)(sh / nhead), nhead, (int)(sh % nhead)), thr, q, k, Sk) ? 1 : 0;
+    }
+}
+
+extern "C" int genie_attention_dropout_mask(uint8_t* keep, int nseq, int nhead, int Sq, int Sk, float dropout_p, uint64_t seed, void* stream) {
+    GENIE_CHECK_ARG(keep && nseq >= 1 && nhead >= 1 && Sq >= 1 && Sk >= 1, "genie_attention_dropout_mask: null pointer / empty problem");
+    GENIE_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "genie_attention_dropout_mask: dropout_p %g not in [0, 1)", (double)dropout_p);
+    GENIE_CHECK_ARG((long long)Sq * Sk < (1ll << 32), "genie_attention_dropout_mask: Sq * Sk must fit 32 bits");
+    const AttnDrop d = attn_drop_of(dropout_p, seed);
+    const long long n = (long long)nseq * nhead * Sq * Sk;
+    const unsigned blocks = (unsigned)((n + 255) / 256 > 65536 ? 65536 : (n + 255) / 256);
+    attn_dropout_mask_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(keep, nseq, nhead, Sq, Sk, d.thr, d.key);
     GENIE_CHECK_LAUNCH();
     return GENIE_OK;
 }
@@ -926,6 +995,7 @@ __global__ void __launch_bounds__(64 * NW) attn_bwd_dq_kernel(const AttnBwdArgs 
 #pragma unroll
         for (int r = 0; r < 16; ++r) dq[d][r] = 0.f;
     const float c2 = a.scale * 1.4426950408889634f;
+    const unsigned drop_key = attn_drop_seqkey(a.drop_key, seq, a.nhead, head);
     const long long kbase = seq_base(a.km, seq) + head * DH;
     const int blk_q_max = qtile * (32 * NW) + 32 * NW - 1;
     int k_end = a.Sk;
@@ -1027,7 +1097,10 @@ __global__ void __launch_bounds__(64 * NW) attn_bwd_dq_kernel(const AttnBwdArgs 
                     const int key = k0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                     if (key >= a.Sk || (a.causal && key > qi) || qi >= a.Sq) p = 0.f;
                 }
-                sacc[kt][r] = p * (pacc[kt][r] - D_q);                                                  // dS^T / scale
+                float dp = pacc[kt][r];
+                if (a.drop_thr)                             // dP reaches the softmax through the same mask and 1 / (1 - p) as the forward's weights
+                    dp = attn_drop_keep(drop_key, a.drop_thr, qi, k0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, a.Sk) ? dp * a.drop_scale : 0.f;
+                sacc[kt][r] = p * (dp - D_q);                                                           // dS^T / scale
             }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
@@ -1116,6 +1189,7 @@ __global__ void __launch_bounds__(64 * NW) attn_bwd_dkv_kernel(const AttnBwdArgs
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dk[d][r] = 0.f; dv[d][r] = 0.f; }
     const float c2 = a.scale * 1.4426950408889634f;
+    const unsigned drop_key = attn_drop_seqkey(a.drop_key, seq, a.nhead, head);
     const long long qbase = seq_base(a.qm, seq) + head * DH;
     const long long obase_s = seq_base(a.om, seq) + head * DH;
     const long long otok_s = seq_base(a.om, seq);
@@ -1230,8 +1304,14 @@ __global__ void __launch_bounds__(64 * NW) attn_bwd_dkv_kernel(const AttnBwdArgs
                         const int qg = qs + ql0 + e;
                         if (qg >= a.Sq || ki >= a.Sk || (a.causal && ki > qg)) p = 0.f;
                     }
-                    sacc[r] = p;
-                    ds[r] = p * (pacc[r] - d4[e]);                                                      // dS / scale
+                    float pd = p, dp = pacc[r];
+                    if (a.drop_thr) {
+                        const bool keep = attn_drop_keep(drop_key, a.drop_thr, qs + ql0 + e, ki, a.Sk);
+                        pd = keep ? p * a.drop_scale : 0.f;
+                        dp = keep ? dp * a.drop_scale : 0.f;
+                    }
+                    sacc[r] = pd;                                                                       // dropped weights: dV^T += dO^T P
+                    ds[r] = p * (dp - d4[e]);                                                           // dS / scale
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1649,10 +1729,10 @@ __global__ void __launch_bounds__(128) attn_smallx_bwd_kernel(const AttnBwdArgs 
 
 // q, k, v, dO: as forward (dO / out / resid share out_map).  Self-attention (q == k == v): du receives dQ + dK + dV.
 // Otherwise dq gets dQ (q-map) and dk / dv (kv-map addressing, caller-provided buffers) get dK / dV.
-extern "C" int genie_attention_bwd(const void* q, const void* k, const void* v, const void* out, const void* resid, const void* dO,
-                                   const float* lse, float* D_ws, void* dq, void* dk, void* dv, int nseq, int nhead, int d_head, int Sq,
-                                   int Sk, const int64_t* q_map, const int64_t* kv_map, const int64_t* out_map, const int64_t* dkv_map,
-                                   float scale, int causal, int out_channels, int64_t out_tokens, void* stream) {
+static int attention_bwd_impl(const void* q, const void* k, const void* v, const void* out, const void* resid, const void* dO,
+                              const float* lse, float* D_ws, void* dq, void* dk, void* dv, int nseq, int nhead, int d_head, int Sq,
+                              int Sk, const int64_t* q_map, const int64_t* kv_map, const int64_t* out_map, const int64_t* dkv_map,
+                              float scale, int causal, int out_channels, int64_t out_tokens, float dropout_p, uint64_t seed, void* stream) {
     GENIE_CHECK_ARG(q && k && v && out && dO && lse && D_ws && dq, "genie_attention_bwd: null pointer");
     GENIE_CHECK_ARG(d_head == 8 || d_head == 16 || d_head == 32 || d_head == 64 || d_head == 128, "genie_attention_bwd: d_head %d not in {8, 16, 32, 64, 128}", d_head);
     const bool self = (q == k && k == v);
@@ -1668,6 +1748,14 @@ extern "C" int genie_attention_bwd(const void* q, const void* k, const void* v, 
     a.out = (const bf16_t*)out; a.resid = (const bf16_t*)resid;
     hipStream_t s = (hipStream_t)stream;
     GENIE_CHECK_ARG(scale > 0.f, "genie_attention_bwd: scale must be positive (got %g)", (double)scale);
+    const bool drop = dropout_p > 0.f;
+    if (drop) {
+        GENIE_CHECK_ARG(dropout_p < 1.f, "genie_attention_bwd_dropout: dropout_p %g not in [0, 1)", (double)dropout_p);
+        GENIE_CHECK_ARG(d_head >= 32, "genie_attention_bwd_dropout: d_head %d < 32 has no dropout path", d_head);
+        GENIE_CHECK_ARG((long long)Sq * Sk < (1ll << 32), "genie_attention_bwd_dropout: Sq * Sk must fit 32 bits");
+        const AttnDrop d = attn_drop_of(dropout_p, seed);
+        a.drop_thr = d.thr; a.drop_key = d.key; a.drop_scale = d.scale;
+    }
     if (d_head < 32) return genie_attn_narrow_bwd(a, d_head, s);                                     // D + dQ, then dK / dV (attention_narrow.hip)
     const unsigned pblocks = (unsigned)((out_tokens + 3) / 4);
     if (d_head == 32) attn_bwd_prep_kernel<32><<<pblocks, 256, 0, s>>>((const bf16_t*)dO, (const bf16_t*)out, (const bf16_t*)resid, D_ws, out_tokens, out_channels, nhead, lse, D_ws + out_tokens * nhead, D_ws + 2 * out_tokens * nhead);
@@ -1675,7 +1763,7 @@ extern "C" int genie_attention_bwd(const void* q, const void* k, const void* v, 
     else attn_bwd_prep_kernel<128><<<pblocks, 256, 0, s>>>((const bf16_t*)dO, (const bf16_t*)out, (const bf16_t*)resid, D_ws, out_tokens, out_channels, nhead, lse, D_ws + out_tokens * nhead, D_ws + 2 * out_tokens * nhead);
     GENIE_CHECK_LAUNCH();
     GENIE_CHECK_ARG(scale > 0.f, "genie_attention_bwd: scale must be positive (got %g)", (double)scale);
-    if (self && Sq == Sk && Sq <= 32 && same_map(a.qm, a.km) && small_attn_mode()) {
+    if (!drop && self && Sq == Sk && Sq <= 32 && same_map(a.qm, a.km) && small_attn_mode()) {
         const int tp = Sq <= 8 ? 8 : (Sq <= 16 ? 16 : 32);
         const long long waves = ((long long)nseq + 32 / tp - 1) / (32 / tp) * nhead;
         const unsigned blocks = (unsigned)((waves + 1) / 2);
@@ -1709,7 +1797,7 @@ extern "C" int genie_attention_bwd(const void* q, const void* k, const void* v, 
         if (lds_k > 65536) GENIE_CHECK_ARG(hipFuncSetAttribute((const void*)kk, hipFuncAttributeMaxDynamicSharedMemorySize, lds_k) == hipSuccess, "hipFuncSetAttribute failed"); \
         kk<<<gk, 64 * NWv, lds_k, s>>>(a);                                                               \
     } while (0)
-    const int lean = genie_attn_lean_bwd_mask(a, d_head);       // d_head 64: the register-lean kernels (attention_lean.hip) where they apply
+    const int lean = drop ? 0 : genie_attn_lean_bwd_mask(a, d_head);       // d_head 64: the register-lean kernels (attention_lean.hip) where they apply
 #define GENIE_ATTN_BWD_DH(DHv)                                                                           \
     do {                                                                                                 \
         if (lean & 1) { if (int rc = genie_attn_lean_bwd_dq(a, s)) return rc; }                          \
@@ -1725,6 +1813,25 @@ extern "C" int genie_attention_bwd(const void* q, const void* k, const void* v, 
 #undef GENIE_ATTN_DQ
     GENIE_CHECK_LAUNCH();
     return GENIE_OK;
+}
+
+extern "C" int genie_attention_bwd(const void* q, const void* k, const void* v, const void* out, const void* resid, const void* dO,
+                                   const float* lse, float* D_ws, void* dq, void* dk, void* dv, int nseq, int nhead, int d_head, int Sq,
+                                   int Sk, const int64_t* q_map, const int64_t* kv_map, const int64_t* out_map, const int64_t* dkv_map,
+                                   float scale, int causal, int out_channels, int64_t out_tokens, void* stream) {
+    return attention_bwd_impl(q, k, v, out, resid, dO, lse, D_ws, dq, dk, dv, nseq, nhead, d_head, Sq, Sk, q_map, kv_map, out_map, dkv_map, scale, causal,
+                              out_channels, out_tokens, 0.f, 0, stream);
+}
+
+// Backward of genie_attention_fwd_dropout: the same (dropout_p, seed) reproduce the forward's mask.  `out` is the dropped output the forward
+// stored (D = rowsum(dO o out) then carries the mask); dS = P o (M dP / (1 - p) - D), dV = (P o M / (1 - p))^T dO.
+extern "C" int genie_attention_bwd_dropout(const void* q, const void* k, const void* v, const void* out, const void* resid, const void* dO,
+                                           const float* lse, float* D_ws, void* dq, void* dk, void* dv, int nseq, int nhead, int d_head, int Sq,
+                                           int Sk, const int64_t* q_map, const int64_t* kv_map, const int64_t* out_map, const int64_t* dkv_map,
+                                           float scale, int causal, int out_channels, int64_t out_tokens, float dropout_p, uint64_t seed, void* stream) {
+    GENIE_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "genie_attention_bwd_dropout: dropout_p %g not in [0, 1)", (double)dropout_p);
+    return attention_bwd_impl(q, k, v, out, resid, dO, lse, D_ws, dq, dk, dv, nseq, nhead, d_head, Sq, Sk, q_map, kv_map, out_map, dkv_map, scale, causal,
+                              out_channels, out_tokens, dropout_p, seed, stream);
 }
 
 

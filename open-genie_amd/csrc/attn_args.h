@@ -22,6 +22,9 @@ struct AttnArgs {
     int causal;
     int kv_same;                // k == v tile (one LDS image)
     int xcd_swizzle;            // lean kernels: 1-D grid, workgroup -> (sequence, head, tile) through attn_block_of (0: blockIdx.x / .y as is)
+    // attention dropout (genie_attention_fwd_dropout; general kernels only): an element is DROPPED when attn_drop_hash(...) < drop_thr
+    unsigned drop_thr = 0, drop_key = 0;
+    float drop_scale = 1.f;     // 1 / (1 - p)
 };
 
 struct AttnBwdArgs {
@@ -37,7 +40,25 @@ struct AttnBwdArgs {
     float scale;
     int causal, kv_same, fuse_self;
     int xcd_swizzle;            // as AttnArgs::xcd_swizzle
+    unsigned drop_thr = 0, drop_key = 0;      // as AttnArgs (genie_attention_bwd_dropout)
+    float drop_scale = 1.f;
 };
+
+// Attention dropout (reference attention.py:229 hands `dropout_p` to scaled_dot_product_attention).  Counter-based: the decision for
+// (sequence, head, query, key) is a pure function of the call's seed -- two rounds of a multiply-xorshift mixer over the element's index,
+// keyed per (sequence, head) -- so the forward kernel, both backward kernels and genie_attention_dropout_mask (which writes the decisions out
+// for the parity tests) agree without any stored mask.
+__device__ __forceinline__ unsigned attn_drop_mix(unsigned x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ unsigned attn_drop_seqkey(unsigned call_key, int seq, int nhead, int head) {
+    return attn_drop_mix(call_key + (unsigned)(seq * nhead + head) * 0x9E3779B9U);
+}
+__device__ __forceinline__ bool attn_drop_keep(unsigned seqkey, unsigned thr, int q, int k, int Sk) {
+    return attn_drop_mix(((unsigned)q * (unsigned)Sk + (unsigned)k) ^ seqkey) >= thr;
+}
+
 
 
 // d_head 8 / 16 (attention_narrow.hip); same contracts as the MFMA kernels behind genie_attention_fwd / genie_attention_bwd

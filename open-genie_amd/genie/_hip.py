@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('GENIE_HIP_LIB', os.path.join(os.path.dirname(_HERE), 'lib', 'libgenie_hip.so'))
 
 GENIE_F32, GENIE_BF16 = 0, 1
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 
 class GenieTap(C.Structure):
@@ -130,6 +130,10 @@ SIGNATURES = {
     'genie_attention_fwd': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _PL, _PL, _PL, _F, _I, _I, _P]),
     'genie_attention_bwd_cond': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _PL, _PL, _PL, _F, _I, _I, _I, _L, _P]),
     'genie_attention_bwd': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _PL, _PL, _PL, _PL, _F, _I, _I, _L, _P]),
+    # genie_attention_fwd / _bwd + (float dropout_p, uint64 seed) before the stream
+    'genie_attention_fwd_dropout': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _PL, _PL, _PL, _F, _I, _I, _F, C.c_uint64, _P]),
+    'genie_attention_bwd_dropout': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _PL, _PL, _PL, _PL, _F, _I, _I, _L, _F, C.c_uint64, _P]),
+    'genie_attention_dropout_mask': (C.c_int, [_P, _I, _I, _I, _I, _F, C.c_uint64, _P]),
     'genie_attention_lean_mode': (C.c_int, [_I]),
     'genie_attention_lean_occupancy': (C.c_int, [_I]),
     'genie_probe_ds_read_tr16': (C.c_int, [_P, _P, _P, _P]),

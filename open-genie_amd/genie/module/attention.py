@@ -109,7 +109,7 @@ COND_SMALL = __import__('os').environ.get('GENIE_ATTN_COND_SMALL', '1') != '0'  
 class _AttnFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x: Tensor, gamma: Tensor, beta: Tensor, table: Optional[Tensor], kext: Optional[Tensor], vext: Optional[Tensor],
-                mode: str, n_head: int, d_head: int, scale: float, causal: bool, add_resid: bool, eps: float):
+                mode: str, n_head: int, d_head: int, scale: float, causal: bool, add_resid: bool, eps: float, dropout_p: float = 0.0, seed: int = 0):
         lib = _hip.load_library()
         b, c, t, h, w = x.shape
         assert pitch_of(x) == c and c == n_head * d_head
@@ -141,13 +141,19 @@ class _AttnFn(torch.autograd.Function):
         lse = torch.empty(ntok * n_head, dtype=torch.float32, device=x.device)
         prof = _conv.PROFILER if _conv.PROFILER is not None and not _conv.PROFILER.only_triple else None
         t0 = prof.begin() if prof is not None else None
-        _hip.check(lib.genie_attention_fwd(P(u), P(k), P(v), P(x) if add_resid else None, P(out), P(oattn), P(lse), nseq, n_head, d_head, S, Sk,
-                                           _hip.i64(qmap), _hip.i64(kvmap), _hip.i64(qmap), scale, 1 if causal else 0, c, _hip.stream_ptr()),
-                   'genie_attention_fwd')
+        if dropout_p > 0.0:                               # general kernels with the counter-based mask (include/genie_hip.h, ABI 13); backward re-derives it
+            _hip.check(lib.genie_attention_fwd_dropout(P(u), P(k), P(v), P(x) if add_resid else None, P(out), P(oattn), P(lse), nseq, n_head, d_head, S, Sk,
+                                                       _hip.i64(qmap), _hip.i64(kvmap), _hip.i64(qmap), scale, 1 if causal else 0, c, dropout_p, seed,
+                                                       _hip.stream_ptr()), 'genie_attention_fwd_dropout')
+        else:
+            _hip.check(lib.genie_attention_fwd(P(u), P(k), P(v), P(x) if add_resid else None, P(out), P(oattn), P(lse), nseq, n_head, d_head, S, Sk,
+                                               _hip.i64(qmap), _hip.i64(kvmap), _hip.i64(qmap), scale, 1 if causal else 0, c, _hip.stream_ptr()),
+                       'genie_attention_fwd')
         if prof is not None:                              # dense count 4 S Sk C per sequence; traffic: read u (q, k / v), resid, write out
             prof.end(_attn_variant('fwd', S, d_head), f'attention fwd {mode} S={S} Sk={Sk} C={c} nseq={nseq}', 4.0 * S * Sk * c * nseq, t0,
                      bytes_=(4.0 if add_resid else 3.0) * ntok * c * 2)
         ctx.cfg = (mode, n_head, d_head, scale, causal, add_resid, eps, qmap, kvmap, nseq, S, Sk, pos_div, pos_mod)
+        ctx.drop = (float(dropout_p), int(seed))
         ctx.save_for_backward(x, gamma, beta, table, kext, vext, u, oattn if oattn is not None else out, lse, stats)
         return out
 
@@ -168,7 +174,8 @@ class _AttnFn(torch.autograd.Function):
         # condition rows' gradients over the pixels of a clip itself (genie_attention_bwd_cond) -- rounds 1-5 took them per sequence (two tensors of the
         # activation's size) and summed them with torch
         tp = 8 if S <= 8 else (16 if S <= 16 else 32)
-        cond_small = (kext is not None and S == Sk and S <= 32 and d_head in (32, 64) and inner % (32 // tp) == 0 and COND_SMALL)
+        dropout_p, seed = ctx.drop
+        cond_small = (kext is not None and S == Sk and S <= 32 and d_head in (32, 64) and inner % (32 // tp) == 0 and COND_SMALL and dropout_p == 0.0)
         if kext is None:
             k, v, dkvmap = u, u, None
         else:
@@ -186,6 +193,10 @@ class _AttnFn(torch.autograd.Function):
             _hip.check(lib.genie_attention_bwd_cond(P(u), P(k), P(v), P(out), None, P(dout), P(lse), P(D), P(du), P(dk32), P(dv32), nseq, n_head, d_head, S,
                                                     _hip.i64(qmap), _hip.i64(kvmap), _hip.i64(qmap), scale, 1 if causal else 0, c, c, ntok, _hip.stream_ptr()),
                        'genie_attention_bwd_cond')
+        elif dropout_p > 0.0:
+            _hip.check(lib.genie_attention_bwd_dropout(P(u), P(k), P(v), P(out), None, P(dout), P(lse), P(D), P(du), P(dk), P(dv),
+                                                       nseq, n_head, d_head, S, Sk, _hip.i64(qmap), _hip.i64(kvmap), _hip.i64(qmap), dkvmap, scale,
+                                                       1 if causal else 0, c, ntok, dropout_p, seed, _hip.stream_ptr()), 'genie_attention_bwd_dropout')
         else:
             _hip.check(lib.genie_attention_bwd(P(u), P(k), P(v), P(out), None, P(dout), P(lse), P(D), P(du), P(dk), P(dv),
                                                nseq, n_head, d_head, S, Sk, _hip.i64(qmap), _hip.i64(kvmap), _hip.i64(qmap), dkvmap, scale,
@@ -207,7 +218,7 @@ class _AttnFn(torch.autograd.Function):
             else:
                 dkext = dk.reshape(b, inner, Sk, c).float().sum(1).to(kext.dtype)
                 dvext = dv.reshape(b, inner, Sk, c).float().sum(1).to(vext.dtype)
-        return (dx, None if direct else dgamma, None if direct else dbeta, None, dkext, dvext, None, None, None, None, None, None, None)
+        return (dx, None if direct else dgamma, None if direct else dbeta, None, dkext, dvext, None, None, None, None, None, None, None, None, None)
 
 
 class Attention(nn.Module):
@@ -229,8 +240,11 @@ class Attention(nn.Module):
         self.scale = default(scale, n_head * d_head ** -0.5)          # QUIRK: operator precedence (attention.py:195)
         self.causal, self.dropout = causal, dropout
         self.n_head, self.d_head = n_head, d_head
-        if dropout != 0.0:
-            raise NotImplementedError('Attention: dropout is not implemented on the HIP path')
+        if not 0.0 <= float(dropout) < 1.0:
+            raise ValueError(f'Attention: dropout={dropout} not in [0, 1)')
+        if dropout != 0.0 and d_head < 32:
+            raise NotImplementedError('Attention: dropout needs d_head >= 32 on the HIP path (the d_head 8 / 16 kernels take no mask)')
+        self.last_dropout_seed = None                               # the seed of the most recent forward (tests rebuild the mask from it)
 
     def _video_forward(self, video: Tensor, cond: Optional[Tensor], mask, transpose: bool, add_resid: bool) -> Tensor:
         if mask is not None:
@@ -256,8 +270,17 @@ class Attention(nn.Module):
             lin = lambda mod, t: GF.linear(t, mod.weight, mod.bias, out_dtype=torch.bfloat16) if isinstance(mod, nn.Linear) else mod(t)
             kext = lin(self.to_qkv.to_k, kc).to(torch.bfloat16).contiguous()       # Linear(key_dim -> C): csrc/linear_small.hip when key_dim <= 32
             vext = lin(self.to_qkv.to_v, kc).to(torch.bfloat16).contiguous()
+        p_drop, seed = float(self.dropout), 0
+        if p_drop > 0.0:
+            # QUIRK kept: the reference passes `dropout_p=self.dropout` to the FUNCTIONAL sdpa (attention.py:229), which has no training switch --
+            # the weights are dropped in eval mode too.  The seed comes from torch's CPU generator (torch.manual_seed reproduces a run; no device
+            # sync) and is baked into the launch arguments, so a captured step would replay one mask for ever: refused.
+            if x.is_cuda and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError('Attention: dropout > 0 cannot be captured in a hipGraph (the mask seed is a launch argument)')
+            seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+            self.last_dropout_seed = seed
         out = _AttnFn.apply(x, self.norm.weight, self.norm.bias, table, kext, vext, self._mode, self.n_head, self.d_head, float(self.scale),
-                            bool(self.causal), add_resid, self.norm.eps)
+                            bool(self.causal), add_resid, self.norm.eps, p_drop, seed)
         if not isinstance(self.to_out[1], nn.Identity):
             o = self.to_out[1](out.permute(0, 2, 3, 4, 1).float())
             out = to_cl(o.permute(0, 4, 1, 2, 3))

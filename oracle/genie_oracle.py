@@ -448,12 +448,15 @@ def rotary_apply(x: Tensor, freq: Tensor) -> Tensor:
 # a10  Attention core                                  genie/module/attention.py:154-239
 # ----------------------------------------------------------------------------------------------
 def attention_core(x: Tensor, sd: SD, prefix: str, n_head: int, d_head: int, causal: bool, rotary_kind: Optional[str],
-                   cond: Optional[Tensor] = None, scale: Optional[float] = None) -> Tensor:
+                   cond: Optional[Tensor] = None, scale: Optional[float] = None, drop_keep: Optional[Tensor] = None, drop_p: float = 0.0) -> Tensor:
     """x: (B', S, C) with C == n_head*d_head (QUIRK 3: to_q/to_k/to_v/to_out are Identity then).
 
     attention.py:219-236: rotary (before the norm, QUIRK 2) -> LayerNorm -> q = k = v = that tensor
     unless `cond` is given, in which case k = to_k(cond) and v = to_v(k) ... see below.
-    QUIRK 1: scale = n_head * d_head**-0.5 (attention.py:195)."""
+    QUIRK 1: scale = n_head * d_head**-0.5 (attention.py:195).
+    `drop_keep` (B', n_head, Sq, Sk; 1 = kept) with `drop_p`: attention.py:229 `dropout_p=self.dropout` -- sdpa's documented form
+    `torch.dropout(softmax(S), p) @ V` with the Bernoulli draws GIVEN (torch's Philox stream is backend-specific; the HIP path's counter-based
+    mask is exported by genie_attention_dropout_mask and applied here)."""
     c = n_head * d_head
     # (no separate gradient store for x: the rotary+LayerNorm backward kernel adds the skip branch's gradient in fp32 and stores the sum)
     if rotary_kind is not None:
@@ -473,16 +476,22 @@ def attention_core(x: Tensor, sd: SD, prefix: str, n_head: int, d_head: int, cau
     qh, kh, vh = heads(q), heads(k), heads(v)
     scale = scale if scale is not None else n_head * d_head ** -0.5
 
-    def sdpa(qc: Tensor, kc: Tensor, vc: Tensor) -> Tensor:
+    def sdpa(qc: Tensor, kc: Tensor, vc: Tensor, keep: Optional[Tensor] = None) -> Tensor:
         att = torch.matmul(qc, kc.transpose(-1, -2)) * scale
         if causal:
             sq, sk = att.shape[-2:]
             m = torch.ones(sq, sk, dtype=torch.bool).tril()          # SDPA is_causal: top-left aligned
             att = att.masked_fill(~m, float('-inf'))
-        return torch.matmul(att.softmax(dim=-1), vc)
+        w = att.softmax(dim=-1)
+        if keep is not None:
+            w = w * keep.to(w.dtype) / (1.0 - drop_p)
+        return torch.matmul(w, vc)
 
     nseq, sq, sk = qh.shape[0], qh.shape[2], kh.shape[2]
-    if nseq > 1 and nseq * n_head * sq * sk > (1 << 27):
+    if drop_keep is not None:
+        assert tuple(drop_keep.shape) == (nseq, n_head, sq, sk) and 0.0 < drop_p < 1.0
+        o = sdpa(qh, kh, vh, drop_keep)
+    elif nseq > 1 and nseq * n_head * sq * sk > (1 << 27):
         # long sequences (LAM at 64x64: 16 x 4 x 4096 x 4096 scores = 4.3 GB per tensor): same arithmetic one sequence at a time, the score
         # matrices recomputed in backward instead of kept
         from torch.utils.checkpoint import checkpoint
@@ -495,27 +504,27 @@ def attention_core(x: Tensor, sd: SD, prefix: str, n_head: int, d_head: int, cau
 
 
 def spatial_attention(video: Tensor, sd: SD, prefix: str, n_head: int, d_head: int, transpose: bool, embed: bool = True,
-                      cond: Optional[Tensor] = None, scale=None) -> Tensor:
+                      cond: Optional[Tensor] = None, scale=None, drop_keep: Optional[Tensor] = None, drop_p: float = 0.0) -> Tensor:
     """attention.py:279-307.  video (B, C, T, H, W) if transpose else (B, T, H, W, C)."""
     x = video.permute(0, 2, 3, 4, 1) if transpose else video
     b, t, h, w, c = x.shape
     seq = x.reshape(b * t, h * w, c)
     if cond is not None:
         cond = cond.repeat_interleave(t, dim=0)                     # 'b hw c -> (b t) hw c'
-    out = attention_core(seq, sd, prefix, n_head, d_head, False, '2d' if embed else None, cond, scale)
+    out = attention_core(seq, sd, prefix, n_head, d_head, False, '2d' if embed else None, cond, scale, drop_keep, drop_p)
     out = out.reshape(b, t, h, w, c)
     return out.permute(0, 4, 1, 2, 3) if transpose else out
 
 
 def temporal_attention(video: Tensor, sd: SD, prefix: str, n_head: int, d_head: int, transpose: bool, embed: bool = True,
-                       cond: Optional[Tensor] = None, scale=None) -> Tensor:
+                       cond: Optional[Tensor] = None, scale=None, drop_keep: Optional[Tensor] = None, drop_p: float = 0.0) -> Tensor:
     """attention.py:347-371.  Causal over T, one sequence per (b, h, w)."""
     x = video.permute(0, 2, 3, 4, 1) if transpose else video           # b t h w c
     b, t, h, w, c = x.shape
     seq = x.permute(0, 2, 3, 1, 4).reshape(b * h * w, t, c)
     if cond is not None:
         cond = cond.repeat_interleave(h * w, dim=0)                 # 'b t c -> (b h w) t c'
-    out = attention_core(seq, sd, prefix, n_head, d_head, True, '1d' if embed else None, cond, scale)
+    out = attention_core(seq, sd, prefix, n_head, d_head, True, '1d' if embed else None, cond, scale, drop_keep, drop_p)
     out = out.reshape(b, h, w, t, c).permute(0, 3, 1, 2, 4)
     return out.permute(0, 4, 1, 2, 3) if transpose else out
 

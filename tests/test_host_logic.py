@@ -296,3 +296,18 @@ def test_linear_ce_plan_fills_whole_rounds():
         assert cost <= max(ideal * 1.12, ideal + 0.13), (m, tiles, ns, rounds, cost, ideal)
     assert splits(24576) == (192, 4)            # the stand-alone bench's shape keeps its three full rounds
     assert lib.genie_linear_ce_ws_floats(24616, d, v, 0) * (2 + d) == lib.genie_linear_ce_ws_floats(24616, d, v, 1) * 2      # lse-only sweep: no O partials
+
+
+def test_attention_dropout_argument_contract():
+    """Attention(dropout=...) (reference attention.py:166-198): any rate in [0, 1) constructs and is handed down by SpaceTimeAttention; what the HIP
+    path cannot do says so at construction (d_head 8 / 16 kernels take no mask), not at the first step."""
+    from genie.module.attention import SpaceTimeAttention, SpatialAttention
+    m = SpaceTimeAttention(n_head=2, d_head=32, dropout=0.25)
+    assert m.space_attn.dropout == 0.25 and m.temp_attn.dropout == 0.25 and m.space_attn.last_dropout_seed is None
+    assert SpatialAttention(n_head=2, d_head=16).dropout == 0.0
+    with pytest.raises(ValueError):
+        SpatialAttention(n_head=2, d_head=32, dropout=1.0)
+    with pytest.raises(ValueError):
+        SpatialAttention(n_head=2, d_head=32, dropout=-0.1)
+    with pytest.raises(NotImplementedError):
+        SpatialAttention(n_head=2, d_head=16, dropout=0.1)
