@@ -191,6 +191,11 @@ typedef struct GenieWgradDesc {
                              row of co' is the natural weight row (co' % shuf_c) * (Cout / shuf_c) + co' / shuf_c.  Served by the lean
                              kw-triple kernel only (GENIE_ERR_ARG when its preconditions do not hold: tri_mode != 0, W in {8, 16, 32, 64},
                              H * W a multiple of 64, Cin, Cout >= 64) */
+    int32_t row_px;        /* (ABI 13) 0, or: `src` and `dy` are a W-WINDOW of wider tensors -- the memory holds row_px pixels per image row and the
+                             problem covers columns [px0, px0 + Ws) of them, zero-padded at the window's edges like a whole image.  Lean kw-triple kernel
+                             only, Ws == Wo == Wd == 64 (GENIE_ERR_ARG otherwise).  Used to run 128-pixel-wide layers (BASELINE configs[4]) as two
+                             64-column windows; the caller adds the two seam terms (dy column 63 x column 64 at kw = +1, dy 64 x 63 at kw = -1) */
+    int32_t px0;
 } GenieWgradDesc;
 
 int genie_conv_wgrad(const GenieWgradDesc* desc, void* stream);

@@ -373,6 +373,8 @@ extern "C" int genie_conv_wgrad(const GenieWgradDesc* d, void* stream) {
     {
         int rc = genie_conv_wgrad3_try(d, (hipStream_t)stream);
         if (rc <= 0) return rc;
+        GENIE_CHECK_ARG(d->row_px == 0, "genie_conv_wgrad: a W-window (row_px = %d) needs the lean kw-triple kernel (tri_mode, Ws = Wo = Wd = 64, "
+                                        "channels >= 64, block range < 2 GiB)", d->row_px);
         GENIE_CHECK_ARG(!d->dy_unshuffled, "genie_conv_wgrad: dy_unshuffled needs the lean kw-triple kernel (tri_mode, W in {8,16,32,64}, H*W %% 64 == 0, "
                                            "channels >= 64); got W=%d H=%d Cin=%d Cout=%d tri_mode=%d", d->Wo, d->Ho, d->Cin, d->Cout, d->tri_mode);
         rc = genie_conv_wgrad_pw_try(d, (hipStream_t)stream);

@@ -50,6 +50,7 @@ struct Wgrad3Args {
     int img_rows, log2W;        // (64 / W) * (W + 2);  W is a power of two in [8, 64]
     int dbg;                    // timing ablations (wrong results): 1 no MFMAs, 2 no fragment reads / MFMAs, 4 no DMA
     int trim;                   // wgrad3l: skip the chunks of time-padding frames (GENIE_W3_TRIM=1; off by default)
+    int row_px, px0;            // wgrad3l, W = 64: memory pixels per image row (>= W) and the window's first column (GenieWgradDesc::row_px; dense: W, 0)
     FastDiv3 dW_, dH_, dT_;
 };
 
@@ -395,11 +396,13 @@ __device__ __forceinline__ void w3l_loop(const Wgrad3Args& a, char* smem, const 
                                           f32x16_t (&acc)[3][2], f32x16_t (&accb)[2], int clip_left, const int clip_chunks, const int skip_frames) {
     constexpr int BK = 64, W = 1 << LOG2W, HS = BK >> LOG2W, PITCH = 256;
     constexpr int A_BYTES = BK * PITCH, X_BYTES = 80 * PITCH, STAGE = A_BYTES + X_BYTES, NSTAGE = W3_NSTAGE, TM = 2;
-    const uint32_t dy_step = (uint32_t)(BK * a.Cd * 2), x_step = (uint32_t)(BK * a.Cs * 2);      // bytes per chunk
+    // bytes per chunk: 64 dense pixels, or -- a 64-column window of wider rows (HS == 1) -- one memory row
+    const uint32_t chunk_px = (uint32_t)(a.row_px > W ? a.row_px : BK);
+    const uint32_t dy_step = chunk_px * (uint32_t)(a.Cd * 2), x_step = chunk_px * (uint32_t)(a.Cs * 2);
     // zero-frame skipping (skip_frames = |dt| > 0): the block walks only the chunks of frames t with 0 <= t + dt < T -- clip_chunks
     // consecutive chunks per clip; after the last of them the cursor jumps skip_frames frames ahead (to the first valid frame of the next clip)
-    const uint32_t dy_skip = (uint32_t)skip_frames * (uint32_t)(a.H * a.W) * (uint32_t)(a.Cd * 2);
-    const uint32_t x_skip = (uint32_t)skip_frames * (uint32_t)(a.H * a.W) * (uint32_t)(a.Cs * 2);
+    const uint32_t dy_skip = (uint32_t)skip_frames * (uint32_t)(a.H * a.row_px) * (uint32_t)(a.Cd * 2);
+    const uint32_t x_skip = (uint32_t)skip_frames * (uint32_t)(a.H * a.row_px) * (uint32_t)(a.Cs * 2);
     uint32_t so_dy = 0, so_x = 0;                        // scalar byte offsets of the NEXT chunk to stage, relative to the block's first
     int staged = 0;                                      // chunks staged so far
 
@@ -591,8 +594,9 @@ __global__ void __launch_bounds__(512) wgrad3l_kernel(const Wgrad3Args a) {
         x_t[i] = __builtin_amdgcn_readfirstlane((int)(q2 - fd3(q2, a.dT_) * a.dT_.d));
     }
     // resource descriptors rebased to the block's first chunk (x: to the tap's shifted row as well; only in-range rows are dereferenced)
-    const long long dy_base = (long long)c_begin * BK * a.Cd;
-    const long long x_base = (long long)c_begin * BK * a.Cs + (long long)(t_dt * a.H + t_dh) * W * a.Cs;
+    const long long chunk_px = a.row_px > W ? a.row_px : BK;
+    const long long dy_base = ((long long)c_begin * chunk_px + a.px0) * a.Cd;
+    const long long x_base = ((long long)c_begin * chunk_px + a.px0) * a.Cs + (long long)(t_dt * a.H + t_dh) * a.row_px * a.Cs;
     const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dy + dy_base), (short)0, (int)W3L_OOB, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(a.src + x_base), (short)0, (int)W3L_OOB, 0x00020000);
 
@@ -684,6 +688,11 @@ int genie_conv_wgrad3_try(const GenieWgradDesc* d, hipStream_t s) {
     if (d->st != 1 || d->sh != 1 || d->sw != 1 || d->To != d->Ts || d->Ho != d->Hs || d->Wo != d->Ws) return 1;
     if (d->ntaps % 3 != 0 || d->ntaps < 3) return 1;
     const int W = d->Wo;
+    const bool window = d->row_px != 0;
+    if (window && !(W == 64 && d->Wd == 64 && d->row_px >= 64 && d->px0 >= 0 && d->px0 + 64 <= d->row_px && !d->dy_unshuffled && d->shuf_c >= d->Cout)) {
+        genie_set_error("genie_conv_wgrad: a W-window wants Ws = Wo = Wd = 64 inside row_px >= px0 + 64 pixels and a plain (unshuffled) dy");
+        return GENIE_ERR_ARG;
+    }
     if (!(W == 8 || W == 16 || W == 32 || W == 64)) return 1;
     if (d->Cin < 64 || d->Cout < 64) return 1;
     Wgrad3Args a;
@@ -757,7 +766,10 @@ int genie_conv_wgrad3_try(const GenieWgradDesc* d, hipStream_t s) {
     genie_note_variant(GENIE_VARIANT_WGRAD3);
     // lean main loop (buffer-addressed LDS-DMA, scalar bookkeeping) where its preconditions hold -- see wgrad3l_kernel
     static const int lean_on = getenv("GENIE_W3_LEAN") ? atoi(getenv("GENIE_W3_LEAN")) : 1;
-    const long long blk_bytes = (long long)a.chunks_per_split * 64 * (d->Cs > d->Cd ? d->Cs : d->Cd) * 2 + ((long long)(d->Hs + 2) * W * d->Cs * 2);
+    a.row_px = window ? d->row_px : W;
+    a.px0 = window ? d->px0 : 0;
+    const long long chunk_px = a.row_px > W ? a.row_px : 64;
+    const long long blk_bytes = (long long)a.chunks_per_split * chunk_px * (d->Cs > d->Cd ? d->Cs : d->Cd) * 2 + ((long long)(d->Hs + 2) * a.row_px * d->Cs * 2);
     a.trim = 0;
     if (lean_on && !shuffled && a.dbg == 0 && (d->Ho * W) % 64 == 0 && 64 / W <= d->Ho && blk_bytes < 0x7f000000ll && d->Td == d->Ts && d->Hd == d->Hs && d->Wd == W) {
         // zero-frame skipping (GENIE_W3_TRIM=1; OFF by default): a block's address range grows by the (<= 2 per clip) padding frames it
@@ -767,7 +779,7 @@ int genie_conv_wgrad3_try(const GenieWgradDesc* d, hipStream_t s) {
         static const int trim_on = getenv("GENIE_W3_TRIM") ? atoi(getenv("GENIE_W3_TRIM")) : 0;
         const long long cpf = (long long)d->Ho * W / 64;
         const long long span = a.chunks_per_split + (a.chunks_per_split / (cpf * (d->To > 2 ? d->To - 2 : 1)) + 2) * 2 * cpf;
-        a.trim = trim_on && d->To >= 3 && span * 64 * (d->Cs > d->Cd ? d->Cs : d->Cd) * 2 + ((long long)(d->Hs + 2) * W * d->Cs * 2) < 0x7f000000ll;
+        a.trim = trim_on && !window && d->To >= 3 && span * 64 * (d->Cs > d->Cd ? d->Cs : d->Cd) * 2 + ((long long)(d->Hs + 2) * W * d->Cs * 2) < 0x7f000000ll;
         void (*lk)(const Wgrad3Args) = a.log2W == 3 ? wgrad3l_kernel<3> : a.log2W == 4 ? wgrad3l_kernel<4> : a.log2W == 5 ? wgrad3l_kernel<5> : wgrad3l_kernel<6>;
         static bool lconf[8] = {false};
         if (!lconf[a.log2W]) {
@@ -783,6 +795,7 @@ int genie_conv_wgrad3_try(const GenieWgradDesc* d, hipStream_t s) {
         GENIE_CHECK_LAUNCH();
         return GENIE_OK;
     }
+    if (window) return 1;                                 // (the caller reports it: only the lean kernel knows windows)
     if (d->dy_unshuffled) {
         genie_set_error("genie_conv_wgrad: dy_unshuffled is served by the lean kw-triple kernel only (H * W %% 64 == 0, 64 / W <= H, block range < 2 GiB)");
         return GENIE_ERR_ARG;

@@ -52,7 +52,7 @@ class GenieWgradDesc(C.Structure):
                 ('dot', C.c_int32), ('doh', C.c_int32), ('dow', C.c_int32),
                 ('shuf_c', C.c_int32), ('shuf_q', C.c_int32), ('shuf_r', C.c_int32),
                 ('s_cout', C.c_int64), ('s_tap', C.c_int64), ('s_cin', C.c_int64), ('split_k', C.c_int32), ('tri_mode', C.c_int32),
-                ('pointwise', C.c_int32), ('dy_unshuffled', C.c_int32)]
+                ('pointwise', C.c_int32), ('dy_unshuffled', C.c_int32), ('row_px', C.c_int32), ('px0', C.c_int32)]
 
 
 class GeniePackJob(C.Structure):

@@ -724,6 +724,57 @@ def unshuffle_dy(dy: Tensor, spec: ConvSpec) -> Tensor:
     return _unshuffle(dy, spec, 'pqrc')
 
 
+# 128-pixel-wide layers (BASELINE configs[4]: the LatentAction ST blocks' 3x3x3 feed-forward convs at 128 x 128): the lean kw-triple weight-gradient
+# kernel stages whole 64-pixel chunks with zero columns left and right, i.e. W <= 64.  A 128-wide image is TWO 64-column windows of the same memory
+# (GenieWgradDesc.row_px / px0: a chunk is then half a memory row) plus the two products the windows' zero edges leave out -- at the seam, dy column 63
+# meets x column 64 through the kw = +1 tap and dy column 64 meets x column 63 through kw = -1: two (kt, kh, 1) weight gradients over one-pixel-wide
+# copies of those columns (1 / 64 of the work, generic kernel).  GENIE_WGRAD_WINDOWS=0: the whole layer on the generic kernel (rounds 1-5; A/B, tests).
+WGRAD_WINDOWS = os.environ.get('GENIE_WGRAD_WINDOWS', '1') != '0'
+
+
+def wgrad_windows_ok(spec: ConvSpec, x: Tensor, dy: Tensor, dy_unshuffled: bool = False) -> bool:
+    n, _, t, h, w = x.shape
+    return bool(WGRAD_WINDOWS and TRI_WGRAD and w == 128 and not dy_unshuffled and spec.shuffle is None and spec.stride == (1, 1, 1) and spec.kernel[2] == 3
+                and spec.dilation[2] == 1 and spec.pad_front[2] == 1 and spec.pad_back[2] == 1 and tuple(dy.shape[2:]) == (t, h, w)
+                and spec.cin >= 64 and spec.cout >= 64
+                and (n * t * h + h + 2) * w * max(pitch_of(x), pitch_of(dy)) * 2 < 0x7f000000)        # a block's buffer range (the kernel's own 2-GiB rule)
+
+
+def _conv_wgrad_windows(x: Tensor, dy: Tensor, spec: ConvSpec, dweight: Tensor, dbias: Optional[Tensor]) -> None:
+    from .cl import to_cl
+    n, _, t, h, w = x.shape
+    s = dweight.stride()
+    kt, kh, kw = spec.kernel
+    if not (s[3] == kw * s[4] and s[2] == kh * s[3]):
+        raise ValueError('conv_wgrad: weight-gradient taps must be flattenable (contiguous or channels_last_3d)')
+    taps, ntaps, _ = fwd_taps(spec)
+    t0 = PROFILER.begin() if PROFILER is not None and not PROFILER.only_triple else None
+    for px0 in (0, 64):
+        d = _hip.GenieWgradDesc()
+        d.src, d.dy, d.dw, d.dbias, d.taps, d.ntaps = x.data_ptr(), dy.data_ptr(), dweight.data_ptr(), _hip.ptr(dbias), taps.data_ptr(), ntaps
+        d.N, d.Ts, d.Hs, d.Ws, d.Cs, d.Cin = n, t, h, 64, pitch_of(x), spec.cin
+        d.To, d.Ho, d.Wo = t, h, 64
+        d.st = d.sh = d.sw = 1
+        d.Td, d.Hd, d.Wd, d.Cd, d.Cout = t, h, 64, pitch_of(dy), spec.cout
+        d.dmt = d.dmh = d.dmw = 1
+        d.dot = d.doh = d.dow = 0
+        d.shuf_c, d.shuf_q, d.shuf_r = spec.cout, 1, 1
+        d.s_cout, d.s_tap, d.s_cin = s[0], s[4], s[1]
+        d.split_k = 1 if DETERMINISTIC else FORCE_SPLIT_K
+        d.tri_mode, d.pointwise, d.dy_unshuffled = 2, 0, 0
+        d.row_px, d.px0 = w, px0
+        _hip.check(_hip.load_library().genie_conv_wgrad(C.byref(d), _hip.stream_ptr()), 'genie_conv_wgrad (W-window)')
+    if t0 is not None:
+        PROFILER.end(_variant('wgrad', spec, 0, False), f'wgrad {spec.cin}->{spec.cout} k{spec.kernel} s{spec.stride} @{(t, h, w)} (2 windows)',
+                     2.0 * n * t * h * w * spec.cout * spec.cin * spec.ntaps, t0)
+    seam = ConvSpec(spec.cin, spec.cout, (kt, kh, 1), (1, 1, 1), (spec.dilation[0], spec.dilation[1], 1), (spec.pad_front[0], spec.pad_front[1], 0),
+                    (spec.pad_back[0], spec.pad_back[1], 0), None)
+    for xc, dc, k in ((64, 63, 2), (63, 64, 0)):
+        dwv = dweight[:, :, :, :, k:k + 1]
+        dwv = dwv.as_strided(dwv.shape, (s[0], s[1], s[2], s[3], s[3]))      # (the size-1 axis takes the stride that makes the taps flattenable)
+        conv_wgrad(to_cl(x[:, :, :, :, xc:xc + 1]), to_cl(dy[:, :, :, :, dc:dc + 1]), seam, dwv, None)       # one-pixel-wide dense copies
+
+
 def _bias_grad_fixed_order(dy: Tensor, spec: ConvSpec, dy_unshuffled: bool) -> Tensor:
     """fp32 [cout] column sums of `dy` in the natural order of the bias, reduced in a fixed tree (torch's sum uses no atomics).  For an
     upsample conv the bias sits before the depth-to-space-time rearrange: channel ``c * PQR + f`` of the bias collects final channel c at
@@ -759,6 +810,8 @@ def conv_wgrad(x: Tensor, dy: Tensor, spec: ConvSpec, dweight: Tensor, dbias: Op
         dbias = None
     if narrow_wgrad_ok(spec, x, dy):
         return conv_narrow_wgrad(x, dy, spec, dweight, dbias, f'wgrad {spec.cin}->{spec.cout} k3 @{(t, h, w)}')
+    if wgrad_windows_ok(spec, x, dy, dy_unshuffled):
+        return _conv_wgrad_windows(x, dy, spec, dweight, dbias)
     s = dweight.stride()
     kt, kh, kw = spec.kernel
     if kt * kh * kw > 1 and not (s[3] == kw * s[4] and s[2] == kh * s[3]):

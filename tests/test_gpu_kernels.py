@@ -547,6 +547,65 @@ TRI_WGRAD_CASES = [
 ]
 
 
+@pytest.mark.parametrize('cin,cout,kernel,causal,size,wfmt', [
+    (64, 128, (3, 3, 3), True, (1, 3, 6, 128), 'cl'),
+    (128, 64, (3, 3, 3), False, (2, 2, 5, 128), 'contig'),
+    (256, 256, (3, 3, 3), True, (1, 4, 16, 128), 'cl'),        # the LatentAction feed-forward conv of BASELINE configs[4], fewer rows
+    (72, 200, (1, 3, 3), False, (1, 2, 4, 128), 'cl'),         # partial channel tiles, kt = 1
+    (64, 64, (3, 1, 3), True, (1, 3, 2, 128), 'cl'),           # kh = 1
+])
+def test_conv_wgrad_128_wide_as_two_windows(G, cin, cout, kernel, causal, size, wfmt, monkeypatch):
+    """W = 128 (BASELINE configs[4]): two 64-column windows on the lean kw-triple kernel (GenieWgradDesc.row_px / px0) + the two seam products, against
+    autograd of the oracle and against the generic kernel on the whole layer (GENIE_WGRAD_WINDOWS=0, what rounds 1-5 ran); the bias gradient is the sum
+    of the two windows'.  A gradient that ignored the seam would be off by ~1 / 64 of the kw = +-1 taps: the bound below is 1e-3 of the maximum."""
+    from oracle import genie_oracle as O
+    torch.manual_seed(29)
+    n, t, h, w = size
+    x = bf16_round(torch.randn(n, cin, t, h, w))
+    wt = torch.randn(cout, cin, *kernel, requires_grad=True)
+    b = torch.randn(cout, requires_grad=True)
+    if causal:
+        ref = O.causal_conv3d(x, wt, b)
+        spec = G.conv.causal_spec(cin, cout, kernel)
+    else:
+        ref = F.conv3d(x, wt, b, padding=tuple((k - 1) // 2 for k in kernel))
+        spec = G.conv.same_spec(cin, cout, kernel)
+    dy = bf16_round(torch.randn_like(ref))
+    ref.backward(dy)
+    xc, dyc = G.cl.to_cl(x.cuda()), G.cl.to_cl(dy.cuda())
+    assert G.conv.wgrad_windows_ok(spec, xc, dyc)
+    mk = lambda: (torch.zeros(cout, cin, *kernel, device='cuda').contiguous(memory_format=torch.channels_last_3d) if wfmt == 'cl'
+                  else torch.zeros(cout, cin, *kernel, device='cuda'))
+    dw, db = mk(), torch.zeros(cout, device='cuda')
+    G.conv.conv_wgrad(xc, dyc, spec, dw, db)
+    amax = wt.grad.abs().max().item()
+    torch.testing.assert_close(dw.cpu(), wt.grad, rtol=1e-3, atol=1e-3 * amax)
+    torch.testing.assert_close(db.cpu(), b.grad, rtol=1e-3, atol=1e-3 * b.grad.abs().max().item())
+    # the seam is there: per-tap error of the kw = +-1 taps no larger than that of the kw = 0 taps
+    err = (dw.cpu() - wt.grad).abs().amax((0, 1, 2, 3))
+    assert err[0] < 4 * err[1] + 1e-4 * amax and err[2] < 4 * err[1] + 1e-4 * amax, err
+    G.conv.conv_wgrad(xc, dyc, spec, dw, None)                                           # accumulates
+    torch.testing.assert_close(dw.cpu(), 2 * wt.grad, rtol=1e-3, atol=2e-3 * amax)
+    monkeypatch.setattr(G.conv, 'WGRAD_WINDOWS', False)
+    dw2, db2 = mk(), torch.zeros(cout, device='cuda')
+    G.conv.conv_wgrad(xc, dyc, spec, dw2, db2)
+    torch.testing.assert_close(dw2, dw * 0.5, rtol=1e-3, atol=1e-3 * amax)
+    torch.testing.assert_close(db2, db, rtol=1e-3, atol=1e-3 * b.grad.abs().max().item())
+    # deterministic mode: one owner per element in both windows, launches serialised on the stream -> bit-identical run to run
+    monkeypatch.setattr(G.conv, 'WGRAD_WINDOWS', True)
+    old = G.conv.set_deterministic(True)
+    try:
+        runs = []
+        for _ in range(2):
+            dwd, dbd = mk(), torch.zeros(cout, device='cuda')
+            G.conv.conv_wgrad(xc, dyc, spec, dwd, dbd)
+            runs.append((dwd, dbd))
+    finally:
+        G.conv.set_deterministic(old)
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+    torch.testing.assert_close(runs[0][0].cpu(), wt.grad, rtol=1e-3, atol=1e-3 * amax)
+
+
 @pytest.mark.parametrize('cin,cout,kernel,causal,size,shuffle', TRI_WGRAD_CASES)
 def test_conv_wgrad_triple_kernel(G, cin, cout, kernel, causal, size, shuffle, monkeypatch):
     """conv_wgrad3.hip (one block per kw-triple: shared dy tile and x image) against autograd of the oracle."""
