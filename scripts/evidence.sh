@@ -85,11 +85,11 @@ PY
     guard)
       # kernel-level suite with every Python-side allocation behind guard pages (tests/guard.py), in TWO file orders (round 4's overrun showed
       # in one order only), then the regression: the library with that overrun compiled back in must die under the harness
-      F1="tests/test_gpu_kernels.py tests/test_gpu_golden.py tests/test_gpu_attention.py tests/test_gpu_maskgit.py tests/test_gpu_linear_ce.py"
-      F2="tests/test_gpu_linear_ce.py tests/test_gpu_maskgit.py tests/test_gpu_golden.py tests/test_gpu_attention.py tests/test_gpu_kernels.py"
+      F1="tests/test_gpu_kernels.py tests/test_gpu_golden.py tests/test_gpu_attention.py tests/test_gpu_attention_dropout.py tests/test_gpu_maskgit.py tests/test_gpu_linear_ce.py"
+      F2="tests/test_gpu_linear_ce.py tests/test_gpu_maskgit.py tests/test_gpu_golden.py tests/test_gpu_attention_dropout.py tests/test_gpu_attention.py tests/test_gpu_kernels.py"
       timeout 1500 python scripts/guard_run.py $F1 -q -m gpu -p no:cacheprovider -x 2>&1 | tail -6 > $OUT/${TAG}_guard_order1.log
       timeout 1500 python scripts/guard_run.py $F2 -q -m gpu -p no:cacheprovider -x 2>&1 | tail -6 > $OUT/${TAG}_guard_order2.log
-      [ -f open-genie_amd/lib/libgenie_hip_oobprobe.so ] || make -C open-genie_amd probe -j 8 > $OUT/make_probe.log 2>&1
+      make -C open-genie_amd probe -j 8 > $OUT/make_probe.log 2>&1      # incremental: rebuilt whenever the sources (or the ABI) moved since the last probe build
       GENIE_GUARD_REGRESSION=1 timeout 600 python -m pytest tests/test_gpu_guard.py -q -m gpu -p no:cacheprovider 2>&1 | tail -4 > $OUT/${TAG}_guard_regression.log
       for f in $OUT/${TAG}_guard_order1.log $OUT/${TAG}_guard_order2.log $OUT/${TAG}_guard_regression.log; do tail -n 2 $f; done ;;
     multigpu)
