@@ -1,0 +1,210 @@
+"""Seeded random sweeps over the geometry the public modules accept (-m gpu): `CausalConv3d` (channels, kernel, stride, dilation, frame / image sizes, with
+and without bias, both spatial paddings) and `SpaceTimeAttention` (heads, head width, T x H x W, layout, temporal condition) against the oracle -- outputs,
+input gradients and every parameter gradient.  The hand-picked cases of test_gpu_kernels.py / test_gpu_attention.py pin each kernel family on the shapes it was
+written for; these draws cross the DISPATCH predicates (narrow / kw-triple / lean / pointwise / windowed / packed / general) at shapes nobody picked.
+The draws are a pure function of the case index, so a failure reproduces from its parameter id."""
+import random
+
+import pytest
+import torch
+
+from util import assert_close_bf16, bf16_round, report
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_rms(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return ((a - b).pow(2).mean().sqrt() / (b.pow(2).mean().sqrt() + 1e-20)).item()
+
+
+def draw_conv(i):
+    r = random.Random(1000 + i)
+    chans = [1, 2, 3, 4, 8, 10, 16, 18, 24, 64, 72, 128, 136, 256]
+    cin, cout = r.choice(chans), r.choice(chans)
+    kt = r.choice([1, 1, 2, 3, 3, 3, 5])
+    ks = r.choice([1, 3, 3, 3, 5])
+    kernel = (kt, ks, ks) if r.random() < 0.8 else (kt, r.choice([1, 3]), r.choice([1, 3, 5]))
+    stride = r.choice([(1, 1, 1)] * 5 + [(1, 2, 2), (2, 2, 2), (2, 1, 1), (1, 1, 2)])
+    dilation = r.choice([(1, 1, 1)] * 4 + [(2, 1, 1), (1, 2, 2)])
+    w = r.choice([3, 5, 7, 8, 11, 16, 20, 32, 32, 64, 64, 128])
+    h = r.choice([2, 3, 4, 6, 8, 9, 16]) if w >= 32 else r.choice([3, 4, 5, 8, 12, 17])
+    t = r.choice([1, 2, 3, 4, 6, 9])
+    n = r.choice([1, 1, 2, 3])
+    if stride[0] == 2 and kt == 1:
+        t = max(t, 3)                                    # the negative causal pad of this combination crops a frame
+    # keep the oracle cheap and the effective kernel inside the padded image
+    while n * t * h * w * max(cin, cout) > 6_000_000:
+        n, t = max(1, n - 1), max(1, t - 1)
+        if n == 1 and t == 1:
+            h = max(2, h // 2)
+    tp = (kt - 1) * dilation[0] + (1 - stride[0])         # causal front padding (negative: crops)
+    while t + tp < dilation[0] * (kt - 1) + 1:
+        t += 1                                            # the padded clip must hold one (dilated) kernel in time
+    bias = r.random() < 0.7
+    return cin, cout, kernel, stride, dilation, (n, t, h, w), bias
+
+
+@pytest.mark.parametrize('i', range(96))
+def test_causal_conv3d_random_geometry(i):
+    from oracle import genie_oracle as O
+    from genie.module.video import CausalConv3d
+    cin, cout, kernel, stride, dilation, (n, t, h, w), bias = draw_conv(i)
+    eff = [dilation[a] * (kernel[a] - 1) + 1 for a in range(3)]
+    if eff[1] > h + 2 * ((kernel[1] - 1) // 2) or eff[2] > w + 2 * ((kernel[2] - 1) // 2):
+        pytest.skip('dilated kernel larger than the padded image')
+    torch.manual_seed(i)
+    m = CausalConv3d(cin, cout, kernel, stride=stride, dilation=dilation, bias=bias)
+    fan = cin * kernel[0] * kernel[1] * kernel[2]
+    with torch.no_grad():
+        m.conv3d.weight.copy_(bf16_round(torch.randn_like(m.conv3d.weight) / fan ** 0.5))
+        if bias:
+            m.conv3d.bias.copy_(torch.randn_like(m.conv3d.bias))
+    wt = m.conv3d.weight.detach().clone().requires_grad_(True)
+    bt = m.conv3d.bias.detach().clone().requires_grad_(True) if bias else None
+    x = bf16_round(torch.randn(n, cin, t, h, w))
+    xr = x.clone().requires_grad_(True)
+    ref = O.causal_conv3d(xr, wt, bt, stride=stride, dilation=dilation)
+    if ref.numel() == 0:
+        pytest.skip('empty output')
+    dy = bf16_round(torch.randn_like(ref))
+    ref.backward(dy)
+    m = m.cuda()
+    xc = x.cuda().requires_grad_(True)
+    out = m(xc)
+    assert tuple(out.shape) == tuple(ref.shape), (tuple(out.shape), tuple(ref.shape))
+    assert_close_bf16(out, ref, f'conv fwd {cin}->{cout} k{kernel} s{stride} d{dilation} @{(n, t, h, w)}')
+    out.backward(dy.cuda())
+    errs = {'dx': rel_rms(xc.grad, xr.grad), 'dw': rel_rms(m.conv3d.weight.grad, wt.grad)}
+    if bias:
+        errs['db'] = rel_rms(m.conv3d.bias.grad, bt.grad)
+    assert errs['dx'] < 1e-2 and errs['dw'] < 5e-3 and errs.get('db', 0.0) < 5e-3, (errs, cin, cout, kernel, stride, dilation, (n, t, h, w))
+    report('random_conv', i=i, cin=cin, cout=cout, kernel=kernel, stride=stride, dilation=dilation, size=(n, t, h, w), **errs)
+
+
+def draw_attn(i):
+    r = random.Random(5000 + i)
+    n_head = r.choice([1, 2, 4, 8])
+    d_head = r.choice([8, 16, 32, 64, 64, 64, 128])
+    while n_head * d_head > 512:
+        n_head //= 2
+    t = r.choice([1, 2, 3, 5, 8, 12, 16, 17, 33])
+    h, w = r.choice([(1, 1), (2, 3), (3, 3), (4, 4), (5, 7), (8, 8), (9, 9), (12, 12), (16, 16)])
+    if t * h * w * n_head * d_head > 1_500_000:
+        t = max(1, 1_500_000 // (h * w * n_head * d_head))
+    transpose = r.random() < 0.5
+    cond = r.random() < 0.3
+    b = r.choice([1, 2, 3])
+    return n_head, d_head, (b, t, h, w), transpose, cond
+
+
+@pytest.mark.parametrize('i', range(64))
+def test_space_time_attention_random_geometry(i):
+    from oracle import genie_oracle as O
+    from genie.module.attention import SpaceTimeAttention
+    n_head, d_head, (b, t, h, w), transpose, cond = draw_attn(i)
+    c = n_head * d_head
+    torch.manual_seed(i)
+    kw = {'time_attn_kw': {'key_dim': 8}} if cond else {}
+    m = SpaceTimeAttention(n_head=n_head, d_head=d_head, transpose=transpose, **kw)
+    with torch.no_grad():
+        for name, p in m.named_parameters():
+            if 'freq' in name:
+                continue
+            if p.dim() < 2:
+                p.copy_(torch.randn_like(p) * 0.3 + (1.0 if name.endswith('weight') else 0.0))
+            else:
+                p.copy_(bf16_round(torch.randn_like(p) * (0.02 if p.dim() == 5 else 0.3)))
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    m = m.cuda()
+    x = bf16_round(torch.randn(b, c, t, h, w) if transpose else torch.randn(b, t, h, w, c))
+    cd = bf16_round(torch.randn(b, t, 8)) if cond else None
+    sd_req = {k: (v.clone().requires_grad_(True) if 'freq' not in k else v) for k, v in sd.items()}
+    xr = x.clone().requires_grad_(True)
+    cr = cd.clone().requires_grad_(True) if cond else None
+    ref = O.space_time_block(xr, sd_req, '', n_head, d_head, transpose=transpose, cond=(None, cr) if cond else None)
+    dy = bf16_round(torch.randn_like(ref))
+    ref.backward(dy)
+    xc = x.cuda().requires_grad_(True)
+    cc = cd.cuda().requires_grad_(True) if cond else None
+    out = m(xc, cond=(None, cc)) if cond else m(xc)
+    assert tuple(out.shape) == tuple(ref.shape)
+    e_out = rel_rms(out, ref)
+    assert e_out < 1.5e-2, (e_out, n_head, d_head, (b, t, h, w), transpose, cond)
+    out.backward(dy.cuda())
+    e_dx = rel_rms(xc.grad, xr.grad)
+    assert e_dx < 5e-2, (e_dx, n_head, d_head, (b, t, h, w), transpose, cond)
+    worst = ('', 0.0)
+    for name, p in m.named_parameters():
+        if 'freq' in name:
+            continue
+        assert p.grad is not None, name
+        want = sd_req[name].grad
+        if want.float().pow(2).mean().sqrt().item() < 1e-7:
+            # T = 1 with a temporal condition: one key, softmax = 1 -- the gradients of everything in front of the scores (LayerNorm, to_k) are exactly
+            # zero in the reference; here they are the rounding noise of p - 1
+            assert p.grad.float().pow(2).mean().sqrt().item() < 1e-4, name
+            continue
+        e = rel_rms(p.grad, want)
+        worst = max(worst, (name, e), key=lambda v: v[1])
+    assert worst[1] < 6e-2, (worst, n_head, d_head, (b, t, h, w), transpose, cond)
+    if cond:
+        assert rel_rms(cc.grad, cr.grad) < 6e-2
+    report('random_st_attention', i=i, n_head=n_head, d_head=d_head, size=(b, t, h, w), transpose=transpose, cond=cond, out=e_out, dx=e_dx,
+           worst_param=worst[0], worst_param_err=worst[1])
+
+
+def draw_gn(i):
+    r = random.Random(9000 + i)
+    c = r.choice([8, 16, 24, 40, 64, 72, 128, 136, 256, 512])
+    divs = [g for g in (1, 2, 3, 4, 5, 8, 9, 16, 17, 32, 64) if c % g == 0]
+    g = r.choice(divs + [1, 1, c])
+    n = r.choice([1, 2, 3, 5])
+    thw = (r.choice([1, 2, 3, 4, 8]), r.choice([1, 3, 4, 8, 13, 16, 32]), r.choice([1, 2, 5, 8, 16, 31, 64]))
+    while n * c * thw[0] * thw[1] * thw[2] > 8_000_000:
+        thw = (max(1, thw[0] // 2), thw[1], thw[2])
+        n = max(1, n - 1)
+    return n, c, g, thw, r.random() < 0.4, r.random() < 0.6
+
+
+@pytest.mark.parametrize('i', range(48))
+def test_groupnorm_random_geometry(i):
+    """GroupNorm (+ adaptive scale / shift, + SiLU) through the C ABI on drawn (N, C, groups, T x H x W): forward, dx, affine and adaptive gradients."""
+    from oracle import genie_oracle as O
+    from genie import _hip, cl
+    n, c, g, thw, ada, act = draw_gn(i)
+    torch.manual_seed(i)
+    x = bf16_round(torch.randn(n, c, *thw) * 1.5 + 0.3)
+    dy = bf16_round(torch.randn(n, c, *thw))
+    gamma, beta = torch.randn(c), torch.randn(c)
+    ada_s = torch.randn(n, c) if ada else None
+    ada_b = torch.randn(n, c) if ada else None
+    leaves = [t.clone().requires_grad_(True) for t in (x, gamma, beta)] + ([ada_s.clone().requires_grad_(True), ada_b.clone().requires_grad_(True)] if ada else [])
+    ref = O.group_norm(leaves[0], g, leaves[1], leaves[2])
+    if ada:
+        ref = ref * leaves[3].reshape(n, c, 1, 1, 1) + leaves[4].reshape(n, c, 1, 1, 1)
+    if act:
+        ref = O.silu(ref)
+    ref.backward(dy)
+    lib = _hip.load_library()
+    P = _hip.ptr
+    xc, dyc = cl.to_cl(x.cuda()), cl.to_cl(dy.cuda())
+    y, dx = cl.empty_like_cl(xc), cl.empty_like_cl(xc)
+    cp, npix = cl.pitch_of(xc), thw[0] * thw[1] * thw[2]
+    dev = lambda t: None if t is None else t.cuda().contiguous()
+    g_, b_, as_, ab_ = dev(gamma), dev(beta), dev(ada_s), dev(ada_b)
+    mean, rstd = torch.empty(n * g, device='cuda'), torch.empty(n * g, device='cuda')
+    ws = torch.empty(lib.genie_groupnorm_ws_floats(n, c, g), device='cuda')
+    _hip.check(lib.genie_groupnorm_fwd(P(xc), P(y), n, npix, c, cp, g, P(g_), P(b_), P(as_), P(ab_), 1e-5, int(act), P(mean), P(rstd), P(ws), _hip.stream_ptr()), 'gn fwd')
+    tag = f'gn N={n} C={c} G={g} thw={thw} ada={ada} act={act}'
+    assert_close_bf16(y, ref, tag + ' fwd')
+    if npix * (c // g) > 1:                               # (a one-element group has zero variance: the gradient is rounding noise on both sides)
+        dgamma, dbeta = torch.zeros(c, device='cuda'), torch.zeros(c, device='cuda')
+        das = torch.empty(n, c, device='cuda') if ada else None
+        dab = torch.empty(n, c, device='cuda') if ada else None
+        _hip.check(lib.genie_groupnorm_bwd(P(xc), P(dyc), P(dx), n, npix, c, cp, g, P(g_), P(b_), P(as_), P(ab_), int(act), P(mean), P(rstd),
+                                           P(dgamma), P(dbeta), P(das), P(dab), P(ws), _hip.stream_ptr()), 'gn bwd')
+        assert_close_bf16(dx, leaves[0].grad, tag + ' dx', rms_frac=5e-3)
+        for got, want, nm in [(dgamma, leaves[1].grad, 'dgamma'), (dbeta, leaves[2].grad, 'dbeta')] + ([(das, leaves[3].grad, 'dada_s'), (dab, leaves[4].grad, 'dada_b')] if ada else []):
+            torch.testing.assert_close(got.cpu(), want, rtol=2e-3, atol=2e-3 * want.abs().max().item(), msg=tag + ' ' + nm)
+    report('random_groupnorm', i=i, N=n, C=c, G=g, thw=thw, ada=ada, act=act)
