@@ -629,12 +629,14 @@ def conv_dgrad(dy: Tensor, wpack_bwd: Tensor, spec: ConvSpec, in_size: Triple, r
     if dy_unshuffled is not None:
         return conv_dgrad(dy_unshuffled, wpack_bwd, _plain(spec), in_size, resid)
     _check_cl(dy, spec.cfinal, 'conv_dgrad')
-    if spec.shuffle is not None and (spec.cfinal % 8 != 0 or (UPCONV_DGRAD_UNSHUFFLE and spec.stride == (1, 1, 1) and spec.kernel[2] == 3
-                                                              and spec.cout % 64 == 0 and spec.cin >= 128)):
+    if spec.shuffle is not None and (spec.cfinal % 8 != 0 or spec.ntaps * spec.shuffle[0] * spec.shuffle[1] * spec.shuffle[2] > 256
+                                     or (UPCONV_DGRAD_UNSHUFFLE and spec.stride == (1, 1, 1) and spec.kernel[2] == 3
+                                         and spec.cout % 64 == 0 and spec.cin >= 128)):
         # the gather through the shuffle wants whole 16-B channel chunks per sub-pixel: un-shuffle the gradient instead; the
         # transposed pack of a shuffled conv is sub-pixel-major, so the plain conv over '(p q r c)' channels is the same GEMM.
         # Also taken for the big upsample convs: one extra pass over dy buys the kw-triple kernels (1.1 - 1.3 PFLOP/s) instead of the
-        # generic gather through the shuffle (0.54 - 0.94)
+        # generic gather through the shuffle (0.54 - 0.94); and whenever the gather would need more than the 256 taps genie_conv_igemm's table
+        # holds (taps x sub-pixels: a 3x3x3 upsample conv with space_factor 4 has 432 -- found by tests/test_gpu_random_geometry.py)
         return conv_dgrad(_unshuffle(dy, spec, 'pqrc'), wpack_bwd, _plain(spec), in_size, resid)
     n = dy.shape[0]
     t, h, w = in_size

@@ -208,3 +208,199 @@ def test_groupnorm_random_geometry(i):
         for got, want, nm in [(dgamma, leaves[1].grad, 'dgamma'), (dbeta, leaves[2].grad, 'dbeta')] + ([(das, leaves[3].grad, 'dada_s'), (dab, leaves[4].grad, 'dada_b')] if ada else []):
             torch.testing.assert_close(got.cpu(), want, rtol=2e-3, atol=2e-3 * want.abs().max().item(), msg=tag + ' ' + nm)
     report('random_groupnorm', i=i, N=n, C=c, G=g, thw=thw, ada=ada, act=act)
+
+
+def _randomise(m, scale=0.1):
+    with torch.no_grad():
+        for name, p in m.named_parameters():
+            if p.dim() >= 2:
+                p.copy_(bf16_round(torch.randn_like(p) * scale / max(1.0, (p[0].numel() / 27.0) ** 0.5)))
+            else:
+                p.copy_(torch.randn_like(p) * 0.3 + (1.0 if 'weight' in name and p.dim() == 1 and 'conv' not in name else 0.0))
+
+
+def _compare_module(m, ref_fn, x, tag, out_tol=2e-2, dx_tol=3e-2, p_tol=3e-2, rounding=None):
+    """m: CPU module with its parameters set; ref_fn(x, sd) -> oracle output.  Output, dx and every parameter gradient (relative RMS).
+    `rounding='bf16_at_stores'`: the oracle rounds where the HIP path stores a tensor (oracle.set_rounding), so that the bounds measure the
+    implementation and not the bf16 representation -- needed where a non-smooth activation sits behind a normalisation (a ReLU mask computed from
+    a bf16-stored pre-norm tensor differs from the fp32 one on every element near zero: 3-10 % on the gradients in front of it, measured)."""
+    from oracle import genie_oracle as O
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    sd_req = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and k in dict(m.named_parameters()) else v) for k, v in sd.items()}
+    xr = x.clone().requires_grad_(True)
+    with O.rounding(rounding):
+        ref = ref_fn(xr, sd_req)
+        dy = bf16_round(torch.randn_like(ref))
+        ref.backward(dy)
+    m = m.cuda()
+    xc = x.cuda().requires_grad_(True)
+    out = m(xc)
+    assert tuple(out.shape) == tuple(ref.shape), (tag, tuple(out.shape), tuple(ref.shape))
+    errs = {'out': rel_rms(out, ref)}
+    assert errs['out'] < out_tol, (tag, errs)
+    out.backward(dy.cuda())
+    errs['dx'] = rel_rms(xc.grad, xr.grad)
+    assert errs['dx'] < dx_tol, (tag, errs)
+    # a parameter gradient is measured against the larger of its own RMS and 2 % of the block's typical (median) parameter-gradient RMS: a gradient
+    # that is analytically zero (a conv bias in front of a channel-summing blur + one-group GroupNorm, which remove it) is rounding noise on both sides
+    rms = lambda v: v.detach().float().pow(2).mean().sqrt().item()
+    refs = {name: sd_req[name].grad for name, _ in m.named_parameters()}
+    assert all(v is not None for v in refs.values()), tag
+    floor = 0.02 * sorted(rms(v) for v in refs.values())[len(refs) // 2]
+    for name, p in m.named_parameters():
+        assert p.grad is not None, (tag, name)
+        errs[name] = rms(p.grad.cpu() - refs[name]) / max(rms(refs[name]), floor, 1e-20)
+        assert errs[name] < p_tol, (tag, name, errs[name], rms(refs[name]), floor)
+    return errs
+
+
+def draw_resblock(i):
+    r = random.Random(13000 + i)
+    cin = r.choice([8, 16, 24, 64, 72, 128, 256])
+    cout = r.choice([None, None, 8, 16, 64, 128, 136, 256])
+    groups = r.choice([g for g in (1, 1, 1, 2, 4, 8) if cin % g == 0 and (cout or cin) % g == 0])
+    causal = r.random() < 0.5
+    down = r.choice([None, None, None, 2, (1, 2), (2, 2), (2, 1)])
+    blur = True if down is not None else r.random() < 0.6      # downsample with use_blur=False raises TypeError in the reference too (video.py:600-615)
+    act = r.choice(['swish', 'swish', 'swish', 'leaky', 'relu', 'gelu'])
+    n, t = r.choice([1, 2]), r.choice([2, 3, 4, 6])
+    h, w = r.choice([(4, 4), (6, 5), (8, 8), (4, 32), (3, 64), (9, 16), (16, 16)])
+    while n * t * h * w * max(cin, cout or cin) > 3_000_000:
+        t = max(2, t - 1)
+        n = 1
+        if t == 2:
+            h = max(2, h // 2)
+    return cin, cout, groups, causal, down, blur, act, (n, t, h, w)
+
+
+@pytest.mark.parametrize('i', range(40))
+def test_video_residual_block_random_geometry(i):
+    from oracle import genie_oracle as O
+    from genie.module.video import VideoResidualBlock
+    cin, cout, groups, causal, down, blur, act, (n, t, h, w) = draw_resblock(i)
+    if down is not None and blur and groups > 1 and ((cin // groups) % 8 != 0 or ((cout or cin) // groups) % 8 != 0):
+        pytest.skip('grouped blur pooling wants 8-channel groups on the HIP path (DESIGN section 7)')
+    torch.manual_seed(i)
+    kw = dict(num_groups=groups, use_causal=causal, downsample=down, use_blur=blur, act_fn=act)
+    m = VideoResidualBlock(cin, cout, **kw)
+    _randomise(m)
+    x = bf16_round(torch.randn(n, cin, t, h, w))
+    tag = f'resblock {cin}->{cout} {kw} @{(n, t, h, w)}'
+    sd_cpu = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    # against the oracle rounding at the HIP path's stores: output 4e-3 (one bf16 ulp on some elements; measured: bit-equal ... 2.5e-3 with GELU), dx 1e-2, parameter gradients 6e-2 (the conv bias in
+    # front of the channel-summing blur + GroupNorm is a cancellation residual: 4-5 % measured; every other one < 2 %) ...
+    errs = _compare_module(m, lambda xx, sd: O.video_residual_block(xx, sd, '', cin, cout, **kw), x, tag, out_tol=4e-3, dx_tol=1e-2, p_tol=6e-2,
+                           rounding='bf16_at_stores')
+    # ... and the representation error against the reference's fp32 arithmetic, output and input gradient only
+    xr = x.clone().requires_grad_(True)
+    ref = O.video_residual_block(xr, sd_cpu, '', cin, cout, **kw)
+    mc = m.cuda()
+    xc = x.cuda().requires_grad_(True)
+    out = mc(xc)
+    g = bf16_round(torch.randn_like(ref))
+    ref.backward(g)
+    out.backward(g.cuda())
+    assert rel_rms(out, ref) < 2e-2 and rel_rms(xc.grad, xr.grad) < 5e-2, (tag, rel_rms(out, ref), rel_rms(xc.grad, xr.grad))
+    errs['out_fp32'], errs['dx_fp32'] = rel_rms(out, ref), rel_rms(xc.grad, xr.grad)
+    report('random_resblock', i=i, cin=cin, cout=cout, size=(n, t, h, w), **kw, out=errs['out'], dx=errs['dx'], out_fp32=errs['out_fp32'], dx_fp32=errs['dx_fp32'],
+           worst_param=max((v for k, v in errs.items() if k not in ('out', 'dx', 'out_fp32', 'dx_fp32')), default=0.0))
+
+
+def draw_resample(i):
+    r = random.Random(17000 + i)
+    cin, cout = r.choice([3, 8, 16, 64, 72, 128]), r.choice([8, 16, 24, 64, 128])
+    tf, sf = r.choice([1, 2]), r.choice([1, 2, 2, 4])
+    up = r.random() < 0.5
+    n, t = r.choice([1, 2]), r.choice([1, 2, 3, 5])
+    h, w = r.choice([(4, 4), (4, 8), (6, 6), (8, 16), (2, 32), (5, 7)])
+    if not up:
+        t, h, w = max(t, tf + 1), h * sf, w * sf
+    return up, cin, cout, tf, sf, (n, t, h, w)
+
+
+@pytest.mark.parametrize('i', range(32))
+def test_spacetime_resample_random_geometry(i):
+    """SpaceTimeDownsample (strided CausalConv3d, video.py:457-483) / DepthToSpaceTimeUpsample (conv to C * tf * sf^2 channels + rearrange, video.py:379-430)."""
+    from oracle import genie_oracle as O
+    from genie.module.video import DepthToSpaceTimeUpsample, SpaceTimeDownsample
+    up, cin, cout, tf, sf, (n, t, h, w) = draw_resample(i)
+    torch.manual_seed(i)
+    cls, ofn = (DepthToSpaceTimeUpsample, O.depth2spacetime_upsample) if up else (SpaceTimeDownsample, O.spacetime_downsample)
+    m = cls(in_channels=cin, out_channels=cout, kernel_size=3, time_factor=tf, space_factor=sf)
+    _randomise(m)
+    x = bf16_round(torch.randn(n, cin, t, h, w))
+    tag = f'{"up" if up else "down"} {cin}->{cout} tf={tf} sf={sf} @{(n, t, h, w)}'
+    errs = _compare_module(m, lambda xx, sd: ofn(xx, sd, '', time_factor=tf, space_factor=sf), x, tag, out_tol=1e-2, dx_tol=1.5e-2, p_tol=1e-2)
+    report('random_resample', i=i, up=up, cin=cin, cout=cout, tf=tf, sf=sf, size=(n, t, h, w), out=errs['out'], dx=errs['dx'])
+
+
+def draw_lfq(i):
+    r = random.Random(21000 + i)
+    d = r.choice([1, 2, 3, 5, 8, 8, 10, 12, 18])
+    ncb = r.choice([1, 1, 1, 2, 3])
+    training = r.random() < 0.6 and d <= 12
+    # input_dim = d * ncb: no projection (what the tokenizer builds); None: the reference's default, 2^d (quantization.py:47) -- kept small here
+    input_dim = r.choice([d * ncb, d * ncb, d * ncb + r.choice([1, 6, 22]), 64, 512] + ([None] if d <= 8 else []))
+    transpose = r.random() < 0.5
+    shape = r.choice([(2, 4, 4, 4), (1, 16, 8, 8), (3, 2, 5, 7), (2, 1, 1, 9), (4, 4, 2, 2)])
+    return d, ncb, training, input_dim, transpose, shape
+
+
+@pytest.mark.parametrize('i', range(40))
+def test_lfq_module_random_geometry(i):
+    """LookupFreeQuantization (quantization.py:32-133) as a module: ids BIT-EXACT and the quantised code exact at the operator boundary (the projected
+    latent the kernel saw), training loss and input gradient against the oracle."""
+    from oracle import genie_oracle as O
+    from genie.module.quantization import LookupFreeQuantization
+    d, ncb, training, input_dim, transpose, (b, t, h, w) = draw_lfq(i)
+    torch.manual_seed(i)
+    m = LookupFreeQuantization(codebook_dim=d, num_codebook=ncb, input_dim=input_dim)
+    project = isinstance(m.proj_inp, torch.nn.Linear)
+    cin = m.proj_inp.in_features if project else d * ncb
+    with torch.no_grad():
+        for p in m.parameters():
+            p.copy_(bf16_round(torch.randn_like(p) * (0.3 if p.dim() == 1 else 1.0 / p.shape[-1] ** 0.5)))
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    x = bf16_round(torch.randn(b, cin, t, h, w) if transpose else torch.randn(b, t, h, w, cin)) * 0.4
+    xr = x.clone().requires_grad_(True)
+    sd_req = {k: (v.clone().requires_grad_(True) if k in dict(m.named_parameters()) else v) for k, v in sd.items()}
+    (o_ref, i_ref), l_ref = O.lfq_forward(xr, sd_req, '', d, ncb, training=training, transpose=transpose)
+    m = m.cuda().train(training)
+    xc = x.cuda().requires_grad_(True)
+    (o_hip, i_hip), l_hip = m(xc, transpose=transpose)
+    assert tuple(o_hip.shape) == tuple(o_ref.shape) and tuple(i_hip.shape) == tuple(i_ref.shape) and i_hip.dtype == i_ref.dtype
+    # ids: equal wherever the projected latent is not within rounding of zero (fp32 Linear on both sides, different summation order)
+    if not project:
+        assert torch.equal(i_hip.cpu(), i_ref), 'LFQ ids differ without a projection in front'
+    else:
+        z = torch.nn.functional.linear(x.movedim(1, -1) if transpose else x, sd['proj_inp.weight'], sd.get('proj_inp.bias'))
+        decided = (z.abs() > 1e-4 * z.abs().max()).reshape(*z.shape[:-1], ncb, d).all(-1)
+        decided = decided.reshape(i_ref.shape) if decided.numel() == i_ref.numel() else decided.squeeze()
+        assert torch.equal(i_hip.cpu()[decided], i_ref[decided]) and decided.float().mean() > 0.9
+    assert rel_rms(o_hip, o_ref) < 1e-2 or (o_hip.float().cpu() - o_ref).abs().max().item() < 2e-2 * o_ref.abs().max().item() + 1e-6
+    if training:
+        assert l_hip is not None and abs(l_hip.item() - l_ref.item()) < 1e-4 + 2e-3 * abs(l_ref.item()), (l_hip.item(), l_ref.item())
+        dy = bf16_round(torch.randn_like(o_ref))
+        (l_ref + (o_ref * dy).sum()).backward()
+        (l_hip + (o_hip.float() * dy.cuda()).sum()).backward()
+        assert rel_rms(xc.grad, xr.grad) < 2e-2, rel_rms(xc.grad, xr.grad)
+    else:
+        assert l_hip is None and l_ref is None
+    report('random_lfq', i=i, d=d, ncb=ncb, training=training, input_dim=input_dim, transpose=transpose, shape=(b, t, h, w))
+
+
+@pytest.mark.parametrize('cin,cout,tf,sf,size', [(16, 8, 1, 4, (1, 2, 4, 4)), (32, 16, 2, 4, (2, 2, 3, 5)), (64, 24, 1, 4, (1, 1, 6, 6)), (16, 8, 2, 3, (1, 2, 4, 4))])
+def test_depth2spacetime_upsample_with_many_sub_pixels(cin, cout, tf, sf, size):
+    """The backward-data pass of an upsample conv gathers through the depth-to-space-time rearrange with (taps x sub-pixels) entries: 27 x 16 = 432 at
+    space_factor 4, 864 with time_factor 2 -- more than the 256 the generic gather's table holds (`genie_conv_igemm: ntaps 432 out of range`, found by the
+    sweep above).  conv_dgrad un-shuffles the gradient and runs the plain 27-tap conv instead whenever the table would overflow."""
+    from oracle import genie_oracle as O
+    from genie.module.video import DepthToSpaceTimeUpsample
+    torch.manual_seed(3)
+    m = DepthToSpaceTimeUpsample(in_channels=cin, out_channels=cout, kernel_size=3, time_factor=tf, space_factor=sf)
+    _randomise(m)
+    n, t, h, w = size
+    x = bf16_round(torch.randn(n, cin, t, h, w))
+    errs = _compare_module(m, lambda xx, sd: O.depth2spacetime_upsample(xx, sd, '', time_factor=tf, space_factor=sf), x,
+                           f'upsample {cin}->{cout} tf={tf} sf={sf}', out_tol=1e-2, dx_tol=1.5e-2, p_tol=1e-2)
+    report('upsample_many_sub_pixels', cin=cin, cout=cout, tf=tf, sf=sf, **{k: v for k, v in errs.items() if k in ('out', 'dx')})
