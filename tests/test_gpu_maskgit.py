@@ -156,7 +156,7 @@ def _check_generate(m, sd, desc, tok, act, u, steps, which, temp, gen_ref=None):
         explained += _explain_draws(torch.softmax(lg / temp, -1), u[step], pred_o, tr['pred'].cpu().reshape(-1), EPS_ULP)
         assert torch.equal(tr['mask_before'].cpu().bool(), mask), f'step {step}: mask state diverged'
         cg = tr['conf'].cpu().reshape(b, n).masked_fill(~mask, -1.)
-        if tr['k'] < n:      # torch.topk's order among equal confidences is unspecified; the kernel's is (lower index first)
+        if tr['k'] < int(mask.sum(-1).min()):      # (with more candidates than picks) torch.topk's order among equal confidences is unspecified; the kernel's is (lower index first)
             top = cg.topk(tr['k'] + 1, -1).values
             assert (top[:, -2] > top[:, -1]).all(), f'step {step}: tied confidences at the top-k boundary (test input too peaked)'
         O.maskgit_paint_step(tr['conf'].cpu().reshape(b, n), tr['pred'].cpu().reshape(b, n), mask, code, tr['k'])

@@ -404,3 +404,146 @@ def test_depth2spacetime_upsample_with_many_sub_pixels(cin, cout, tf, sf, size):
     errs = _compare_module(m, lambda xx, sd: O.depth2spacetime_upsample(xx, sd, '', time_factor=tf, space_factor=sf), x,
                            f'upsample {cin}->{cout} tf={tf} sf={sf}', out_tol=1e-2, dx_tol=1.5e-2, p_tol=1e-2)
     report('upsample_many_sub_pixels', cin=cin, cout=cout, tf=tf, sf=sf, **{k: v for k, v in errs.items() if k in ('out', 'dx')})
+
+
+def draw_blueprint(i):
+    """A random but well-formed (encoder, decoder) blueprint pair in the reference's vocabulary (genie/module/__init__.py:23-93): stem conv, stages of
+    `video-residual` (n_rep, widening, groups, causal or not) with `spacetime_downsample` between them, optionally a `space-time_attn` block at the lowest
+    resolution, GroupNorm + SiLU + 1x1x1 conv to the code; the decoder mirrors it with `adaptive_group_norm(has_ext)` and `depth2spacetime_upsample`."""
+    r = random.Random(31000 + i)
+    c = r.choice([16, 32, 64])
+    d = r.choice([4, 6, 8, 10])
+    enc = [('causal-conv3d', {'in_channels': 3, 'out_channels': c, 'kernel_size': 3})]
+    factors, widths = [], [c]
+    for _ in range(r.choice([1, 2, 2, 3])):
+        c2 = c * 2 if (r.random() < 0.5 and c < 128) else c
+        kw = {'in_channels': c, 'out_channels': c2}
+        if r.random() < 0.4:
+            kw['n_rep'] = 2
+            kw.pop('out_channels')
+            c2 = c
+        if r.random() < 0.3:
+            kw['num_groups'] = r.choice([2, 4, 8])
+        if r.random() < 0.5:
+            kw['use_causal'] = True
+        enc.append(('video-residual', kw))
+        c = c2
+        if r.random() < 0.7:
+            tf, sf = r.choice([(1, 2), (2, 2), (2, 1), (1, 2)])
+            enc.append(('spacetime_downsample', {'in_channels': c, 'out_channels': c, 'kernel_size': 3, 'time_factor': tf, 'space_factor': sf}))
+            factors.append((tf, sf))
+        else:
+            factors.append(None)
+        widths.append(c)
+    attn = r.random() < 0.4
+    if attn:
+        dh = r.choice([16, 32])
+        enc.append(('space-time_attn', {'n_head': c // dh, 'd_head': dh, 'transpose': True}))
+    enc += [('group_norm', {'num_groups': 8, 'num_channels': c}), ('silu', {}), ('causal-conv3d', {'in_channels': c, 'out_channels': d, 'kernel_size': 1})]
+    dec = [('causal-conv3d', {'in_channels': d, 'out_channels': c, 'kernel_size': 3})]
+    if attn:
+        dec.append(('space-time_attn', {'n_head': c // dh, 'd_head': dh, 'transpose': True}))
+    for f, cw in zip(reversed(factors), reversed(widths[:-1])):
+        dec.append(('video-residual', {'in_channels': c}))
+        if r.random() < 0.6:
+            dec.append(('adaptive_group_norm', {'dim_cond': d, 'num_groups': 8, 'num_channels': c, 'has_ext': True}))
+        if f is not None:
+            dec.append(('depth2spacetime_upsample', {'in_channels': c, 'kernel_size': 3, 'time_factor': f[0], 'space_factor': f[1]}))
+        if cw != c:
+            dec.append(('video-residual', {'in_channels': c, 'out_channels': cw}))
+            c = cw
+    dec += [('group_norm', {'num_groups': 8, 'num_channels': c}), ('silu', {}), ('causal-conv3d', {'in_channels': c, 'out_channels': 3, 'kernel_size': 3})]
+    ft = 1
+    fs = 1
+    for f in factors:
+        if f is not None:
+            ft, fs = ft * f[0], fs * f[1]
+    t, hw = ft * r.choice([1, 2, 3]), fs * r.choice([3, 4, 6, 8, 16])
+    return tuple(enc), tuple(dec), d, (r.choice([1, 2]), 3, max(t, 2 if ft == 1 else t), hw, hw)
+
+
+@pytest.mark.parametrize('i', range(32))
+def test_tokenizer_random_blueprints(i):
+    """`VideoTokenizer` built from drawn blueprints: encoder output, LFQ ids at the operator boundary (bit-exact), decoder output from the same code, and the
+    training forward's loss, against the oracle's layer loops (`tokenizer_encode / _decode / _forward_hotpath`): the registry, `parse_blueprint`, `n_rep`,
+    `has_ext` routing and every module pairing nobody wrote a test for."""
+    from oracle import genie_oracle as O
+    from genie import VideoTokenizer
+    enc, dec, d, shape = draw_blueprint(i)
+    torch.manual_seed(i)
+    m = VideoTokenizer(enc, dec, d_codebook=d, gan_loss_weight=0., perc_loss_weight=0.)
+    for n, p in m.named_parameters():
+        if '.std.' in n or '.avg.' in n:
+            torch.nn.init.normal_(p, std=0.3)
+    with torch.no_grad():
+        for p in m.parameters():
+            if p.dim() >= 2:
+                p.copy_(bf16_round(p))
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    m = m.cuda()
+    x = bf16_round(torch.randn(shape))
+    xc = x.cuda()
+    enc_ref = O.tokenizer_encode(x, sd, enc)
+    enc_hip = m.encode(xc)
+    assert tuple(enc_hip.shape) == tuple(enc_ref.shape), (enc, shape)
+    e_enc = rel_rms(enc_hip, enc_ref)
+    assert e_enc < 3e-2, (e_enc, enc)
+    q_hip, idx_hip = m.tokenize(xc)
+    (q_o, idx_o), _ = O.lfq_forward(enc_hip.float().cpu(), sd, 'quant.', d, 1, training=False, transpose=True)
+    assert torch.equal(idx_hip.cpu(), idx_o) and torch.equal(q_hip.float().cpu(), q_o)
+    rec_ref = O.tokenizer_decode(q_o, sd, dec)
+    rec_hip = m.decode(q_hip)
+    assert tuple(rec_hip.shape) == tuple(rec_ref.shape) == tuple(shape), (dec, shape)
+    e_dec = rel_rms(rec_hip, rec_ref)
+    assert e_dec < 4e-2, (e_dec, dec)
+    m.train()
+    loss, _ = m(xc)
+    loss.backward()
+    assert torch.isfinite(loss) and all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters() if p.requires_grad)
+    report('random_blueprint', i=i, layers=(len(enc), len(dec)), d=d, shape=shape, enc=e_enc, dec=e_dec, loss=loss.item())
+
+
+def draw_dynamics(i):
+    r = random.Random(41000 + i)
+    n_head, d_head = r.choice([(2, 16), (2, 32), (4, 16), (1, 64), (2, 64), (4, 32), (8, 8)])
+    vocab = r.choice([64, 256, 1000, 4096, 1 << 14])
+    return (r.choice([1, 2]), n_head, d_head, vocab, r.choice([2, 3, 5, 8]), n_head * d_head,
+            (r.choice([2, 3]), r.choice([2, 3, 5, 6]), r.choice([2, 4, 5, 8]), r.choice([2, 3, 4, 10])),
+            r.choice([3, 5, 7, 10]), r.choice(['linear', 'cosine', 'arccos']), r.choice([0.7, 1.0, 1.3]))
+
+
+@pytest.mark.parametrize('i', range(12))
+def test_dynamics_model_random_configs(i):
+    """`DynamicsModel` on drawn (blocks, heads, vocabulary, action count, token grid, MaskGIT steps / schedule / temperature): logits and the masked
+    cross-entropy against the oracle, and `generate` through tests/test_gpu_maskgit.py's checker (sampler bit-exact on identical logits; every id that
+    differs from the fp32 oracle end to end explained by the logits' noise)."""
+    from oracle import genie_oracle as O
+    from test_gpu_maskgit import _build, _check_generate
+    n_rep, n_head, d_head, vocab, n_act, dim, shape, steps, which, temp = draw_dynamics(i)
+    while int(O.maskgit_schedule(steps, shape[2:], which).min()) < 0:
+        # more steps than positions: `clamp(min=1)` over-asks and the reference's last entry goes NEGATIVE (dynamics.py:187-193) -- its behaviour is then
+        # the tie order of topk among -inf confidences (an already painted position is painted again): not a contract, not swept
+        steps -= 1
+    desc = (('space-time_attn', {'n_rep': n_rep, 'n_head': n_head, 'd_head': d_head}),)
+    m, sd = _build(desc, vocab, n_act, dim, seed=i)
+    torch.manual_seed(300 + i)
+    b, t, h, w = shape
+    tok, act = torch.randint(0, vocab, shape), torch.randint(0, n_act, (b, t))
+    logits, last = m(tok.cuda(), act.cuda())
+    ref, _ = O.dynamics_forward(tok, act, sd, desc)
+    assert tuple(logits.shape) == (b, t, h, w, vocab) and tuple(last.shape) == (b, h, w, vocab)
+    e_logits = rel_rms(logits, ref)
+    assert e_logits < 2e-2, (e_logits, desc, vocab, shape)
+    mask = torch.rand(shape) < 0.7
+    mask[0, 0, 0, 0] = True
+    m.train()
+    loss = m.compute_loss(tok.cuda(), act.cuda(), mask=mask.cuda())
+    loss_ref = O.dynamics_loss(tok, act, mask, sd, desc)
+    assert abs(loss.item() - loss_ref.item()) < 2e-2 * abs(loss_ref.item()) + 1e-3, (loss.item(), loss_ref.item())
+    loss.backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for n, p in m.named_parameters() if 'freq' not in n and p.requires_grad)
+    m.eval()
+    u = torch.rand(steps, b * h * w)
+    match = _check_generate(m, sd, desc, tok, act, u, steps, which, temp)
+    report('random_dynamics', i=i, n_rep=n_rep, heads=(n_head, d_head), vocab=vocab, shape=shape, steps=steps, which=which, temp=temp,
+           logits=e_logits, loss=loss.item(), loss_ref=loss_ref.item(), id_match=match)
