@@ -547,3 +547,50 @@ def test_dynamics_model_random_configs(i):
     match = _check_generate(m, sd, desc, tok, act, u, steps, which, temp)
     report('random_dynamics', i=i, n_rep=n_rep, heads=(n_head, d_head), vocab=vocab, shape=shape, steps=steps, which=which, temp=temp,
            logits=e_logits, loss=loss.item(), loss_ref=loss_ref.item(), id_match=match)
+
+
+def draw_lam(i):
+    r = random.Random(51000 + i)
+    n_head, d_head = r.choice([(2, 16), (2, 32), (4, 16), (1, 64), (4, 32), (2, 64)])
+    c = n_head * d_head
+    d = r.choice([2, 3, 4, 8])
+    st = lambda ext: ('space-time_attn', {'n_head': n_head, 'd_head': d_head, 'transpose': True,
+                                          **({'has_ext': True, 'time_attn_kw': {'key_dim': d}} if ext else {})})
+    down = r.random() < 0.7
+    enc = [st(False)] * r.choice([1, 2])
+    dec = [st(True)]
+    if down:
+        enc = enc + [('spacetime_downsample', {'in_channels': c, 'kernel_size': 3, 'time_factor': 1, 'space_factor': 2}), st(False)]
+        dec = dec + [('depth2spacetime_upsample', {'in_channels': c, 'kernel_size': 3, 'time_factor': 1, 'space_factor': 2}), st(r.random() < 0.7)]
+    hw = r.choice([(8, 8), (16, 16), (8, 16), (4, 12), (32, 32)])
+    return tuple(enc), tuple(dec), d, c, hw, (r.choice([1, 2]), 3, r.choice([2, 3, 5, 8]), *hw)
+
+
+@pytest.mark.parametrize('i', range(12))
+def test_latent_action_random_configs(i):
+    """R-lam (`LatentAction` with the SURVEY 8c repairs) on drawn blueprints / widths / frame sizes / codebooks: the training forward against
+    `oracle.latent_action_forward` -- action ids where the pre-sign latent is decided, reconstruction and quantiser losses -- and a finite backward."""
+    from oracle import genie_oracle as O
+    from genie import LatentAction
+    enc, dec, d, c, hw, shape = draw_lam(i)
+    torch.manual_seed(i)
+    m = LatentAction(enc, dec, d_codebook=d, inp_shape=hw, n_embd=c)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if p.dim() >= 2:
+                p.copy_(bf16_round(p))
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    m = m.cuda().train()
+    x = bf16_round(torch.randn(shape))
+    idxs, loss, (rec_loss, q_loss) = m(x.cuda())
+    tr = {}
+    idx_ref, loss_ref, (rec_ref, q_ref), _ = O.latent_action_forward(x, sd, enc, dec, d, training=True, trace=tr)
+    assert tuple(idxs.shape) == tuple(idx_ref.shape)
+    assert abs(rec_loss.item() - rec_ref.item()) < 4e-2 * abs(rec_ref.item()), (rec_loss.item(), rec_ref.item(), enc, shape)
+    act = tr['act']                                                     # (B, T, d) pre-sign latent of the oracle
+    decided = (act.abs() > 0.03 * act.abs().mean()).all(-1).reshape(idx_ref.shape)        # every bit of the id further from 0 than the latent's noise
+    assert torch.equal(idxs.cpu()[decided], idx_ref[decided]) and decided.float().mean() >= 0.25, (idxs.cpu(), idx_ref, decided)
+    loss.backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for n, p in m.named_parameters() if 'freq' not in n)
+    report('random_lam', i=i, width=c, d=d, shape=shape, layers=(len(enc), len(dec)), rec=rec_loss.item(), rec_ref=rec_ref.item(),
+           ids_decided=decided.float().mean().item())
