@@ -594,3 +594,116 @@ def test_latent_action_random_configs(i):
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for n, p in m.named_parameters() if 'freq' not in n)
     report('random_lam', i=i, width=c, d=d, shape=shape, layers=(len(enc), len(dec)), rec=rec_loss.item(), rec_ref=rec_ref.item(),
            ids_decided=decided.float().mean().item())
+
+
+def draw_conv_options(i):
+    r = random.Random(61000 + i)
+    kind = r.choice(['pad', 'pad', 'groups', 'groups', 'transpose'])
+    if kind == 'groups':
+        g = r.choice([2, 3, 4, 8, 16])
+        cin, cout = g * r.choice([1, 2, 4, 8, 16]), g * r.choice([1, 2, 8, 12])
+    else:
+        g = 1
+        cin, cout = r.choice([8, 16, 24, 64, 128]), r.choice([8, 16, 48, 64, 128])
+    k = r.choice([3, 3, (3, 3, 3), (1, 3, 3), (3, 1, 1), (2, 3, 3)])
+    stride = r.choice([(1, 1, 1), (1, 1, 1), (1, 2, 2), (2, 2, 2), (2, 1, 1)])
+    n, t, h, w = r.choice([1, 2]), r.choice([3, 4, 6]), r.choice([4, 6, 8, 9]), r.choice([4, 5, 8, 16])
+    mode = r.choice(['replicate', 'reflect', 'circular']) if kind == 'pad' else 'constant'
+    return kind, cin, cout, g, k, stride, mode, (n, t, h, w)
+
+
+@pytest.mark.parametrize('i', range(40))
+def test_causal_conv3d_options_random(i):
+    """The less-travelled constructor options on drawn shapes: `pad_mode` (reference video.py:154-192: F.pad(..., mode) then an unpadded conv), `groups`
+    (video.py:168-175) and `causal-conv3d-transpose` (video.py:202-277) -- outputs, input and parameter gradients against those compositions in fp32."""
+    from oracle import genie_oracle as O
+    from genie.module import get_module
+    from genie.module.video import CausalConv3d
+    F = torch.nn.functional
+    kind, cin, cout, g, k, stride, mode, (n, t, h, w) = draw_conv_options(i)
+    kt, kh, kw = (k, k, k) if isinstance(k, int) else k
+    torch.manual_seed(i)
+    x = bf16_round(torch.randn(n, cin, t, h, w))
+    xr = x.clone().requires_grad_(True)
+    if kind == 'transpose':
+        m = get_module('causal-conv3d-transpose')(cin, cout, kernel_size=k, stride=stride)
+        with torch.no_grad():
+            m.weight.copy_(bf16_round(m.weight))
+        wt, bt = m.weight.detach().clone().requires_grad_(True), m.bias.detach().clone().requires_grad_(True)
+        ref = O.causal_conv_transpose3d(xr, wt, bt, stride, (1, 1, 1), None)
+        grads = lambda mm: (mm.weight.grad, mm.bias.grad)
+        out_kw = dict(rel=2 ** -6, rms_frac=4e-3)
+    else:
+        tp = (kt - 1) + (1 - stride[0])
+        if tp < 0 and mode != 'constant':
+            pytest.skip('a negative causal pad with a non-constant pad_mode is not implemented (DESIGN section 7)')
+        if mode in ('reflect', 'circular') and ((kh - 1) // 2 >= h or (kw - 1) // 2 >= w or tp >= t):
+            pytest.skip('padding wider than the image: torch refuses it as well')
+        m = CausalConv3d(cin, cout, k, stride=stride, pad_mode=mode, groups=g)
+        with torch.no_grad():
+            m.conv3d.weight.copy_(bf16_round(m.conv3d.weight))
+        wt, bt = m.conv3d.weight.detach().clone().requires_grad_(True), m.conv3d.bias.detach().clone().requires_grad_(True)
+        pads = ((kw - 1) // 2, (kw - 1) // 2, (kh - 1) // 2, (kh - 1) // 2, tp, 0)
+        ref = F.conv3d(F.pad(xr, pads, mode=mode) if mode != 'constant' else F.pad(xr, pads), wt, bt, stride=stride, groups=g)
+        grads = lambda mm: (mm.conv3d.weight.grad, mm.conv3d.bias.grad)
+        out_kw = {}
+    if ref.numel() == 0:
+        pytest.skip('empty output')
+    dy = bf16_round(torch.randn_like(ref))
+    ref.backward(dy)
+    m = m.cuda()
+    xc = x.cuda().requires_grad_(True)
+    out = m(xc)
+    tag = f'{kind} {cin}->{cout} g={g} k={k} s={stride} {mode} @{(n, t, h, w)}'
+    assert tuple(out.shape) == tuple(ref.shape), tag
+    assert_close_bf16(out, ref, tag, **out_kw)
+    out.backward(dy.cuda())
+    gw, gb = grads(m)
+    errs = {'dx': rel_rms(xc.grad, xr.grad), 'dw': rel_rms(gw, wt.grad), 'db': rel_rms(gb, bt.grad)}
+    assert errs['dx'] < 8e-3 and errs['dw'] < 3e-3 and errs['db'] < 3e-3, (tag, errs)
+    report('random_conv_options', i=i, kind=kind, cin=cin, cout=cout, groups=g, kernel=k, stride=stride, mode=mode, size=(n, t, h, w), **errs)
+
+
+def draw_image_block(i):
+    r = random.Random(71000 + i)
+    cin = r.choice([8, 16, 24, 32, 64, 128])
+    cout = r.choice([None, cin, 16, 32, 64, 128])
+    down = r.choice([None, None, 2]) if cout is not None else None
+    groups = r.choice([g for g in (1, 2, 4, 8) if cin % g == 0 and (cout or cin) % g == 0])
+    n, h, w = r.choice([1, 2, 3]), r.choice([4, 6, 8, 12, 16]), r.choice([4, 6, 8, 10, 32])
+    return dict(inp_channel=cin, out_channel=cout, num_groups=groups, **({'downsample': down} if down else {})), (n, cin, h, w)
+
+
+@pytest.mark.parametrize('i', range(24))
+def test_image_residual_block_random(i):
+    """`image-residual` (reference image.py:105-163; the FrameDiscriminator's block) on drawn widths / groups / sizes, with and without the
+    pixel-unshuffle downsample, against the oracle."""
+    from genie.module.image import ImageResidualBlock
+    from oracle import genie_oracle as O
+    kw, size = draw_image_block(i)
+    torch.manual_seed(i)
+    m = ImageResidualBlock(**kw)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            p.copy_(bf16_round(p) if p.dim() >= 2 else torch.randn_like(p) * 0.3 + (1. if n.endswith('weight') else 0.))
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    m = m.cuda()
+    x = bf16_round(torch.randn(size))
+    xr = x.clone().requires_grad_(True)
+    ref = O.image_residual_block(xr, sd, '', **kw)
+    dy = bf16_round(torch.randn_like(ref))
+    ref.backward(dy)
+    xc = x.cuda().requires_grad_(True)
+    out = m(xc)
+    assert tuple(out.shape) == tuple(ref.shape) and out.dim() == 4
+    e_out = rel_rms(out, ref)
+    assert e_out < 1e-2, (e_out, kw, size)
+    out.backward(dy.cuda())
+    e_dx = rel_rms(xc.grad, xr.grad)
+    assert e_dx < 3e-2, (e_dx, kw, size)
+    rms = lambda v: v.detach().float().pow(2).mean().sqrt().item()
+    floor = 0.02 * sorted(rms(sd[n].grad) for n, _ in m.named_parameters())[len(list(m.parameters())) // 2]
+    for n, p in m.named_parameters():
+        e = rms(p.grad.cpu() - sd[n].grad) / max(rms(sd[n].grad), floor)
+        assert e < (0.2 if p.dim() == 1 else 6e-2), (n, e, kw, size)     # per-channel sums of bf16 gradients over few pixels (the bound of test_gpu_gan.py)
+    report('random_image_block', i=i, size=size, out=e_out, dx=e_dx, **{k: v for k, v in kw.items()})
