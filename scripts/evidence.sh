@@ -90,8 +90,9 @@ PY
       timeout 1500 python scripts/guard_run.py $F1 -q -m gpu -p no:cacheprovider -x 2>&1 | tail -6 > $OUT/${TAG}_guard_order1.log
       timeout 1500 python scripts/guard_run.py $F2 -q -m gpu -p no:cacheprovider -x 2>&1 | tail -6 > $OUT/${TAG}_guard_order2.log
       make -C open-genie_amd probe -j 8 > $OUT/make_probe.log 2>&1      # incremental: rebuilt whenever the sources (or the ABI) moved since the last probe build
+      timeout 900 python scripts/guard_run.py tests/test_gpu_random_geometry.py -q -m gpu -p no:cacheprovider 2>&1 | tail -4 > $OUT/${TAG}_guard_random_geometry.log
       GENIE_GUARD_REGRESSION=1 timeout 600 python -m pytest tests/test_gpu_guard.py -q -m gpu -p no:cacheprovider 2>&1 | tail -4 > $OUT/${TAG}_guard_regression.log
-      for f in $OUT/${TAG}_guard_order1.log $OUT/${TAG}_guard_order2.log $OUT/${TAG}_guard_regression.log; do tail -n 2 $f; done ;;
+      for f in $OUT/${TAG}_guard_order1.log $OUT/${TAG}_guard_order2.log $OUT/${TAG}_guard_random_geometry.log $OUT/${TAG}_guard_regression.log; do tail -n 2 $f; done ;;
     multigpu)
       # first contact with more than one GPU (no gpurun box has had two so far): the plain launcher branch of bench.py, both all-reduce
       # algorithms, fp32 and bf16 payload -> <tag>_bench_gpus2.jsonl with the `comm` object of each; skipped on a one-GPU box
