@@ -267,10 +267,13 @@ class BlurPooling3d(nn.Module):
         # channel of group i is the strided blur of the SUM of group i's input channels -- the one-group kernels on channel-slice views
         # (a CL tensor with a pitch wider than its channel count), one launch pair per group, concatenated.  VideoResidualBlock hands its
         # GroupNorm's num_groups to this module (video.py:592-597), so `video-residual` blueprints with groups AND a downsample land here.
-        if c % g or o % g or (c // g) % 8 or (o // g) % 8:
-            raise NotImplementedError(f'BlurPooling3d: {c} -> {o} channels in {g} groups: groups of a multiple of 8 channels only on the HIP path')
+        if c % g or o % g:
+            raise ValueError(f'BlurPooling3d: {c} -> {o} channels are not divisible into {g} groups (F.conv3d refuses this in the reference)')
         cg, og = c // g, o // g
-        outs = [GF.blur_pool3d(inp[:, i * cg:(i + 1) * cg], self.blur, self.stride, self.padding, og) for i in range(g)]
+        # groups of a multiple of 8 channels are views of the input (16-byte aligned slices); any other width is first copied into a tensor of its own
+        # (`to_cl` of the slice: differentiable, one extra pass over 1 / g of the tensor per group -- round 6; rounds 1-5 raised)
+        piece = (lambda i: inp[:, i * cg:(i + 1) * cg]) if cg % 8 == 0 else (lambda i: to_cl(inp[:, i * cg:(i + 1) * cg]))
+        outs = [GF.blur_pool3d(piece(i), self.blur, self.stride, self.padding, og) for i in range(g)]
         return to_cl(torch.cat(outs, dim=1))
 
     def __repr__(self):

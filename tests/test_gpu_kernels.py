@@ -753,6 +753,32 @@ def test_blur_pool3d(G, c, o, ks, tf, sf, size):
     assert_close_bf16(xd.grad, xr.grad, 'blur pool bwd', rms_frac=4e-3)
 
 
+@pytest.mark.parametrize('c,o,g,tf,sf,size', [(12, None, 3, 2, 2, (2, 4, 6, 6)), (40, 20, 5, 1, 2, (1, 3, 8, 8)), (16, None, 4, 2, 1, (2, 4, 5, 5)),
+                                              (64, 32, 4, 2, 2, (1, 4, 8, 8)), (6, 6, 6, 2, 2, (2, 2, 4, 4))])
+def test_blur_pool3d_groups_of_any_width(G, c, o, g, tf, sf, size):
+    """BlurPooling3d(num_groups = g) (video.py:520-533: F.conv3d(groups = g) with the Pascal kernel repeated over (o, c / g)): every output channel of a
+    group is the strided blur of the SUM of that group's input channels.  Groups of a multiple of 8 channels run on channel-slice views; any other width
+    (rounds 1-5 raised) on an aligned copy of the slice -- forward and backward against the oracle's grouped conv."""
+    from genie.module.video import BlurPooling3d
+    from oracle import genie_oracle as O
+    torch.manual_seed(19)
+    n, t, h, w = size
+    x = bf16_round(torch.randn(n, c, t, h, w))
+    xr = x.clone().requires_grad_(True)
+    ref = O.blur_pool3d(xr, 3, tf, sf, num_groups=g, out_channels=o)
+    dy = bf16_round(torch.randn_like(ref))
+    ref.backward(dy)
+    m = BlurPooling3d(c, 3, out_channels=o, time_factor=tf, space_factor=sf, num_groups=g).cuda()
+    xd = x.cuda().requires_grad_(True)
+    out = m(xd)
+    assert tuple(out.shape) == tuple(ref.shape)
+    assert_close_bf16(out, ref, 'grouped blur pool fwd')
+    out.backward(dy.cuda())
+    assert_close_bf16(xd.grad, xr.grad, 'grouped blur pool bwd', rms_frac=4e-3)
+    with pytest.raises(ValueError):
+        BlurPooling3d(c, 3, num_groups=c + 1).cuda()(x.cuda())
+
+
 def test_residual_block_with_blur_downsample(G):
     """VideoResidualBlock(downsample=...) -- the README / test_tokenizer.py configuration of the reference (video.py:588-648):
     blur pooling in both branches -- forward against the oracle."""
