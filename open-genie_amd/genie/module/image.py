@@ -84,14 +84,12 @@ class LeakyReLU(nn.LeakyReLU):
 
 class BlurPooling2d(nn.Module):
     """reference image.py:44-84: ``conv2d`` with every (out, in / groups) tap equal to the blur kernel, i.e. every output channel
-    is the strided blur of the SUM of its group's input channels.  num_groups = 1 runs on the channel-sum + stencil kernels."""
+    is the strided blur of the SUM of its group's input channels: the channel-sum + stencil kernels, once per group."""
 
     def __init__(self, kernel_size, stride=2, num_groups: int = 1, **kwargs) -> None:
         super().__init__()
         if kwargs:
             raise NotImplementedError(f'BlurPooling2d: extra conv2d arguments {sorted(kwargs)} are not implemented on the HIP path')
-        if num_groups != 1:
-            raise NotImplementedError('BlurPooling2d: num_groups > 1 is not implemented on the HIP path')
         self.register_buffer('blur', get_blur_kernel(kernel_size))
         self.stride, self.kwargs, self.num_groups = stride, kwargs, num_groups
         sh, sw = _pair(stride)
@@ -101,7 +99,17 @@ class BlurPooling2d(nn.Module):
     def forward(self, inp: Tensor) -> Tensor:
         x, was_4d = as_frames(inp)
         sh, sw = _pair(self.stride)
-        y = GF.blur_pool3d(x, self.blur.unsqueeze(0), (1, sh, sw), (0, *self.padding), x.shape[1])
+        c, g = x.shape[1], self.num_groups
+        if g == 1:
+            y = GF.blur_pool3d(x, self.blur.unsqueeze(0), (1, sh, sw), (0, *self.padding), c)
+        else:
+            # conv2d(groups = g): every output channel of a group is the strided blur of the SUM of that group's input channels -- the one-group
+            # kernels per group, on a view of the slice where it is 16-byte aligned and on a copy of it otherwise (as BlurPooling3d, video.py)
+            if c % g:
+                raise ValueError(f'BlurPooling2d: {c} channels are not divisible into {g} groups (conv2d refuses this in the reference)')
+            cg = c // g
+            piece = (lambda i: x[:, i * cg:(i + 1) * cg]) if cg % 8 == 0 else (lambda i: to_cl(x[:, i * cg:(i + 1) * cg]))
+            y = to_cl(torch.cat([GF.blur_pool3d(piece(i), self.blur.unsqueeze(0), (1, sh, sw), (0, *self.padding), cg) for i in range(g)], dim=1))
         return like_input(y, was_4d)
 
 

@@ -82,8 +82,22 @@ def test_blur_pool2d_and_registry():
     ker = m.blur.cpu()[None, None].expand(16, 16, 3, 3)
     ref = torch.nn.functional.conv2d(x, ker, stride=2, padding=m.padding)          # image.py:75-84
     assert_close_bf16(m(x.cuda()), ref, 'blur_pool2d', rms_frac=4e-3)
-    with pytest.raises(NotImplementedError):
-        BlurPooling2d(3, num_groups=2)
+    # num_groups > 1 (conv2d(groups = g), image.py:75-84): aligned groups as views, any other width on a copy of the slice -- forward and backward
+    for c, g, stride in ((16, 2, 2), (12, 3, 2), (10, 5, (1, 2)), (6, 6, 2)):
+        mg = BlurPooling2d(3, stride=stride, num_groups=g).cuda()
+        xg = bf16_round(torch.randn(2, c, 9, 10))
+        xr = xg.clone().requires_grad_(True)
+        kg = mg.blur.cpu()[None, None].expand(c, c // g, 3, 3)
+        rg = torch.nn.functional.conv2d(xr, kg, stride=stride, padding=mg.padding, groups=g)
+        dy = bf16_round(torch.randn_like(rg))
+        rg.backward(dy)
+        xd = xg.cuda().requires_grad_(True)
+        og = mg(xd)
+        assert_close_bf16(og, rg, f'blur_pool2d groups={g}', rms_frac=4e-3)
+        og.backward(dy.cuda())
+        assert_close_bf16(xd.grad, xr.grad, f'blur_pool2d groups={g} dx', rms_frac=4e-3)
+    with pytest.raises(ValueError):
+        BlurPooling2d(3, num_groups=5).cuda()(torch.randn(1, 16, 8, 8, device='cuda'))
 
 
 ENC = (('causal-conv3d', {'in_channels': 3, 'out_channels': 32, 'kernel_size': 3}),
