@@ -479,7 +479,8 @@ int genie_attention_bwd_cond(const void* q, const void* k, const void* v, const 
  * (sequence, head) from the seed), evaluated in registers by the forward and by both backward kernels: no mask is stored, the backward call passes the
  * forward's (dropout_p, seed).  Arguments and contracts otherwise as genie_attention_fwd / genie_attention_bwd; lse is the softmax's, o_attn the DROPPED
  * output (so that D = rowsum(dO o o_attn)).  d_head 32 / 64 / 128 on the general MFMA kernels (the packed, conditioned and lean families take no mask:
- * dropout costs the fast paths, as it does in every flash implementation's bookkeeping); d_head < 32 -> GENIE_ERR_ARG.  dropout_p = 0 is the plain call.
+ * dropout costs the fast paths, as it does in every flash implementation's bookkeeping); d_head 8 / 16 on the fp32 kernels of attention_narrow.hip.
+ * dropout_p = 0 is the plain call.
  * torch's Philox stream cannot be reproduced (and differs between its own backends): parity with the reference is through the mask --
  * genie_attention_dropout_mask writes the decisions out, keep[((seq * nhead + head) * Sq + q) * Sk + k], for the oracle to apply. */
 int genie_attention_fwd_dropout(const void* q, const void* k, const void* v, const void* resid, void* out, void* o_attn, float* lse, int nseq, int nhead,

@@ -806,7 +806,6 @@ static int attention_fwd_impl(const void* q, const void* k, const void* v, const
     const bool drop = dropout_p > 0.f;
     if (drop) {                                             // the general kernels only (the packed, conditioned and lean families take no mask)
         GENIE_CHECK_ARG(dropout_p < 1.f, "genie_attention_fwd_dropout: dropout_p %g not in [0, 1)", (double)dropout_p);
-        GENIE_CHECK_ARG(d_head >= 32, "genie_attention_fwd_dropout: d_head %d < 32 has no dropout path", d_head);
         GENIE_CHECK_ARG((long long)Sq * Sk < (1ll << 32), "genie_attention_fwd_dropout: Sq * Sk must fit 32 bits");
         const AttnDrop d = attn_drop_of(dropout_p, seed);
         a.drop_thr = d.thr; a.drop_key = d.key; a.drop_scale = d.scale;
@@ -1751,7 +1750,6 @@ static int attention_bwd_impl(const void* q, const void* k, const void* v, const
     const bool drop = dropout_p > 0.f;
     if (drop) {
         GENIE_CHECK_ARG(dropout_p < 1.f, "genie_attention_bwd_dropout: dropout_p %g not in [0, 1)", (double)dropout_p);
-        GENIE_CHECK_ARG(d_head >= 32, "genie_attention_bwd_dropout: d_head %d < 32 has no dropout path", d_head);
         GENIE_CHECK_ARG((long long)Sq * Sk < (1ll << 32), "genie_attention_bwd_dropout: Sq * Sk must fit 32 bits");
         const AttnDrop d = attn_drop_of(dropout_p, seed);
         a.drop_thr = d.thr; a.drop_key = d.key; a.drop_scale = d.scale;

@@ -9,6 +9,7 @@
 //             dV_j = sum_i P_ij dO_i  (lane = key);   P_ij = exp(scale * s_ij - lse_i),  dS_ij = P_ij (dO_i . V_j - D_i)
 // Same contracts as the MFMA kernels of attention.hip (address maps, causal = "key <= query", lse / D indexed by token row,
 // self-attention fused to du = dQ + dK + dV); nothing is rounded to bf16 before the final store, and there are no atomics.
+// Dropout (genie_attention_fwd_dropout / _bwd_dropout): the counter-based keep mask of attn_args.h, one evaluation per score.
 #include "attn_args.h"
 #include "genie_hip.h"
 
@@ -45,6 +46,7 @@ __global__ void __launch_bounds__(256) attn_narrow_fwd_kernel(const AttnArgs a) 
     const bf16_t* vb = a.v + seq_base(a.km, seq) + head * DH;
     const int kend = (a.causal && qi + 1 < a.Sk) ? qi + 1 : a.Sk;
     float m = -INFINITY, l = 0.f;
+    const unsigned drop_key = attn_drop_seqkey(a.drop_key, seq, a.nhead, head);
 #pragma unroll 2
     for (int kj = 0; kj < kend; ++kj) {
         float kr[DH], vr[DH];
@@ -54,11 +56,13 @@ __global__ void __launch_bounds__(256) attn_narrow_fwd_kernel(const AttnArgs a) 
         const float mn = fmaxf(m, s);
         const float corr = __expf(m - mn), p = __expf(s - mn);        // first key: exp(-inf) = 0
         l = __builtin_fmaf(l, corr, p);
+        // dropout (genie_attention_fwd_dropout): the row sum is of the undropped weights, the output takes the kept ones (x 1 / (1 - p) below)
+        const float pk = (a.drop_thr && !attn_drop_keep(drop_key, a.drop_thr, qi, kj, a.Sk)) ? 0.f : p;
 #pragma unroll
-        for (int d = 0; d < DH; ++d) o[d] = __builtin_fmaf(o[d], corr, p * vr[d]);
+        for (int d = 0; d < DH; ++d) o[d] = __builtin_fmaf(o[d], corr, pk * vr[d]);
         m = mn;
     }
-    const float inv = l > 0.f ? 1.f / l : 0.f;
+    const float inv = l > 0.f ? a.drop_scale / l : 0.f;
 #pragma unroll
     for (int d = 0; d < DH; ++d) o[d] *= inv;
     const long long orow = seq_base(a.om, seq) + (long long)qi * a.om.pos_stride;
@@ -105,13 +109,16 @@ __global__ void __launch_bounds__(256) attn_narrow_dq_kernel(const AttnBwdArgs a
     const bf16_t* kb = a.k + seq_base(a.km, seq) + head * DH;
     const bf16_t* vb = a.v + seq_base(a.km, seq) + head * DH;
     const int kend = (a.causal && qi + 1 < a.Sk) ? qi + 1 : a.Sk;
+    const unsigned drop_key = attn_drop_seqkey(a.drop_key, seq, a.nhead, head);
 #pragma unroll 2
     for (int kj = 0; kj < kend; ++kj) {
         float kr[DH], vr[DH];
         load_row<DH>(kb + (long long)kj * a.km.pos_stride, kr);
         load_row<DH>(vb + (long long)kj * a.km.pos_stride, vr);
         const float p = __expf(dot<DH>(q, kr) - lse);
-        const float ds = p * (dot<DH>(dO, vr) - D);
+        float dp = dot<DH>(dO, vr);
+        if (a.drop_thr) dp = attn_drop_keep(drop_key, a.drop_thr, qi, kj, a.Sk) ? dp * a.drop_scale : 0.f;      // dS = P o (M dP / (1 - p) - D)
+        const float ds = p * (dp - D);
 #pragma unroll
         for (int d = 0; d < DH; ++d) dq[d] = __builtin_fmaf(ds, kr[d], dq[d]);
     }
@@ -135,6 +142,7 @@ __global__ void __launch_bounds__(256) attn_narrow_dkv_kernel(const AttnBwdArgs 
     const bf16_t* qb = a.q + seq_base(a.qm, seq) + head * DH;
     const long long ob = seq_base(a.om, seq);
     const int qbeg = a.causal ? kj : 0;
+    const unsigned drop_key = attn_drop_seqkey(a.drop_key, seq, a.nhead, head);
 #pragma unroll 2
     for (int qi = qbeg; qi < a.Sq; ++qi) {
         float qr[DH], dO[DH];
@@ -144,10 +152,16 @@ __global__ void __launch_bounds__(256) attn_narrow_dkv_kernel(const AttnBwdArgs 
         const long long tok = orow / a.C;
         const float lse = a.lse[tok * a.nhead + head], D = a.D[tok * a.nhead + head];
         const float p = __expf(dot<DH>(qr, kr) - lse);
-        const float ds = p * (dot<DH>(dO, vr) - D);
+        float dp = dot<DH>(dO, vr), pd = p;
+        if (a.drop_thr) {
+            const bool keep = attn_drop_keep(drop_key, a.drop_thr, qi, kj, a.Sk);
+            dp = keep ? dp * a.drop_scale : 0.f;
+            pd = keep ? p * a.drop_scale : 0.f;
+        }
+        const float ds = p * (dp - D);
 #pragma unroll
         for (int d = 0; d < DH; ++d) {
-            dv[d] = __builtin_fmaf(p, dO[d], dv[d]);
+            dv[d] = __builtin_fmaf(pd, dO[d], dv[d]);
             dk[d] = __builtin_fmaf(ds, qr[d], dk[d]);
         }
     }

@@ -242,8 +242,6 @@ class Attention(nn.Module):
         self.n_head, self.d_head = n_head, d_head
         if not 0.0 <= float(dropout) < 1.0:
             raise ValueError(f'Attention: dropout={dropout} not in [0, 1)')
-        if dropout != 0.0 and d_head < 32:
-            raise NotImplementedError('Attention: dropout needs d_head >= 32 on the HIP path (the d_head 8 / 16 kernels take no mask)')
         self.last_dropout_seed = None                               # the seed of the most recent forward (tests rebuild the mask from it)
 
     def _video_forward(self, video: Tensor, cond: Optional[Tensor], mask, transpose: bool, add_resid: bool) -> Tensor:

@@ -22,7 +22,11 @@ def make_block(n_head, d_head, transpose, seed=0, **kw):
         for n, p in m.named_parameters():
             if 'freq' in n:
                 continue
-            if p.dim() < 2:
+            if n.endswith('attn.norm.weight'):
+                # (round 6) a small LayerNorm gain in front of q = k = v: with gamma ~ 1 the self-score |u|^2 * scale (~ 20) dwarfs the cross scores and
+                # the softmax is the identity, which hides masking errors from every block-level test; here the weights are spread over the keys
+                p.copy_(torch.randn_like(p) * 0.1 + 0.45)
+            elif p.dim() < 2:
                 p.copy_(torch.randn_like(p) * 0.3 + (1.0 if n.endswith('weight') else 0.0))
             else:
                 p.copy_(bf16_round(torch.randn_like(p) * (0.02 if p.dim() == 5 else 0.3)))

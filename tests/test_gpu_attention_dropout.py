@@ -58,6 +58,9 @@ def test_dropout_mask_is_bernoulli_and_keyed(p):
     (2, 1, 128, 130, 130, False, True, 0.2),
     (3, 2, 64, 96, 40, False, False, 0.25),           # separate K / V rows, Sq != Sk
     (2, 2, 32, 33, 150, False, False, 0.4),
+    (3, 4, 16, 50, 50, True, True, 0.3),              # narrow heads: the fp32 kernels of attention_narrow.hip (the reference's own small blueprints are 4 x 16)
+    (2, 2, 8, 40, 21, False, False, 0.25),
+    (5, 4, 16, 10, 10, True, True, 0.5),
 ])
 def test_attention_dropout_through_the_c_abi(nseq, nhead, dh, sq, sk, causal, self_attn, p):
     """genie_attention_fwd_dropout / genie_attention_bwd_dropout against fp32 softmax attention with the exported mask applied, and autograd of it."""
@@ -134,12 +137,12 @@ def test_dropout_refuses_what_it_cannot_do():
     u = torch.zeros(1, 8, 32, dtype=torch.bfloat16, device='cuda')
     o = torch.empty_like(u)
     m = _hip.i64((1, 8 * 32, 0, 32))
-    assert lib.genie_attention_fwd_dropout(P(u), P(u), P(u), None, P(o), None, None, 1, 2, 16, 8, 8, m, m, m, 0.25, 0, 32, 0.5, 1, _hip.stream_ptr()) != 0   # d_head 16
     assert lib.genie_attention_fwd_dropout(P(u), P(u), P(u), None, P(o), None, None, 1, 1, 32, 8, 8, m, m, m, 0.25, 0, 32, 1.0, 1, _hip.stream_ptr()) != 0   # p = 1
     assert lib.genie_attention_fwd_dropout(P(u), P(u), P(u), None, P(o), None, None, 1, 1, 32, 8, 8, m, m, m, 0.25, 0, 32, -0.1, 1, _hip.stream_ptr()) != 0
 
 
-@pytest.mark.parametrize('kind,n_head,d_head,thw,p', [('space', 2, 64, (3, 12, 12), 0.2), ('time', 4, 32, (12, 4, 5), 0.3), ('space', 2, 32, (2, 6, 7), 0.5)])
+@pytest.mark.parametrize('kind,n_head,d_head,thw,p', [('space', 2, 64, (3, 12, 12), 0.2), ('time', 4, 32, (12, 4, 5), 0.3), ('space', 2, 32, (2, 6, 7), 0.5),
+                                                      ('space', 4, 16, (2, 8, 8), 0.3), ('time', 4, 16, (9, 3, 4), 0.2)])
 def test_attention_module_with_dropout_matches_oracle(kind, n_head, d_head, thw, p):
     """SpatialAttention / TemporalAttention(dropout=p) against the oracle's spatial_attention / temporal_attention with the module's own mask (rebuilt from
     `last_dropout_seed`): output, input gradient, LayerNorm gradients.  Eval mode drops as well (the reference hands `dropout_p` to the FUNCTIONAL sdpa)."""
@@ -147,10 +150,13 @@ def test_attention_module_with_dropout_matches_oracle(kind, n_head, d_head, thw,
     from genie.module.attention import SpatialAttention, TemporalAttention
     torch.manual_seed(11)
     cls, ofn = (SpatialAttention, O.spatial_attention) if kind == 'space' else (TemporalAttention, O.temporal_attention)
-    m = cls(n_head=n_head, d_head=d_head, transpose=True, dropout=p)
+    # (TemporalAttention is causal only where SpaceTimeAttention builds it, attention.py:409-424; the oracle's temporal_attention IS that use)
+    m = cls(n_head=n_head, d_head=d_head, transpose=True, dropout=p, **({'causal': True} if kind == 'time' else {}))
     with torch.no_grad():
-        m.norm.weight.copy_(torch.randn_like(m.norm.weight) * 0.3 + 1.0)
-        m.norm.bias.copy_(torch.randn_like(m.norm.bias) * 0.3)
+        # a small LayerNorm gain: with gamma ~ 1 the self-score |u|^2 * scale (~ 20) dwarfs the cross scores and softmax is the identity -- a test
+        # through which a wrong mask (or a missing causal flag: the first version of this test) passes; here the weights are spread over the keys
+        m.norm.weight.copy_(torch.randn_like(m.norm.weight) * 0.1 + 0.45)
+        m.norm.bias.copy_(torch.randn_like(m.norm.bias) * 0.2)
     sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
     m = m.cuda()
     c = n_head * d_head
@@ -179,7 +185,7 @@ def test_attention_module_with_dropout_matches_oracle(kind, n_head, d_head, thw,
     assert m.last_dropout_seed == seed and torch.equal(again, out.detach())
     other = m(x.cuda())
     assert m.last_dropout_seed != seed and rel_rms(other, out) > 0.05
-    plain = cls(n_head=n_head, d_head=d_head, transpose=True)
+    plain = cls(n_head=n_head, d_head=d_head, transpose=True, **({'causal': True} if kind == 'time' else {}))
     plain.load_state_dict(sd)
     plain = plain.cuda()
     m.eval()

@@ -299,8 +299,8 @@ def test_linear_ce_plan_fills_whole_rounds():
 
 
 def test_attention_dropout_argument_contract():
-    """Attention(dropout=...) (reference attention.py:166-198): any rate in [0, 1) constructs and is handed down by SpaceTimeAttention; what the HIP
-    path cannot do says so at construction (d_head 8 / 16 kernels take no mask), not at the first step."""
+    """Attention(dropout=...) (reference attention.py:166-198): any rate in [0, 1) constructs and is handed down by SpaceTimeAttention, for every head
+    width the path supports; a rate outside [0, 1) is refused at construction."""
     from genie.module.attention import SpaceTimeAttention, SpatialAttention
     m = SpaceTimeAttention(n_head=2, d_head=32, dropout=0.25)
     assert m.space_attn.dropout == 0.25 and m.temp_attn.dropout == 0.25 and m.space_attn.last_dropout_seed is None
@@ -309,5 +309,4 @@ def test_attention_dropout_argument_contract():
         SpatialAttention(n_head=2, d_head=32, dropout=1.0)
     with pytest.raises(ValueError):
         SpatialAttention(n_head=2, d_head=32, dropout=-0.1)
-    with pytest.raises(NotImplementedError):
-        SpatialAttention(n_head=2, d_head=16, dropout=0.1)
+    assert SpatialAttention(n_head=2, d_head=16, dropout=0.1).dropout == 0.1          # narrow heads too (attention_narrow.hip)
