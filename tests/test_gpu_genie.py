@@ -146,6 +146,10 @@ def test_genie_configs4_size_parity():
         for n, p in g.named_parameters():
             if p.dim() >= 2:
                 p.copy_(bf16_round(p))
+            elif n.endswith('attn.norm.weight'):
+                # (round 6) LayerNorm gain 0.45 in front of q = k = v: with gamma ~ 1 the self-score makes softmax attention the identity at every
+                # sequence length of this test, and the attention kernels would be checked on their diagonal only
+                p.copy_(torch.randn_like(p) * 0.1 + 0.45)
             elif ('norm' in n or '.net.0.' in n) and 'latent_action' in n:
                 p.copy_(torch.randn_like(p) * 0.2 + (1.0 if n.endswith('weight') else 0.0))     # non-trivial affine terms
     sd_tok = {k: v.detach().clone() for k, v in g.tokenizer.state_dict().items()}

@@ -24,6 +24,10 @@ def build_lam(enc, dec, d, shape, n_embd, seed):
                 continue
             if p.dim() >= 2:
                 p.copy_(bf16_round(p))
+            elif n.endswith('attn.norm.weight'):
+                # (round 6) LayerNorm gain 0.45 in front of q = k = v: with gamma ~ 1 the self-score makes softmax attention the identity at every
+                # sequence length of this test, and the attention kernels would be checked on their diagonal only
+                p.copy_(torch.randn_like(p) * 0.1 + 0.45)
             elif 'norm' in n or '.net.0.' in n:
                 p.copy_(torch.randn_like(p) * 0.2 + (1.0 if n.endswith('weight') else 0.0))     # non-trivial affine terms
     sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
