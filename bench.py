@@ -465,6 +465,20 @@ def main():
         kern = {k: {'launches': v['launches'], 'ms_per_step': round(v['ms'] / args.steps, 3),
                     'tflops': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2) if v['ms'] > 0 else None} for k, v in summ.items()}
         out['conv_kernels'] = kern
+        # the stem / head CausalConv3d launches INSIDE the timed region (HIP events around five launches per step), on SURVEY 8(d)'s bytes:
+        # (3 + 128) channels x 2 B per pixel + the weight tensor.  The stand-alone figures under `hbm_kernels` depend on what ran on the chip
+        # before them (the head forward read 0.54 or 0.59 in the same process on the same box); these are the rates the training step sees.
+        npx = B * 16 * 64 * 64
+        nb = npx * (3 + 128) * 2 + 128 * 3 * 27 * 2
+        in_step = {}
+        for var in ('conv_narrow_in_kernel', 'conv_narrow_out_kernel', 'conv_narrow_wgrad_kernel'):
+            for label, b in summ.get(var, {}).get('by_label', {}).items():
+                if b['launches'] and b['ms'] > 0:
+                    ms1 = b['ms'] / b['launches']
+                    in_step[f'{var} | {label}'] = {'launches': b['launches'], 'ms': round(ms1, 5), 'gbps': round(nb / ms1 / 1e6, 1), 'hbm_frac': round(nb / ms1 / 1e6 / 8000.0, 4)}
+        if in_step:
+            out['causal_conv3d_in_step'] = {'peak_gbps': 8000.0, 'bytes_per_launch': nb, 'bytes': 'SURVEY 8(d): (3 + 128) channels x 2 B x pixels + weights, per launch of %d clips' % B,
+                                            'kernels': in_step}
         if args.dump:
             os.makedirs(os.path.dirname(args.dump) or '.', exist_ok=True)
             with open(args.dump, 'w') as f:

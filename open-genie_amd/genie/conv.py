@@ -30,11 +30,17 @@ class LaunchProfiler:
     """Optional per-launch HIP-event timing of the conv kernels (bench.py's roofline leg).  Events are recorded
     on the stream the kernels are launched on; nothing is synchronised until ``summary()``."""
 
-    def __init__(self, only_triple: bool = False) -> None:
+    def __init__(self, only_triple: bool = False, narrow: bool = True) -> None:
         self.records = []          # (variant, label, flops, start_event, end_event)
         # only_triple: time only the forward / backward-data launches that carry a kw-triple schedule (the dominant kernel).
         # Two events around each of the ~360 conv launches of a step cost ~4 % of the step; around these ~100, under 1 %.
         self.only_triple = only_triple
+        # narrow: the stem / head convs' HBM-bound launches too (five per step: their in-step rate is the one that counts -- a stand-alone
+        # microbench of the head forward read 0.54 or 0.59 of 8 TB/s depending on what had run on the chip before it)
+        self.narrow = narrow
+
+    def times_narrow(self) -> bool:
+        return self.narrow or not self.only_triple
 
     def begin(self):
         ev = torch.cuda.Event(enable_timing=True)
@@ -428,7 +434,7 @@ def conv_narrow_wgrad(x: Tensor, dy: Tensor, spec: ConvSpec, dweight: Tensor, db
         if dbias is not None:
             dbias += db_c
         return
-    t0 = PROFILER.begin() if PROFILER is not None and not PROFILER.only_triple else None
+    t0 = PROFILER.begin() if PROFILER is not None and PROFILER.times_narrow() else None
     # straight into dW / db (the kernel's epilogue knows both parameter layouts): no G tile to zero, no scatter, no torch reduction for the head's bias
     wide = spec.cout if stem else spec.cin
     if wide == 128:
@@ -463,7 +469,7 @@ def conv_narrow_out(x: Tensor, pack: Tensor, bias: Optional[Tensor], cout: int, 
     n, c, t, h, w = x.shape
     out = empty_cl(n, cout, t, h, w, x.device, zero_pad=False)           # the kernel writes whole 8-channel pixels (pad channels zero)
     b32 = None if bias is None else bias.detach().float().contiguous()
-    t0 = PROFILER.begin() if PROFILER is not None and not PROFILER.only_triple else None
+    t0 = PROFILER.begin() if PROFILER is not None and PROFILER.times_narrow() else None
     _hip.check(_hip.load_library().genie_conv_narrow_out(x.data_ptr(), pack.data_ptr(), _hip.ptr(b32), out.data_ptr(), n, t, h, w, cout, int(t_lo),
                                                          _hip.stream_ptr()), 'genie_conv_narrow_out')
     if t0 is not None:
@@ -477,7 +483,7 @@ def conv_narrow_in(x: Tensor, pack: Tensor, t_lo: int, label: str = '') -> Tenso
     n, c, t, h, w = x.shape
     cout = pack.shape[0]
     out = empty_cl(n, cout, t, h, w, x.device)
-    t0 = PROFILER.begin() if PROFILER is not None and not PROFILER.only_triple else None
+    t0 = PROFILER.begin() if PROFILER is not None and PROFILER.times_narrow() else None
     for c0 in range(0, cout, 128):
         _hip.check(_hip.load_library().genie_conv_narrow_in(x.data_ptr(), pitch_of(x), pack[c0:c0 + 128].data_ptr(), out.data_ptr() + 2 * c0, pitch_of(out), n, t, h, w,
                                                             int(t_lo), _hip.stream_ptr()), 'genie_conv_narrow_in')
