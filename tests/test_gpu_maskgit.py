@@ -131,6 +131,8 @@ def _build(desc, tok_vocab, act_vocab, embed_dim, sd=None, seed=0, head_gain=2.)
             for n_, p in m.named_parameters():
                 if 'freq' not in n_ and p.dim() >= 2:
                     p.copy_(bf16_round(p * (head_gain if 'head' in n_ else 1.)))
+                elif n_.endswith('attn.norm.weight'):
+                    p.fill_(0.45)        # (round 6) spread softmax: with gamma = 1 the self-score makes q = k = v attention the identity and masks go untested
         sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
     return m.cuda().eval(), sd
 
